@@ -1,0 +1,277 @@
+/*
+ * vlfb.h -- C ABI of libvlfb_hip.so, the MI355X (gfx950) kernel library behind the
+ * R50/R101-I3D-NL + long-term-feature-bank training path.
+ *
+ * The reference (facebookresearch/video-long-term-feature-banks) reaches its GPU code
+ * through the Caffe2 operator registry; Caffe2 is gone, so this header IS the plug-in
+ * boundary.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / HIP types in signatures (vlfb_stream_t is a
+ *     hipStream_t passed as void*).
+ *   - the caller owns every buffer; kernels are asynchronous on `stream`; the library
+ *     allocates nothing and keeps no mutable global state besides a thread-local error string.
+ *   - every function returns VLFB_OK (0) or a negative error code; vlfb_last_error() gives text.
+ *   - "NCTHW" = the reference's blob layout (kwargs['order']='NCHW',
+ *     lib/models/model_builder_video.py:69).  "NTHWC" = this library's internal
+ *     channels-last activation layout (rows = N*T*H*W positions, C contiguous).
+ *   - element types: VLFB_F32 (parity path, fp32 MFMA) and VLFB_BF16 (throughput path,
+ *     bf16 MFMA with fp32 accumulation).
+ */
+#ifndef VLFB_H_
+#define VLFB_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vlfb_stream_t;
+
+enum { VLFB_F32 = 0, VLFB_BF16 = 1 };
+
+enum {
+  VLFB_OK = 0,
+  VLFB_ERR_ARG = -1,
+  VLFB_ERR_LAUNCH = -2,
+  VLFB_ERR_UNSUPPORTED = -3,
+  VLFB_ERR_WORKSPACE = -4
+};
+
+const char* vlfb_last_error(void);
+int vlfb_version(void);
+/* number of bytes per element of a VLFB_* dtype (0 if unknown) */
+int vlfb_dtype_size(int dtype);
+
+/* ------------------------------------------------------------------------------------------
+ * AffineNd / AffineNdGradient -- the reference's only native op, on its own layout.
+ * Replaces REGISTER_CUDA_OPERATOR(AffineNd, ...) / (AffineNdGradient, ...)
+ *   caffe2_customized_ops/video/affine_nd_op.cu:31-44,61-83  (y = x*s[c] + b[c])
+ *   caffe2_customized_ops/video/affine_nd_op.cu:46-58,85-104 (dx = dy*s[c]; no ds/db)
+ * x,y: fp32 NCTHW with `inner` = T*H*W elements per (n,c); in-place allowed (x==y, dy==dx)
+ * as in the schema (affine_nd_op.cc:35-43).  numel must be < 2^31 as in the reference.
+ * ------------------------------------------------------------------------------------------ */
+int vlfb_affine_nd_fwd(const float* x, const float* scale, const float* bias, float* y,
+                       int64_t n, int64_t c, int64_t inner, vlfb_stream_t stream);
+int vlfb_affine_nd_bwd(const float* dy, const float* scale, float* dx,
+                       int64_t n, int64_t c, int64_t inner, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM 3-D convolution family (MFMA), channels-last.
+ * Replaces every cuDNN `Conv` the builders emit (ModelBuilder.ConvNd call sites:
+ * lib/models/model_builder_video.py:181,211; resnet_video.py:169; nonlocal_helper.py:36,58,68,131;
+ * lib/models/lfb_helper.py:175,184,194,244,303,323), its auto-generated ConvGradient
+ * (dgrad + wgrad), and the cuBLAS BatchMatMul calls (nonlocal_helper.py:94,121) -- a plain or
+ * batched GEMM is the 1x1x1 special case.
+ *
+ * mode FPROP:  O[m][n]  = sum_{tap,c} A[src(m,tap)][c] * B[n][tap][c]
+ *              rows m enumerate the OUTPUT positions (N,Tr,Hr,Wr);
+ *              src(m,tap) = m*stride - pad + tap*dil, inside (Ts,Hs,Ws) else 0.
+ * mode DGRAD:  same contraction, rows m enumerate the conv's INPUT positions (N,Tr,Hr,Wr) and
+ *              A is the output-gradient (N,Ts,Hs,Ws,Cs): src = (m + pad - tap*dil)/stride when
+ *              divisible and in range else 0; B is the weight in [Cin][tap][Cout] order.
+ * mode WGRAD:  O[p][tap][c] = sum_m P[m][p] * A[src(m,tap)][c]
+ *              (m = output positions; P = output gradient [M][Cn]; A = the conv input).
+ *              If the launch is split along m, fp32 partial slabs go to `workspace` and
+ *              vlfb_conv_wgrad_reduce must follow (vlfb_conv_run does it when it is given
+ *              a workspace).
+ * pack_w:      stem mode (conv1, Cs = 4 padded RGB): the kw taps are packed with the channel
+ *              dim into the contiguous K axis, K = kt*kh*(kw_pad*Cs); requires dw == 1.
+ * epilogue (FPROP/DGRAD): v = alpha*acc + bias + R[m][n]; relu; then v = (Mask[m][n] > 0) ? v : 0
+ * epilogue (WGRAD):       v = alpha * rowscale[p] * acc (+ O if accumulate)
+ * ------------------------------------------------------------------------------------------ */
+enum { VLFB_CONV_FPROP = 0, VLFB_CONV_DGRAD = 1, VLFB_CONV_WGRAD = 2 };
+enum { VLFB_BIAS_NONE = 0, VLFB_BIAS_COL = 1, VLFB_BIAS_ROW = 2 };
+
+typedef struct vlfb_conv_desc {
+  int32_t mode;
+  int32_t dtype;      /* operand element type of A, B(,P), R, Mask */
+  int32_t out_dtype;  /* VLFB_F32 or == dtype */
+  /* row space (see mode) */
+  int32_t N, Tr, Hr, Wr;
+  /* gather-source extents and channels (per tap K extent = Cs, or kw_pad*Cs with pack_w) */
+  int32_t Ts, Hs, Ws, Cs;
+  int32_t kt, kh, kw;
+  int32_t st, sh, sw;
+  int32_t pt, ph, pw;
+  int32_t dt, dh, dw;
+  int32_t pack_w;     /* 0, or kw_pad (padded kw, power of two) */
+  /* FPROP/DGRAD: number of output columns; WGRAD: channels of P (output rows) */
+  int32_t Cn;
+  /* leading dimensions in elements (0 = dense default) */
+  int32_t lda;        /* A position stride            (default Cs)            */
+  int32_t ldb;        /* B row stride                 (default K)             */
+  int32_t ldo;        /* O row stride                 (default Cn, WGRAD: K)  */
+  int32_t ldr;        /* R / Mask row stride          (default ldo)           */
+  int32_t ldp;        /* WGRAD: P position stride     (default Cn)            */
+  /* batched GEMM (blockIdx.z); strides in elements */
+  int32_t batch;
+  int64_t a_bstride, b_bstride, o_bstride, r_bstride, p_bstride;
+  /* epilogue */
+  float alpha;
+  int32_t relu;
+  int32_t bias_mode;
+  int32_t accumulate; /* WGRAD only: O += ... */
+  int32_t splits;     /* WGRAD only: 0 = library chooses */
+} vlfb_conv_desc;
+
+/* fills the desc with zeros and safe defaults (1x1x1, stride 1, alpha 1, batch 1) */
+void vlfb_conv_desc_init(vlfb_conv_desc* d);
+/* bytes of fp32 workspace vlfb_conv_run needs for this desc (0 unless a split WGRAD) */
+int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d);
+/* A: activation / gradient operand; B: weight operand (FPROP/DGRAD) or unused (WGRAD);
+ * P: WGRAD output-gradient operand; O: output; bias/rowscale: fp32 vectors or NULL;
+ * R, Mask: optional, dtype elements. */
+int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void* B, const void* P, void* O,
+                  const float* bias, const float* rowscale, const void* R, const void* Mask,
+                  void* workspace, int64_t workspace_bytes, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / dtype movers at the boundary.
+ * ------------------------------------------------------------------------------------------ */
+/* fp32 NCTHW (the `data` blob, lib/datasets/ava_data_input.py:143-161) -> NTHWC with C padded
+ * to c_pad (zeros) in `dtype`. */
+int vlfb_ncthw_to_nthwc(const float* src, void* dst, int dtype, int64_t n, int64_t c, int64_t thw,
+                        int64_t c_pad, vlfb_stream_t stream);
+/* NTHWC `dtype` -> fp32 NCTHW (for FetchBlob of activations / gradients) */
+int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64_t n, int64_t c, int64_t thw,
+                        vlfb_stream_t stream);
+/* generic cast fp32 <-> dtype, n elements */
+int vlfb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
+              vlfb_stream_t stream);
+/* batched 2-D transpose of dtype elements: dst[b][j][i] = src[b][i][j], src is rows x cols */
+int vlfb_transpose2d(const void* src, void* dst, int dtype, int64_t batch, int64_t rows,
+                     int64_t cols, vlfb_stream_t stream);
+/* Weight preparation: fp32 master W[Cout][taps][Cin] (kernel K-order) and the frozen affine
+ * scale s[Cout] (may be NULL = 1) -> operand copies in `dtype`:
+ *   w_fprop[Cout][taps][Cin] = W*s          (B operand of FPROP)
+ *   w_dgrad[Cin][taps][Cout] = W*s          (B operand of DGRAD; may be NULL)
+ * Folding the frozen scale is exact algebra: affine(conv(x,W)) = conv(x, W*s) + b
+ * (affine_nd_op.cu:31-44 has no gradient for s, affine_nd_op.cc:45-53). */
+int vlfb_weight_prep(const float* w, const float* scale, void* w_fprop, void* w_dgrad, int dtype,
+                     int64_t cout, int64_t taps, int64_t cin, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pools (channels-last).  Replace Caffe2 MaxPool / AveragePool:
+ * resnet_video.py:190,219; nonlocal_helper.py:49; head_helper.py:37,92,113; lfb_helper.py:112,124.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlfb_pool_desc {
+  int32_t dtype;
+  int32_t N, Ti, Hi, Wi, C;
+  int32_t To, Ho, Wo;
+  int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+} vlfb_pool_desc;
+/* y[N,To,Ho,Wo,C]; argmax (uint8 tap index inside the window, first maximum in t,h,w scan
+ * order) may be NULL in inference. */
+int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, uint8_t* argmax,
+                     vlfb_stream_t stream);
+/* dx = (accumulate ? add : 0) + scatter(dy) ; then dx = (mask > 0) ? dx : 0 when mask != NULL.
+ * `add` may alias dx. Gather formulation: deterministic, no atomics. */
+int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const uint8_t* argmax, void* dx,
+                     const void* add, const void* mask, vlfb_stream_t stream);
+/* average over the window (pad 0 only, as every AveragePool in the reference) */
+int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream);
+int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* dx, const void* add,
+                     const void* mask, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row softmax with pre-scale: P[r][:] = softmax(scale * S[r][:]).
+ * Replaces Scale + Softmax(axis=2, engine=CUDNN): nonlocal_helper.py:98-104, lfb_helper.py:227-230.
+ * S is fp32 (the affinity is kept in fp32 on both paths); P is `dtype`.
+ * bwd: dS[r][:] = scale * P .* (dP - sum(dP .* P)), dP fp32, dS `dtype`.
+ * ------------------------------------------------------------------------------------------ */
+int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows, int64_t cols, float scale,
+                     vlfb_stream_t stream);
+int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dtype, int64_t rows,
+                     int64_t cols, float scale, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small elementwise / reduction ops (rows x cols matrices of `dtype`, cols contiguous).
+ * ------------------------------------------------------------------------------------------ */
+/* y = a + b (optionally relu, optionally masked by mask>0); any of y,a,b may alias.
+ * Replaces Sum (+Relu): resnet_helper.py:112-117; nonlocal_helper.py:170,201; lfb_helper.py:286 */
+int vlfb_add(const void* a, const void* b, void* y, const void* mask, int dtype, int64_t n,
+             int relu, vlfb_stream_t stream);
+/* y = relu(x); dx = (y>0) ? dy : 0  (model_builder_video.py:169-174) */
+int vlfb_relu_fwd(const void* x, void* y, int dtype, int64_t n, vlfb_stream_t stream);
+int vlfb_relu_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n,
+                  vlfb_stream_t stream);
+/* colsum[c] (+)= sum_r g[r][c] -- bias gradients of the convs that carry a bias
+ * (nonlocal_helper.py:36-77, lfb_helper.py:175-200, resnet_video.py:327) */
+int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out,
+                int accumulate, vlfb_stream_t stream);
+/* LayerNorm over each row, no learnable scale/bias, eps inside sqrt (lfb_helper.py:160-166,
+ * 252-256; Caffe2 LayerNorm axis=1).  rstd[r] = 1/sqrt(var+eps) saved for backward. */
+int vlfb_layernorm_fwd(const void* x, void* y, float* rstd, int dtype, int64_t rows, int64_t cols,
+                       float eps, vlfb_stream_t stream);
+int vlfb_layernorm_bwd(const void* dy, const void* y, const float* rstd, void* dx, int dtype,
+                       int64_t rows, int64_t cols, vlfb_stream_t stream);
+/* Dropout (lfb_helper.py:259,314,334; resnet_video.py:323): counter-based mask
+ * keep(i) = u(seed, i) >= ratio with u from vlfb's mix32 generator over the REFERENCE-layout
+ * linear index i; y = keep ? x/(1-ratio) : 0.  The mask is written as bytes for backward.
+ * Logical tensor is (rows, ch, inner) in reference order [(r*ch + c)*inner + k] while the
+ * data is stored [(r*inner + k)*ch + c] (channels-last). */
+int vlfb_dropout_fwd(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows, int64_t inner,
+                     int64_t ch, float ratio, uint64_t seed, vlfb_stream_t stream);
+int vlfb_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dtype, int64_t n,
+                     float ratio, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FC + loss.  Replace FC, Sigmoid, SigmoidCrossEntropyLoss (resnet_video.py:327-338).
+ * ------------------------------------------------------------------------------------------ */
+/* logits[r][k] = sum_c x[r][c] * w[k][c] + b[k]; x `dtype`, w/b fp32 master, logits fp32 */
+int vlfb_fc_fwd(const void* x, int dtype, const float* w, const float* b, float* logits,
+                int64_t rows, int64_t cin, int64_t cout, vlfb_stream_t stream);
+/* dx[r][c] = sum_k dl[r][k]*w[k][c] ; dw[k][c] (+)= sum_r dl[r][k]*x[r][c]; db[k] (+)= sum_r dl */
+int vlfb_fc_bwd(const void* x, int dtype, const float* w, const float* dlogits, void* dx,
+                float* dw, float* db, int64_t rows, int64_t cin, int64_t cout, int accumulate,
+                vlfb_stream_t stream);
+/* prob = sigmoid(logits); loss = scale * sum(l) / max(#(t>=0),1) with
+ * l = -x*(t - (x>=0)) + log(1 + exp(x - 2x*(x>=0))), t in {0,1} (or -1 = ignore);
+ * dlogits = scale * (prob - t) / normalizer (0 where ignored).  loss: 1 float. */
+int vlfb_sigmoid_ce(const float* logits, const int32_t* labels, float* prob, float* loss,
+                    float* dlogits, int64_t rows, int64_t cols, float scale, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RoI head.  Replaces RoIAlign + 7x7 MaxPool (head_helper.py:88-123, lfb_helper.py:130-152).
+ * feat: [N,H,W,C] channels-last `dtype`; rois: fp32 (R,5) = [batch_idx, x1,y1,x2,y2];
+ * out: [R,C] = max over the pooled x pooled RoIAlign bins; argbin: uint8 [R,C].
+ * dbg (optional, int32 [R][pooled][pooled][8]) receives the integer decisions of the first
+ * sample of every bin: {batch, grid_h, grid_w, y_low, x_low, y_high, x_high, inside}.
+ * ------------------------------------------------------------------------------------------ */
+int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* rois, void* out,
+                           uint8_t* argbin, int32_t* dbg, int64_t n, int64_t h, int64_t w,
+                           int64_t c, int64_t r, int pooled, float spatial_scale,
+                           vlfb_stream_t stream);
+/* dfeat (fp32 [N,H,W,C], must be zeroed by the caller) += scatter of dout through argbin */
+int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois, const uint8_t* argbin,
+                           float* dfeat, int64_t n, int64_t h, int64_t w, int64_t c, int64_t r,
+                           int pooled, float spatial_scale, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FBO-NL attention core for one query per row (lfb_helper.py:170-263, num_feat1 == 1):
+ *   aff[r][k] = scale * <theta[r], phi[r][k]>, p = softmax_k(aff), t[r] = sum_k p[r][k] g[r][k].
+ * theta [R][D], phi/g [R][K][D] (row stride ld), p fp32 [R][K], t [R][D].
+ * ------------------------------------------------------------------------------------------ */
+int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,
+                      int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                      vlfb_stream_t stream);
+int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const void* g,
+                      const float* p, void* dtheta, void* dphi, void* dg, int dtype, int64_t r,
+                      int64_t k, int64_t d, int64_t ld, float scale, vlfb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Solver.  Replaces WeightedSum + MomentumSGDUpdate(nesterov) per parameter
+ * (model_builder_video.py:348-389) with one pass over a flat fp32 bucket:
+ *   g += wd*p ; m' = mu*m + lr*g ; p -= (1+mu)*m' - mu*m   (nesterov)  |  p -= m' (plain)
+ * ------------------------------------------------------------------------------------------ */
+int vlfb_sgd_update(float* p, float* g, float* m, int64_t n, float lr, float wd, float mu,
+                    int nesterov, vlfb_stream_t stream);
+int vlfb_scale_inplace(float* x, int64_t n, float s, vlfb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLFB_H_ */

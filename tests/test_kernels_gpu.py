@@ -1,0 +1,512 @@
+"""GPU parity tests of every C-ABI kernel against plain torch-CPU restatements of the same op.
+
+All calls go through libvlfb_hip.so (ctypes); inputs are rounded through the kernel's element type
+first so the comparison measures the kernel, not the input quantisation.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DTYPES, TOL, dev, q, rel_err, to_ncthw, to_nthwc, w_to_kernel
+
+pytestmark = pytest.mark.gpu
+
+hip = None
+
+
+def setup_module(module):
+    from vlfb import hip as h
+    module.hip = h
+    h.lib()
+
+
+def gpu(t, dtype=None):
+    t = t.to(dev())
+    return t.to(dtype) if dtype is not None else t
+
+
+# ------------------------------------------------------------------------------------------------
+def test_affine_nd_matches_reference_formula():
+    g = torch.Generator().manual_seed(0)
+    for shape in [(2, 5, 3, 4, 4), (1, 7, 1, 1, 1), (3, 64, 4, 7, 7)]:
+        x = torch.randn(shape, generator=g)
+        s = torch.rand(shape[1], generator=g) + 0.5
+        b = torch.randn(shape[1], generator=g)
+        n, c = shape[0], shape[1]
+        inner = int(np.prod(shape[2:]))
+        xg, sg, bg = gpu(x), gpu(s), gpu(b)
+        y = torch.empty_like(xg)
+        hip.call("vlfb_affine_nd_fwd", hip.ptr(xg), hip.ptr(sg), hip.ptr(bg), hip.ptr(y), n, c, inner)
+        ref = x * s.view(1, -1, 1, 1, 1) + b.view(1, -1, 1, 1, 1)
+        assert torch.equal(y.cpu(), ref) or rel_err(y, ref) < 1e-7
+        dx = torch.empty_like(xg)
+        hip.call("vlfb_affine_nd_bwd", hip.ptr(xg), hip.ptr(sg), hip.ptr(dx), n, c, inner)
+        assert rel_err(dx, x * s.view(1, -1, 1, 1, 1)) < 1e-7
+        # in place, as the schema allows (affine_nd_op.cc:35-43)
+        hip.call("vlfb_affine_nd_fwd", hip.ptr(xg), hip.ptr(sg), hip.ptr(bg), hip.ptr(xg), n, c, inner)
+        assert rel_err(xg, ref) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = {
+    # name: (N, Cin, Cout, T, H, W, k, stride, pad, dil)
+    "pw_ident": (2, 64, 128, 2, 9, 9, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    "pw_small_cout": (1, 128, 64, 2, 7, 7, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    "temporal3": (2, 64, 64, 5, 6, 6, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),
+    "spatial3": (2, 64, 64, 2, 10, 10, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "spatial3_s2": (2, 64, 128, 2, 12, 12, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),
+    "spatial3_dil2": (1, 64, 64, 2, 9, 9, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),
+    "shortcut_s2": (2, 64, 128, 2, 10, 10, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
+    "wide": (1, 256, 192, 2, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+}
+
+
+def conv_out_dims(T, H, W, k, s, p, d):
+    return tuple((x + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for x, kk, ss, pp, dd in zip((T, H, W), k, s, p, d))
+
+
+def geom_kwargs(k, s, p, d):
+    return dict(kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
+                dt=d[0], dh=d[1], dw=d[2])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", sorted(CONV_CASES))
+def test_conv_fprop_dgrad_wgrad(case, dtype):
+    N, Cin, Cout, T, H, W, k, s, p, d = CONV_CASES[case]
+    gen = torch.Generator().manual_seed(sum(map(ord, case)))
+    x = q(torch.randn(N, Cin, T, H, W, generator=gen), dtype)
+    w = q(torch.randn(Cout, Cin, *k, generator=gen) * (1.0 / math.sqrt(Cin * k[0] * k[1] * k[2])), dtype)
+    To, Ho, Wo = conv_out_dims(T, H, W, k, s, p, d)
+    bias = torch.randn(Cout, generator=gen)
+    res = q(torch.randn(N, Cout, To, Ho, Wo, generator=gen), dtype)
+    code = hip.dtype_code(dtype)
+
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_lin = F.conv3d(xd, wd, None, s, p, d)
+    y_ref = torch.relu(y_lin + bias.double().view(1, -1, 1, 1, 1) + res.double())
+
+    A = gpu(to_nthwc(x), dtype)
+    Bw = gpu(w_to_kernel(w), dtype)
+    O = torch.empty(N, To, Ho, Wo, Cout, device=dev(), dtype=dtype)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo,
+                         Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout, relu=1, bias_mode=hip.BIAS_COL,
+                         **geom_kwargs(k, s, p, d))
+    hip.conv_run(desc, A, Bw, None, O, bias=gpu(bias), R=gpu(to_nthwc(res), dtype))
+    assert rel_err(to_ncthw(O.float()), y_ref) < TOL[dtype], "fprop"
+
+    # mask epilogue + fp32 output
+    if dtype == torch.bfloat16:
+        O32 = torch.empty(N, To, Ho, Wo, Cout, device=dev(), dtype=torch.float32)
+        desc2 = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo,
+                              Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout, **geom_kwargs(k, s, p, d))
+        hip.conv_run(desc2, A, Bw, None, O32)
+        assert rel_err(to_ncthw(O32), y_lin) < 2e-5, "fprop fp32-out"
+
+    # ---- dgrad -------------------------------------------------------------------------------
+    dy = q(torch.randn(N, Cout, To, Ho, Wo, generator=gen), dtype)
+    gx, gw = torch.autograd.grad(y_lin, (xd, wd), dy.double())
+    mask_src = q(torch.randn(N, Cin, T, H, W, generator=gen), dtype)
+    add_src = q(torch.randn(N, Cin, T, H, W, generator=gen), dtype)
+    dx_ref = torch.where(mask_src.double() > 0, gx + add_src.double(), torch.zeros_like(gx))
+    G = gpu(to_nthwc(dy), dtype)
+    Wd = gpu(w.permute(1, 2, 3, 4, 0).contiguous(), dtype)  # [Cin][taps][Cout]
+    DX = torch.empty(N, T, H, W, Cin, device=dev(), dtype=dtype)
+    desc = hip.conv_desc(mode=hip.DGRAD, dtype=code, out_dtype=code, N=N, Tr=T, Hr=H, Wr=W,
+                         Ts=To, Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, **geom_kwargs(k, s, p, d))
+    hip.conv_run(desc, G, Wd, None, DX, R=gpu(to_nthwc(add_src), dtype), mask=gpu(to_nthwc(mask_src), dtype))
+    assert rel_err(to_ncthw(DX.float()), dx_ref) < TOL[dtype], "dgrad"
+
+    # ---- wgrad (library-chosen split, forced split, and direct) --------------------------------
+    scale = torch.rand(Cout, generator=gen) + 0.5
+    gw_ref = w_to_kernel(gw * scale.double().view(-1, 1, 1, 1, 1))
+    for splits in (0, 1, 3):
+        DW = torch.full((Cout, k[0], k[1], k[2], Cin), float("nan"), device=dev(), dtype=torch.float32)
+        desc = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo,
+                             Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout, splits=splits, **geom_kwargs(k, s, p, d))
+        nbytes = hip.conv_workspace_bytes(desc)
+        ws = torch.empty(max(nbytes, 16) // 4, device=dev(), dtype=torch.float32)
+        hip.conv_run(desc, A, None, G, DW, rowscale=gpu(scale), workspace=ws)
+        assert rel_err(DW, gw_ref) < (2e-5 if dtype == torch.float32 else 2e-3), "wgrad splits=%d" % splits
+    # accumulate
+    base = torch.randn(Cout, k[0], k[1], k[2], Cin, generator=gen)
+    DW = gpu(base.clone())
+    desc = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo,
+                         Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout, splits=2, accumulate=1, **geom_kwargs(k, s, p, d))
+    ws = torch.empty(max(hip.conv_workspace_bytes(desc), 16) // 4, device=dev(), dtype=torch.float32)
+    hip.conv_run(desc, A, None, G, DW, workspace=ws)
+    assert rel_err(DW, base.double() + w_to_kernel(gw)) < (2e-5 if dtype == torch.float32 else 2e-3), "wgrad acc"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_stem_packed(dtype):
+    """conv1: 5x7x7, stride (1,2,2), pad (2,3,3), Cin=3 packed as [kw_pad=8][4] runs (resnet_video.py:169-179)"""
+    N, T, H, W, Cout = 2, 6, 20, 20, 64
+    k, s, p, d = (5, 7, 7), (1, 2, 2), (2, 3, 3), (1, 1, 1)
+    gen = torch.Generator().manual_seed(3)
+    x = q(torch.randn(N, 3, T, H, W, generator=gen), dtype)
+    w = q(torch.randn(Cout, 3, *k, generator=gen) * 0.05, dtype)
+    To, Ho, Wo = conv_out_dims(T, H, W, k, s, p, d)
+    code = hip.dtype_code(dtype)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv3d(xd, wd, None, s, p, d)
+    # NTHWC with C padded to 4 via the library's own mover
+    X4 = torch.empty(N, T, H, W, 4, device=dev(), dtype=dtype)
+    hip.call("vlfb_ncthw_to_nthwc", hip.ptr(gpu(x)), hip.ptr(X4), code, N, 3, T * H * W, 4)
+    assert torch.equal(X4[..., :3].float().cpu(), to_nthwc(x)) and float(X4[..., 3].abs().max()) == 0.0
+    wp = torch.zeros(Cout, 5, 7, 8, 4)
+    wp[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
+    Bw = gpu(wp, dtype)
+    O = torch.empty(N, To, Ho, Wo, Cout, device=dev(), dtype=dtype)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo,
+                         Ts=T, Hs=H, Ws=W, Cs=4, Cn=Cout, pack_w=8, **geom_kwargs(k, s, p, d))
+    hip.conv_run(desc, X4, Bw, None, O)
+    assert rel_err(to_ncthw(O.float()), y_ref) < TOL[dtype]
+    # wgrad in the packed layout
+    dy = q(torch.randn(N, Cout, To, Ho, Wo, generator=gen), dtype)
+    (gw,) = torch.autograd.grad(y_ref, (wd,), dy.double())
+    G = gpu(to_nthwc(dy), dtype)
+    DW = torch.empty(Cout, 5, 7, 8, 4, device=dev(), dtype=torch.float32)
+    desc = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo,
+                         Ts=T, Hs=H, Ws=W, Cs=4, Cn=Cout, pack_w=8, **geom_kwargs(k, s, p, d))
+    ws = torch.empty(max(hip.conv_workspace_bytes(desc), 16) // 4, device=dev(), dtype=torch.float32)
+    hip.conv_run(desc, X4, None, G, DW, workspace=ws)
+    got = DW[:, :, :, :7, :3].permute(0, 4, 1, 2, 3)
+    assert rel_err(got, gw) < (2e-5 if dtype == torch.float32 else 2e-3)
+    assert float(DW[..., 3].abs().max()) == 0.0  # the zero-padded input channel
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batched_gemms_of_the_nonlocal_block(dtype):
+    """theta.phi^T (fp32 out), P.g (K = L2 not a multiple of the 64-wide k tile), and the two
+    contract-over-L1 products of the backward (nonlocal_helper.py:94,121 and their gradients)."""
+    B, L1, L2, Ci = 3, 200, 72, 64
+    gen = torch.Generator().manual_seed(5)
+    code = hip.dtype_code(dtype)
+    theta = q(torch.randn(B, L1, Ci, generator=gen), dtype)
+    phi = q(torch.randn(B, L2, Ci, generator=gen), dtype)
+    S = torch.empty(B, L1, L2, device=dev(), dtype=torch.float32)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=hip.F32, N=1, Tr=1, Hr=1, Wr=L1,
+                         Ts=1, Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci,
+                         b_bstride=L2 * Ci, o_bstride=L1 * L2)
+    hip.conv_run(desc, gpu(theta, dtype), gpu(phi, dtype), None, S)
+    S_ref = torch.einsum("blc,bmc->blm", theta.double(), phi.double())
+    assert rel_err(S, S_ref) < 2e-5
+
+    P = q(torch.softmax(S_ref.float() * Ci ** -0.5, dim=2), dtype)
+    g = q(torch.randn(B, L2, Ci, generator=gen), dtype)
+    gT = g.transpose(1, 2).contiguous()  # [B][Ci][L2]
+    Y = torch.empty(B, L1, Ci, device=dev(), dtype=dtype)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1,
+                         Ts=1, Hs=1, Ws=L1, Cs=L2, Cn=Ci, batch=B, a_bstride=L1 * L2,
+                         b_bstride=Ci * L2, o_bstride=L1 * Ci)
+    hip.conv_run(desc, gpu(P, dtype), gpu(gT, dtype), None, Y)
+    Y_ref = torch.einsum("blm,bmc->blc", P.double(), g.double())
+    assert rel_err(Y.float(), Y_ref) < TOL[dtype]
+
+    # library transpose agrees with torch
+    gT_dev = torch.empty(B, Ci, L2, device=dev(), dtype=dtype)
+    hip.call("vlfb_transpose2d", hip.ptr(gpu(g, dtype)), hip.ptr(gT_dev), code, B, L2, Ci)
+    assert torch.equal(gT_dev.float().cpu(), gT)
+
+    # dphi[b][m][c] = sum_l dS[b][l][m] * theta[b][l][c]   (TN, batched, direct epilogue)
+    dS = q(torch.randn(B, L1, L2, generator=gen), dtype)
+    dphi = torch.empty(B, L2, Ci, device=dev(), dtype=dtype)
+    desc = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1,
+                         Ts=1, Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci,
+                         p_bstride=L1 * L2, o_bstride=L2 * Ci)
+    hip.conv_run(desc, gpu(theta, dtype), None, gpu(dS, dtype), dphi)
+    dphi_ref = torch.einsum("blm,blc->bmc", dS.double(), theta.double())
+    assert rel_err(dphi.float(), dphi_ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_row_bias_and_swapped_roles_gives_transposed_conv_output(dtype):
+    """g^T = W_g . x^T with a per-row bias: the transposed 1x1x1 conv output the non-local block needs"""
+    M, Cin, Cout = 150, 64, 128
+    gen = torch.Generator().manual_seed(7)
+    code = hip.dtype_code(dtype)
+    x = q(torch.randn(M, Cin, generator=gen), dtype)
+    w = q(torch.randn(Cout, Cin, generator=gen) * 0.1, dtype)
+    b = torch.randn(Cout, generator=gen)
+    O = torch.empty(Cout, M, device=dev(), dtype=dtype)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=Cout,
+                         Ts=1, Hs=1, Ws=Cout, Cs=Cin, Cn=M, bias_mode=hip.BIAS_ROW)
+    # M = 150 is not a multiple of 4 -> scalar-store epilogue path
+    hip.conv_run(desc, gpu(w, dtype), gpu(x, dtype), None, O, bias=gpu(b))
+    ref = (x.double() @ w.double().t() + b.double()).t()
+    assert rel_err(O.float(), ref) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------------------
+POOLS = {
+    "pool1": ((1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 11, 11)),   # resnet_video.py:190-196
+    "pool2": ((2, 1, 1), (2, 1, 1), (0, 0, 0), (2, 4, 5, 5)),     # resnet_video.py:219-225
+    "nlpool": ((1, 2, 2), (1, 2, 2), (0, 0, 0), (2, 2, 6, 6)),    # nonlocal_helper.py:48-54
+}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", sorted(POOLS))
+def test_maxpool_fwd_bwd(name, dtype):
+    k, s, p, (N, T, H, W) = POOLS[name]
+    Cc = 16
+    gen = torch.Generator().manual_seed(11)
+    code = hip.dtype_code(dtype)
+    x = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
+    xd = x.double().requires_grad_(True)
+    y_ref = F.max_pool3d(xd, k, s, p)
+    To, Ho, Wo = y_ref.shape[2:]
+    X = gpu(to_nthwc(x), dtype)
+    Y = torch.empty(N, To, Ho, Wo, Cc, device=dev(), dtype=dtype)
+    AM = torch.empty(N, To, Ho, Wo, Cc, device=dev(), dtype=torch.uint8)
+    d = hip.pool_desc(code, N, T, H, W, Cc, To, Ho, Wo, k, s, p)
+    import ctypes as C
+    hip.call("vlfb_maxpool_fwd", C.byref(d), hip.ptr(X), hip.ptr(Y), hip.ptr(AM))
+    assert torch.equal(to_ncthw(Y.float()).cpu(), y_ref.float())
+    dy = q(torch.randn(N, Cc, To, Ho, Wo, generator=gen), dtype)
+    (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
+    add = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
+    DX = torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype)
+    hip.call("vlfb_maxpool_bwd", C.byref(d), hip.ptr(gpu(to_nthwc(dy), dtype)), hip.ptr(AM), hip.ptr(DX),
+             hip.ptr(gpu(to_nthwc(add), dtype)), hip.ptr(X))
+    ref = torch.where(x.double() > 0, gx + add.double(), torch.zeros_like(gx))
+    assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_avgpool_global_and_temporal(dtype):
+    import ctypes as C
+    gen = torch.Generator().manual_seed(13)
+    code = hip.dtype_code(dtype)
+    N, Cc, T, H, W = 2, 64, 4, 5, 5
+    x = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
+    X = gpu(to_nthwc(x), dtype)
+    for k in [(T, H, W), (T, 1, 1)]:  # head_helper.py:37-40 and :92-98
+        To, Ho, Wo = T - k[0] + 1, H - k[1] + 1, W - k[2] + 1
+        xd = x.double().requires_grad_(True)
+        y_ref = F.avg_pool3d(xd, k, (1, 1, 1))
+        Y = torch.empty(N, To, Ho, Wo, Cc, device=dev(), dtype=dtype)
+        d = hip.pool_desc(code, N, T, H, W, Cc, To, Ho, Wo, k, (1, 1, 1), (0, 0, 0))
+        hip.call("vlfb_avgpool_fwd", C.byref(d), hip.ptr(X), hip.ptr(Y))
+        assert rel_err(to_ncthw(Y.float()), y_ref) < TOL[dtype]
+        dy = q(torch.randn(N, Cc, To, Ho, Wo, generator=gen), dtype)
+        (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
+        DX = torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype)
+        hip.call("vlfb_avgpool_bwd", C.byref(d), hip.ptr(gpu(to_nthwc(dy), dtype)), hip.ptr(DX), None, hip.ptr(X))
+        ref = torch.where(x.double() > 0, gx, torch.zeros_like(gx))
+        assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_fwd_bwd(dtype):
+    gen = torch.Generator().manual_seed(17)
+    code = hip.dtype_code(dtype)
+    rows, cols, scale = 37, 784, 512 ** -0.5
+    s = torch.randn(rows, cols, generator=gen) * 8
+    S = gpu(s)
+    P = torch.empty(rows, cols, device=dev(), dtype=dtype)
+    hip.call("vlfb_softmax_fwd", hip.ptr(S), hip.ptr(P), code, rows, cols, scale)
+    sd = s.double().requires_grad_(True)
+    p_ref = torch.softmax(sd * scale, dim=1)
+    assert rel_err(P.float(), p_ref) < (1e-5 if dtype == torch.float32 else 4e-3)
+    dp = torch.randn(rows, cols, generator=gen)
+    # backward uses the stored (rounded) probabilities, as the engine does
+    pq = P.float().cpu().double()
+    ds_ref = scale * pq * (dp.double() - (dp.double() * pq).sum(1, keepdim=True))
+    DS = torch.empty(rows, cols, device=dev(), dtype=dtype)
+    hip.call("vlfb_softmax_bwd", hip.ptr(gpu(dp)), hip.ptr(P), hip.ptr(DS), code, rows, cols, scale)
+    assert rel_err(DS.float(), ds_ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_relu_colsum(dtype):
+    gen = torch.Generator().manual_seed(19)
+    code = hip.dtype_code(dtype)
+    n = 8 * 1000 + 3
+    a = q(torch.randn(n, generator=gen), dtype)
+    b = q(torch.randn(n, generator=gen), dtype)
+    m = q(torch.randn(n, generator=gen), dtype)
+    Y = torch.empty(n, device=dev(), dtype=dtype)
+    hip.call("vlfb_add", hip.ptr(gpu(a, dtype)), hip.ptr(gpu(b, dtype)), hip.ptr(Y), hip.ptr(gpu(m, dtype)), code, n, 1)
+    ref = torch.where(m > 0, torch.relu(a + b), torch.zeros_like(a))
+    assert rel_err(Y.float(), q(ref, dtype)) < 1e-6
+    rows, cols = 1000, 96
+    g = q(torch.randn(rows, cols, generator=gen), dtype)
+    out = torch.empty(cols, device=dev(), dtype=torch.float32)
+    hip.call("vlfb_colsum", hip.ptr(gpu(g, dtype)), code, rows, cols, cols, hip.ptr(out), 0)
+    assert rel_err(out, g.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_dropout(dtype):
+    from oracle import rng as orng
+    gen = torch.Generator().manual_seed(23)
+    code = hip.dtype_code(dtype)
+    rows, cols = 9, 512
+    x = q(torch.randn(rows, cols, generator=gen) * 3 + 1, dtype)
+    xd = x.double().requires_grad_(True)
+    y_ref = F.layer_norm(xd, (cols,), eps=1e-5)
+    Y = torch.empty(rows, cols, device=dev(), dtype=dtype)
+    rstd = torch.empty(rows, device=dev(), dtype=torch.float32)
+    hip.call("vlfb_layernorm_fwd", hip.ptr(gpu(x, dtype)), hip.ptr(Y), hip.ptr(rstd), code, rows, cols, 1e-5)
+    assert rel_err(Y.float(), y_ref) < TOL[dtype]
+    dy = q(torch.randn(rows, cols, generator=gen), dtype)
+    (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
+    DX = torch.empty(rows, cols, device=dev(), dtype=dtype)
+    hip.call("vlfb_layernorm_bwd", hip.ptr(gpu(dy, dtype)), hip.ptr(Y), hip.ptr(rstd), hip.ptr(DX), code, rows, cols)
+    assert rel_err(DX.float(), gx) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+    # dropout: mask must equal the oracle's generator, defined over the REFERENCE (r, c, k) index
+    R, K, Cc, ratio, seed = 3, 5, 16, 0.2, 0x1234567890ABCDEF
+    xs = q(torch.randn(R, K, Cc, generator=gen), dtype)  # stored [(r*K + k)*C + c]
+    Yd = torch.empty(R, K, Cc, device=dev(), dtype=dtype)
+    Md = torch.empty(R, K, Cc, device=dev(), dtype=torch.uint8)
+    hip.call("vlfb_dropout_fwd", hip.ptr(gpu(xs, dtype)), hip.ptr(Yd), hip.ptr(Md), code, R, K, Cc, ratio, seed)
+    keep_ref = orng.dropout_keep_mask(seed, (R, Cc, K), ratio)  # reference layout (R, C, K)
+    keep_ref = torch.from_numpy(keep_ref).permute(0, 2, 1)
+    assert torch.equal(Md.cpu().bool(), keep_ref)
+    ref = torch.where(keep_ref, xs / (1 - ratio), torch.zeros_like(xs))
+    assert rel_err(Yd.float(), q(ref, dtype)) < 1e-6 if dtype == torch.float32 else rel_err(Yd.float(), ref) < 4e-3
+    DXd = torch.empty(R, K, Cc, device=dev(), dtype=dtype)
+    hip.call("vlfb_dropout_bwd", hip.ptr(gpu(xs, dtype)), hip.ptr(Md), hip.ptr(DXd), code, R * K * Cc, ratio)
+    assert rel_err(DXd.float(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fc_and_sigmoid_ce(dtype):
+    gen = torch.Generator().manual_seed(29)
+    code = hip.dtype_code(dtype)
+    rows, cin, cout = 6, 2560, 157
+    x = q(torch.randn(rows, cin, generator=gen), dtype)
+    w = torch.randn(cout, cin, generator=gen) * 0.01
+    b = torch.randn(cout, generator=gen) * 0.1
+    labels = (torch.rand(rows, cout, generator=gen) < 0.05).to(torch.int32)
+    labels[0, 3] = -1  # ignored entry
+    scale = 1.0 / 8
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    logits_ref = xd @ wd.t() + bd
+    t = labels.double()
+    valid = t >= 0
+    pos = (logits_ref >= 0).double()
+    l = -logits_ref * (t - pos) + torch.log(1 + torch.exp(logits_ref - 2 * logits_ref * pos))
+    loss_ref = scale * (l * valid).sum() / valid.sum()
+    gx, gw, gb = torch.autograd.grad(loss_ref, (xd, wd, bd))
+    X = gpu(x, dtype)
+    L = torch.empty(rows, cout, device=dev())
+    hip.call("vlfb_fc_fwd", hip.ptr(X), code, hip.ptr(gpu(w)), hip.ptr(gpu(b)), hip.ptr(L), rows, cin, cout)
+    assert rel_err(L, logits_ref) < 1e-5
+    prob = torch.empty_like(L)
+    loss = torch.empty(1, device=dev())
+    dl = torch.empty_like(L)
+    hip.call("vlfb_sigmoid_ce", hip.ptr(L), hip.ptr(gpu(labels)), hip.ptr(prob), hip.ptr(loss), hip.ptr(dl), rows, cout, scale)
+    assert rel_err(prob, torch.sigmoid(logits_ref)) < 1e-5
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    DX = torch.empty(rows, cin, device=dev(), dtype=dtype)
+    DW = torch.empty(cout, cin, device=dev())
+    DB = torch.empty(cout, device=dev())
+    hip.call("vlfb_fc_bwd", hip.ptr(X), code, hip.ptr(gpu(w)), hip.ptr(dl), hip.ptr(DX), hip.ptr(DW), hip.ptr(DB), rows, cin, cout, 0)
+    assert rel_err(DX.float(), gx) < TOL[dtype]
+    assert rel_err(DW, gw) < 1e-4 and rel_err(DB, gb) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fbo_attention_core(dtype):
+    gen = torch.Generator().manual_seed(31)
+    code = hip.dtype_code(dtype)
+    R, K, D = 5, 300, 512
+    theta = q(torch.randn(R, D, generator=gen), dtype)
+    phi = q(torch.randn(R, K, D, generator=gen), dtype)
+    g = q(torch.randn(R, K, D, generator=gen), dtype)
+    scale = D ** -0.5
+    td, pd, gd = (t.double().requires_grad_(True) for t in (theta, phi, g))
+    aff = torch.einsum("rd,rkd->rk", td, pd) * scale
+    p_ref = torch.softmax(aff, dim=1)
+    t_ref = torch.einsum("rk,rkd->rd", p_ref, gd)
+    P = torch.empty(R, K, device=dev())
+    T = torch.empty(R, D, device=dev(), dtype=dtype)
+    TH, PH, G = gpu(theta, dtype), gpu(phi, dtype), gpu(g, dtype)
+    hip.call("vlfb_fbo_attn_fwd", hip.ptr(TH), hip.ptr(PH), hip.ptr(G), hip.ptr(P), hip.ptr(T), code, R, K, D, D, scale)
+    assert rel_err(P, p_ref) < 1e-5
+    assert rel_err(T.float(), t_ref) < TOL[dtype]
+    dt = q(torch.randn(R, D, generator=gen), dtype)
+    gth, gph, gg = torch.autograd.grad(t_ref, (td, pd, gd), dt.double())
+    DTH = torch.empty(R, D, device=dev(), dtype=dtype)
+    DPH = torch.empty(R, K, D, device=dev(), dtype=dtype)
+    DG = torch.empty(R, K, D, device=dev(), dtype=dtype)
+    hip.call("vlfb_fbo_attn_bwd", hip.ptr(gpu(dt, dtype)), hip.ptr(TH), hip.ptr(PH), hip.ptr(G), hip.ptr(P),
+             hip.ptr(DTH), hip.ptr(DPH), hip.ptr(DG), code, R, K, D, D, scale)
+    assert rel_err(DTH.float(), gth) < TOL[dtype]
+    assert rel_err(DPH.float(), gph) < TOL[dtype]
+    assert rel_err(DG.float(), gg) < TOL[dtype]
+
+
+def test_sgd_weight_prep_cast():
+    gen = torch.Generator().manual_seed(37)
+    n = 10007
+    p, g, m = (torch.randn(n, generator=gen) for _ in range(3))
+    lr, wd, mu = 0.02, 1e-4, 0.9
+    P, G, M = gpu(p.clone()), gpu(g.clone()), gpu(m.clone())
+    hip.call("vlfb_sgd_update", hip.ptr(P), hip.ptr(G), hip.ptr(M), n, lr, wd, mu, 1)
+    g2 = g.double() + wd * p.double()
+    m2 = mu * m.double() + lr * g2
+    step = (1 + mu) * m2 - mu * m.double()
+    assert rel_err(P, p.double() - step) < 1e-6 and rel_err(M, m2) < 1e-6 and rel_err(G, step) < 1e-6
+    cout, taps, cin = 40, 3, 72
+    w = torch.randn(cout, taps, cin, generator=gen)
+    s = torch.rand(cout, generator=gen) + 0.5
+    for dtype in DTYPES:
+        code = hip.dtype_code(dtype)
+        wf = torch.empty(cout, taps, cin, device=dev(), dtype=dtype)
+        wg = torch.empty(cin, taps, cout, device=dev(), dtype=dtype)
+        hip.call("vlfb_weight_prep", hip.ptr(gpu(w)), hip.ptr(gpu(s)), hip.ptr(wf), hip.ptr(wg), code, cout, taps, cin)
+        ref = (w * s.view(-1, 1, 1)).to(dtype)
+        assert torch.equal(wf.cpu(), ref)
+        assert torch.equal(wg.cpu(), ref.permute(2, 1, 0).contiguous())
+    x = torch.randn(1000, generator=gen)
+    xb = torch.empty(1000, device=dev(), dtype=torch.bfloat16)
+    hip.call("vlfb_cast", hip.ptr(gpu(x)), hip.F32, hip.ptr(xb), hip.BF16, 1000)
+    assert torch.equal(xb.cpu(), x.to(torch.bfloat16))  # round-to-nearest-even, same as torch
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_roi_align_max_head(dtype):
+    """RoIAlign(7x7, 1/16, sampling_ratio 0) + 7x7 max (head_helper.py:88-123): integer decisions
+    bit-exact against the oracle, values within tolerance, backward against autograd."""
+    from oracle.roi_align import roi_align_loop, roi_align_torch
+    gen = torch.Generator().manual_seed(41)
+    code = hip.dtype_code(dtype)
+    N, Cc, H, W = 2, 32, 14, 14
+    feat = q(torch.randn(N, Cc, H, W, generator=gen), dtype)
+    rois = torch.tensor([[0, 10, 20, 200, 220], [1, 0, 0, 223, 223], [1, 100, 50, 108, 58],
+                         [0, 3.3, 7.7, 15.2, 223], [1, 64, 64, 223, 100], [0, 0, 190, 223, 223]],
+                        dtype=torch.float32)
+    R = rois.shape[0]
+    out_np, dbg_np = roi_align_loop(feat.numpy(), rois.numpy())
+    Fg = gpu(feat.permute(0, 2, 3, 1).contiguous(), dtype)  # [N,H,W,C]
+    O = torch.empty(R, Cc, device=dev(), dtype=dtype)
+    AB = torch.empty(R, Cc, device=dev(), dtype=torch.uint8)
+    DBG = torch.empty(R, 7, 7, 8, device=dev(), dtype=torch.int32)
+    hip.call("vlfb_roi_align_max_fwd", hip.ptr(Fg), code, hip.ptr(gpu(rois)), hip.ptr(O), hip.ptr(AB), hip.ptr(DBG),
+             N, H, W, Cc, R, 7, 1.0 / 16)
+    assert np.array_equal(DBG.cpu().numpy(), dbg_np), "RoIAlign integer decisions must be bit-exact"
+    flat = torch.from_numpy(out_np).reshape(R, Cc, 49)
+    ref_max, ref_arg = flat.max(dim=2)
+    assert rel_err(O.float(), q(ref_max, dtype)) < (1e-6 if dtype == torch.float32 else 4e-3)
+    if dtype == torch.float32:
+        assert torch.equal(AB.cpu().long(), ref_arg)
+    # backward
+    fd = feat.double().requires_grad_(True)
+    pooled = roi_align_torch(fd, rois.numpy()).reshape(R, Cc, 49)
+    sel = pooled.gather(2, AB.cpu().long().unsqueeze(2)).squeeze(2)
+    dout = q(torch.randn(R, Cc, generator=gen), dtype)
+    (gf,) = torch.autograd.grad(sel, (fd,), dout.double())
+    DF = torch.zeros(N, H, W, Cc, device=dev(), dtype=torch.float32)
+    hip.call("vlfb_roi_align_max_bwd", hip.ptr(gpu(dout, dtype)), code, hip.ptr(gpu(rois)), hip.ptr(AB), hip.ptr(DF),
+             N, H, W, Cc, R, 7, 1.0 / 16)
+    assert rel_err(DF.permute(0, 3, 1, 2), gf) < 1e-5

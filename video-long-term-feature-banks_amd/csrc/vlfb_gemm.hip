@@ -1,0 +1,779 @@
+// Implicit-GEMM 3-D convolution / batched GEMM on CDNA4 matrix cores (gfx950).
+//
+// One kernel family covers every contraction on the hot path (SURVEY.md 8a rows M1, M4-M6, M10,
+// H3-H5): conv fprop, conv dgrad (NT form: both operands K-contiguous) and conv wgrad / the
+// "contract over positions" attention products (TN form: both operands are stored with the
+// contraction index as the slow dimension, so the stager transposes 8x8 (bf16) / 4x4 (fp32)
+// register blocks on the way into LDS).
+//
+// Data layout: activations are channels-last [N,T,H,W,C] so a 16-byte global load is a run of
+// consecutive K for one output row; weights are [Cout][tap][Cin].  LDS tiles are rows of 128
+// bytes (64 bf16 / 32 fp32 of K) with the 16-byte chunk index XOR-ed by (row & 7), which makes
+// both the ds_write_b128 of the stager and the ds_read_b128 of the fragment reader
+// conflict-free (cdna_hip_programming.md, T2).  Wave tile 64x64 (2x2 waves, 128x128 block) out
+// of 16x16 MFMA fragments: v_mfma_f32_16x16x32_bf16 on the throughput path,
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) on the parity path.  The two paths share the
+// same lane<->k mapping: lane l owns 8 consecutive k of row (l & 15) at k-offset (l >> 4) * 8.
+// MFMA operands are swapped (weights as A, activations as B) so that each lane ends up holding
+// 4 consecutive output channels of one output row -> 8/16-byte epilogue stores.
+#include "vlfb_common.h"
+#include <string.h>
+
+namespace vlfb {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;  // one LDS tile row = 128 bytes of K
+
+struct GP {
+  const char* A;
+  const char* B;
+  const char* P;
+  char* O;
+  const float* bias;
+  const float* rowscale;
+  const char* R;
+  const char* Mask;
+  float* ws;
+  int M, Ncols, K;
+  int Tr, Hr, Wr, Ts, Hs, Ws, Cs;
+  int kh, kw;
+  float inv_khw, inv_kw, inv_kh;
+  int st, sh, sw, pt, ph, pw, dt, dh, dw;
+  int lst, lsh, lsw;  // log2 strides (DGRAD)
+  int cpt_shift;      // log2(16-byte chunks per tap)
+  int lda, ldb, ldo, ldr, ldp;
+  long long a_bs, b_bs, o_bs, r_bs, p_bs;
+  float alpha;
+  int relu, bias_mode, accumulate;
+  int tiles_m, tiles_n;
+  int splits, kper;
+};
+
+struct RowC { int n, t, h, w; };
+
+__device__ __forceinline__ RowC decode_row(const GP& p, int m) {
+  RowC r;
+  int hw = p.Hr * p.Wr;
+  int thw = p.Tr * hw;
+  r.n = m / thw;
+  int rem = m - r.n * thw;
+  r.t = rem / hw;
+  rem -= r.t * hw;
+  r.h = rem / p.Wr;
+  r.w = rem - r.h * p.Wr;
+  return r;
+}
+__device__ __forceinline__ void advance_row(const GP& p, RowC& r) {
+  if (++r.w == p.Wr) {
+    r.w = 0;
+    if (++r.h == p.Hr) {
+      r.h = 0;
+      if (++r.t == p.Tr) { r.t = 0; ++r.n; }
+    }
+  }
+}
+
+struct TapC { int a, b, c, ci; bool ok; };
+
+// kc = global 16-byte chunk index along K
+template <typename T, bool PACKW>
+__device__ __forceinline__ TapC decode_tap(const GP& p, int kc) {
+  constexpr int EPC = Elem<T>::EPC;
+  TapC t;
+  t.ok = kc * EPC < p.K;
+  int tap = kc >> p.cpt_shift;
+  int within = kc & ((1 << p.cpt_shift) - 1);
+  if (PACKW) {
+    // taps enumerate (a, b); the packed (kw, channel) run is the per-tap K extent
+    t.a = (int)(((float)tap + 0.5f) * p.inv_kh);
+    t.b = tap - t.a * p.kh;
+    t.c = within * (EPC / 4);  // first pixel of this chunk (Cs == 4)
+    t.ci = 0;
+  } else {
+    t.a = (int)(((float)tap + 0.5f) * p.inv_khw);
+    int rem = tap - t.a * p.kh * p.kw;
+    t.b = (int)(((float)rem + 0.5f) * p.inv_kw);
+    t.c = rem - t.b * p.kw;
+    t.ci = within * EPC;
+  }
+  return t;
+}
+
+// element offset of the source chunk, or -1 if it is padding. (non-PACKW)
+template <bool DGRAD>
+__device__ __forceinline__ long long src_offset(const GP& p, const RowC& r, const TapC& t) {
+  int ts, hs, ws;
+  bool ok;
+  if (!DGRAD) {
+    ts = r.t * p.st - p.pt + t.a * p.dt;
+    hs = r.h * p.sh - p.ph + t.b * p.dh;
+    ws = r.w * p.sw - p.pw + t.c * p.dw;
+    ok = (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+  } else {
+    int nt = r.t + p.pt - t.a * p.dt;
+    int nh = r.h + p.ph - t.b * p.dh;
+    int nw = r.w + p.pw - t.c * p.dw;
+    ok = nt >= 0 && nh >= 0 && nw >= 0 && ((nt & (p.st - 1)) | (nh & (p.sh - 1)) | (nw & (p.sw - 1))) == 0;
+    ts = nt >> p.lst; hs = nh >> p.lsh; ws = nw >> p.lsw;
+    ok = ok && ts < p.Ts && hs < p.Hs && ws < p.Ws;
+  }
+  if (!ok) return -1;
+  return ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * p.lda + t.ci;
+}
+
+__device__ __forceinline__ uint4 ld16(const char* base, long long byte_off) {
+  return *reinterpret_cast<const uint4*>(base + byte_off);
+}
+__device__ __forceinline__ uint2 ld8(const char* base, long long byte_off) {
+  return *reinterpret_cast<const uint2*>(base + byte_off);
+}
+
+// One gathered 16-byte chunk of the activation operand.
+template <typename T, bool IDENT, bool DGRAD, bool PACKW>
+__device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, int m, bool m_ok,
+                                                const RowC& r, const TapC& t, int kc) {
+  constexpr int EPC = Elem<T>::EPC;
+  uint4 z = make_uint4(0, 0, 0, 0);
+  if (IDENT) {
+    if (!(m_ok && t.ok)) return z;
+    return ld16(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T));
+  } else if (PACKW) {
+    if (!(m_ok && t.ok)) return z;
+    int ts = r.t * p.st - p.pt + t.a * p.dt;
+    int hs = r.h * p.sh - p.ph + t.b * p.dh;
+    if (!((unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs)) return z;
+    int w0 = r.w * p.sw - p.pw + t.c;
+    long long rowoff = ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws) * 4;
+    if (sizeof(T) == 4) {  // one pixel (4 ch) per chunk
+      if (!((unsigned)w0 < (unsigned)p.Ws)) return z;
+      return ld16(base, (rowoff + (long long)w0 * 4) * 4);
+    } else {  // two pixels per chunk, 8 bytes each
+      uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
+      if ((unsigned)w0 < (unsigned)p.Ws) lo = ld8(base, (rowoff + (long long)w0 * 4) * 2);
+      if ((unsigned)(w0 + 1) < (unsigned)p.Ws) hi = ld8(base, (rowoff + (long long)(w0 + 1) * 4) * 2);
+      return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  } else {
+    if (!(m_ok && t.ok)) return z;
+    long long off = src_offset<DGRAD>(p, r, t);
+    if (off < 0) return z;
+    return ld16(base, off * (long long)sizeof(T));
+  }
+}
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * kRowBytes + ((chunk ^ (row & 7)) << 4);
+}
+
+// ---- MFMA wrappers --------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KSTEPS = 2;
+  struct Frag { bf16x8_v v; };
+  __device__ static __forceinline__ Frag load(const char* tile, int row, int ks, int g) {
+    Frag f;
+    f.v = *reinterpret_cast<const bf16x8_v*>(tile + lds_off(row, ks * 4 + g));
+    return f;
+  }
+  __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KSTEPS = 1;
+  struct Frag { float v[8]; };
+  __device__ static __forceinline__ Frag load(const char* tile, int row, int /*ks*/, int g) {
+    Frag f;
+    float4 lo = *reinterpret_cast<const float4*>(tile + lds_off(row, 2 * g));
+    float4 hi = *reinterpret_cast<const float4*>(tile + lds_off(row, 2 * g + 1));
+    f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w;
+    f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
+    return f;
+  }
+  __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float ld_elem(const char* base, long long idx) {
+  return Elem<T>::ld(reinterpret_cast<const T*>(base) + idx);
+}
+
+// store 4 consecutive fp32 results as OutT (vector when aligned)
+template <typename OutT>
+__device__ __forceinline__ void store4(char* base, long long idx, const float (&v)[4], int count, bool vec_ok) {
+  OutT* o = reinterpret_cast<OutT*>(base) + idx;
+  if (vec_ok && count == 4) {
+    if (sizeof(OutT) == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    }
+  } else {
+    for (int i = 0; i < count; ++i) Elem<OutT>::st(o + i, v[i]);
+  }
+}
+
+// XCD-aware remap of a linear workgroup id: consecutive ids on one XCD share operand panels.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// =============================================================================================
+// NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
+// =============================================================================================
+template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW>
+__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int BUF = (BM + BN) * kRowBytes;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  // n-tiles fastest: neighbouring workgroups reuse the same activation rows from L2
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+
+  const char* Ab = p.A + (long long)z * p.a_bs * (long long)sizeof(T);
+  const char* Bb = p.B + (long long)z * p.b_bs * (long long)sizeof(T);
+
+  const int cc = tid & 7;
+  const int r0 = tid >> 3;
+
+  RowC arow[A_IT];
+  bool aok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + r0 + 32 * i;
+    aok[i] = m < p.M;
+    if (!IDENT) arow[i] = decode_row(p, aok[i] ? m : 0);
+  }
+
+  uint4 ra[A_IT], rb[B_IT];
+  const int ktiles = (p.K * (int)sizeof(T) + kRowBytes - 1) / kRowBytes;
+
+  auto load_tile = [&](int kt) {
+    const int kc = kt * 8 + cc;
+    TapC tap;
+    if (IDENT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
+    else tap = decode_tap<T, PACKW>(p, kc);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      ra[i] = load_act_chunk<T, IDENT, DGRAD, PACKW>(p, Ab, m0 + r0 + 32 * i, aok[i], arow[i], tap, kc);
+    const bool kok = kc * EPC < p.K;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int n = n0 + r0 + 32 * i;
+      if (kok && n < p.Ncols)
+        rb[i] = ld16(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T));
+      else
+        rb[i] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* xa = smem + buf * BUF;
+    char* wb = xa + BM * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(xa + lds_off(r0 + 32 * i, cc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(wb + lds_off(r0 + 32 * i, cc)) = rb[i];
+  };
+
+  f32x4_v acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const bool more = kt + 1 < ktiles;
+    if (more) load_tile(kt + 1);
+    const char* xa = smem + (kt & 1) * BUF;
+    const char* wb = xa + BM * kRowBytes;
+#pragma unroll
+    for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
+      typename Mma<T>::Frag xf[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) xf[i] = Mma<T>::load(xa, wm * WM + i * 16 + l15, ks, g);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = Mma<T>::load(wb, wn * WN + j * 16 + l15, ks, g);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[j][i] = Mma<T>::mma(wf[j], xf[i], acc[j][i]);
+    }
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = nb + 0..3 (consecutive) for row m ---------------------------
+  char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
+  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
+  const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
+  const bool vec_ok = (p.ldo & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nb = n0 + wn * WN + j * 16 + g * 4;
+      if (nb >= p.Ncols) continue;
+      const int cnt = (p.Ncols - nb) < 4 ? (p.Ncols - nb) : 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[j][i][r] * p.alpha;
+        if (r < cnt) {
+          if (p.bias_mode == VLFB_BIAS_COL) x += p.bias[nb + r];
+          else if (p.bias_mode == VLFB_BIAS_ROW) x += p.bias[m];
+          if (Rb) x += ld_elem<T>(Rb, (long long)m * p.ldr + nb + r);
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (Mb) x = ld_elem<T>(Mb, (long long)m * p.ldr + nb + r) > 0.f ? x : 0.f;
+        }
+        v[r] = x;
+      }
+      store4<OutT>(Ob, (long long)m * p.ldo + nb, v, cnt, vec_ok);
+    }
+  }
+}
+
+// =============================================================================================
+// TN kernel: O[pp][qq] = sum_m P[m][pp] * Xg[m][qq]   (qq = (tap, channel) of the gathered input)
+// =============================================================================================
+// register-block transposes: `in[j]` = 16 bytes of consecutive channels for position j;
+// `out[c]` = 16 bytes of consecutive positions for channel c.
+__device__ __forceinline__ uint32_t word_of(const uint4& v, int i) {
+  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ void transpose_block(const uint4 (&in)[8], uint4 (&out)[8], bf16_t) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w0 = word_of(in[2 * q], c >> 1), w1 = word_of(in[2 * q + 1], c >> 1);
+      o[q] = (c & 1) ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16));
+    }
+    out[c] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+__device__ __forceinline__ void transpose_block(const uint4 (&in)[4], uint4 (&out)[4], float) {
+  out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
+  out[1] = make_uint4(in[0].y, in[1].y, in[2].y, in[3].y);
+  out[2] = make_uint4(in[0].z, in[1].z, in[2].z, in[3].z);
+  out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
+}
+
+template <typename T, typename OutT, int BP, int BQ, bool IDENT, bool PACKW>
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = kRowBytes / (int)sizeof(T);
+  constexpr int NPB = BP / EPC * 8, NQB = BQ / EPC * 8;  // staging blocks per tile
+  constexpr int ITER = (NPB + NQB + kThreads - 1) / kThreads;
+  constexpr int WP = BP / 2, WQ = BQ / 2;
+  constexpr int FP = WP / 16, FQ = WQ / 16;
+  constexpr int BUF = (BP + BQ) * kRowBytes;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tile_p = bid / p.tiles_n, tile_q = bid - tile_p * p.tiles_n;
+  const int p0 = tile_p * BP, q0 = tile_q * BQ;
+  const int split = blockIdx.y, z = blockIdx.z;
+
+  const char* Pb = p.P + (long long)z * p.p_bs * (long long)sizeof(T);
+  const char* Ab = p.A + (long long)z * p.a_bs * (long long)sizeof(T);
+
+  const int kbeg = split * p.kper;
+  const int kend = min(p.M, kbeg + p.kper);
+  const int ktiles = (kend - kbeg + BK - 1) / BK;
+
+  // static per-thread block assignment
+  int blk_kind[ITER], blk_r[ITER], blk_k[ITER];
+  TapC qtap[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int id = tid + it * kThreads;
+    if (id < NPB) { blk_kind[it] = 0; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
+    else if (id < NPB + NQB) { id -= NPB; blk_kind[it] = 1; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
+    else { blk_kind[it] = 2; blk_r[it] = 0; blk_k[it] = 0; }
+    if (blk_kind[it] == 1) {
+      int kc = (q0 + blk_r[it] * EPC) / EPC;
+      if (IDENT) { qtap[it].ok = kc * EPC < p.K; qtap[it].a = qtap[it].b = qtap[it].c = 0; qtap[it].ci = 0; }
+      else qtap[it] = decode_tap<T, PACKW>(p, kc);
+    }
+  }
+
+  uint4 stg[ITER][EPC];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int kk = kbeg + kt * BK + blk_k[it] * EPC;  // first position of the block
+      if (blk_kind[it] == 0) {
+        const int pc = p0 + blk_r[it] * EPC;
+        const bool cok = pc < p.Ncols;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const int k = kk + j;
+          if (cok && k < kend)
+            stg[it][j] = ld16(Pb, ((long long)k * p.ldp + pc) * (long long)sizeof(T));
+          else
+            stg[it][j] = make_uint4(0, 0, 0, 0);
+        }
+      } else if (blk_kind[it] == 1) {
+        const int kc = (q0 + blk_r[it] * EPC) / EPC;
+        RowC r;
+        if (!IDENT) r = decode_row(p, kk < kend ? kk : 0);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const int k = kk + j;
+          stg[it][j] = load_act_chunk<T, IDENT, false, PACKW>(p, Ab, k, k < kend, r, qtap[it], kc);
+          if (!IDENT) advance_row(p, r);
+        }
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* pt = smem + buf * BUF;
+    char* qt = pt + BP * kRowBytes;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (blk_kind[it] == 2) continue;
+      uint4 tr[EPC];
+      transpose_block(stg[it], tr, T());
+      char* dst = blk_kind[it] == 0 ? pt : qt;
+#pragma unroll
+      for (int c = 0; c < EPC; ++c)
+        *reinterpret_cast<uint4*>(dst + lds_off(blk_r[it] * EPC + c, blk_k[it])) = tr[c];
+    }
+  };
+
+  f32x4_v acc[FQ][FP];
+#pragma unroll
+  for (int a = 0; a < FQ; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  if (ktiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const bool more = kt + 1 < ktiles;
+    if (more) load_tile(kt + 1);
+    const char* pt = smem + (kt & 1) * BUF;
+    const char* qt = pt + BP * kRowBytes;
+#pragma unroll
+    for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
+      typename Mma<T>::Frag pf[FP], qf[FQ];
+#pragma unroll
+      for (int i = 0; i < FP; ++i) pf[i] = Mma<T>::load(pt, wp * WP + i * 16 + l15, ks, g);
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) qf[j] = Mma<T>::load(qt, wq * WQ + j * 16 + l15, ks, g);
+#pragma unroll
+      for (int j = 0; j < FQ; ++j)
+#pragma unroll
+        for (int i = 0; i < FP; ++i) acc[j][i] = Mma<T>::mma(qf[j], pf[i], acc[j][i]);
+    }
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds qq = qb + 0..3 for output row pp ---------------------------------
+  const bool vec_ok = (p.ldo & 3) == 0;
+  const bool to_ws = p.splits > 1;
+#pragma unroll
+  for (int i = 0; i < FP; ++i) {
+    const int pp = p0 + wp * WP + i * 16 + l15;
+    if (pp >= p.Ncols) continue;
+    const float rs = (to_ws || !p.rowscale) ? 1.f : p.rowscale[pp];
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      const int qb = q0 + wq * WQ + j * 16 + g * 4;
+      if (qb >= p.K) continue;
+      const int cnt = (p.K - qb) < 4 ? (p.K - qb) : 4;
+      const long long idx = (long long)pp * p.ldo + qb;
+      float v[4];
+      if (to_ws) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r];
+        store4<float>(reinterpret_cast<char*>(p.ws),
+                      (long long)split * ((long long)p.Ncols * p.ldo) + idx, v, cnt, vec_ok);
+      } else {
+        char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[j][i][r] * p.alpha * rs;
+          if (p.accumulate && r < cnt) x += ld_elem<OutT>(Ob, idx + r);
+          v[r] = x;
+        }
+        store4<OutT>(Ob, idx, v, cnt, vec_ok);
+      }
+    }
+  }
+}
+
+template <typename OutT>
+__global__ void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale, long long n,
+                                    int ldo, int splits, float alpha, int accumulate) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    float4 s = *reinterpret_cast<const float4*>(ws + i);
+    for (int k = 1; k < splits; ++k) {
+      float4 t = *reinterpret_cast<const float4*>(ws + (long long)k * n + i);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float rs = alpha * (rowscale ? rowscale[i / ldo] : 1.f);
+    float v[4] = {s.x * rs, s.y * rs, s.z * rs, s.w * rs};
+    if (accumulate) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += ld_elem<OutT>(O, i + r);
+    }
+    store4<OutT>(O, i, v, 4, true);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return ((1 << l) == v) ? l : -1;
+}
+
+struct Plan {
+  GP gp;
+  bool ident, packw;
+  int bm, bn;     // tile (NT: m x n; TN: p x q)
+  int splits;
+  dim3 grid;
+  size_t lds;
+  long long ws_elems;
+};
+
+int make_plan(const vlfb_conv_desc* d, Plan* pl) {
+  GP& g = pl->gp;
+  ::memset(&g, 0, sizeof(g));
+  VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "conv: bad dtype %d", d->dtype);
+  VLFB_REQUIRE(d->out_dtype == VLFB_F32 || d->out_dtype == d->dtype, "conv: bad out_dtype");
+  VLFB_REQUIRE(d->mode >= 0 && d->mode <= 2, "conv: bad mode %d", d->mode);
+  const int es = d->dtype == VLFB_F32 ? 4 : 2;
+  const int epc = 16 / es;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  VLFB_REQUIRE(d->N > 0 && d->Tr > 0 && d->Hr > 0 && d->Wr > 0, "conv: empty row space");
+  VLFB_REQUIRE(d->Cs > 0 && d->Cn > 0, "conv: Cs/Cn must be positive");
+  const long long M = (long long)d->N * d->Tr * d->Hr * d->Wr;
+  VLFB_REQUIRE(M < (1ll << 31), "conv: too many rows");
+  const int taps = d->kt * d->kh * d->kw;
+  VLFB_REQUIRE(taps >= 1, "conv: bad kernel size");
+  pl->packw = d->pack_w != 0;
+  long long K;
+  int cpt;  // 16-byte chunks per tap
+  if (pl->packw) {
+    VLFB_REQUIRE(d->Cs == 4 && d->dw == 1 && d->pack_w >= d->kw && ilog2_exact(d->pack_w) >= 0,
+                 "conv: pack_w needs Cs==4, dw==1 and a power-of-two kw_pad >= kw");
+    VLFB_REQUIRE(d->mode != VLFB_CONV_DGRAD, "conv: pack_w has no DGRAD");
+    K = (long long)d->kt * d->kh * d->pack_w * 4;
+    cpt = d->pack_w * 4 / epc;
+  } else {
+    VLFB_REQUIRE(d->Cs % epc == 0, "conv: Cs=%d must be a multiple of %d", d->Cs, epc);
+    K = (long long)taps * d->Cs;
+    cpt = d->Cs / epc;
+  }
+  pl->ident = !pl->packw && taps == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
+              d->ph == 0 && d->pw == 0 && d->Ts == d->Tr && d->Hs == d->Hr && d->Ws == d->Wr;
+  if (!pl->ident) {
+    VLFB_REQUIRE(ilog2_exact(cpt) >= 0, "conv: channels per tap must give a power-of-two chunk count");
+    VLFB_REQUIRE(ilog2_exact(d->st) >= 0 && ilog2_exact(d->sh) >= 0 && ilog2_exact(d->sw) >= 0,
+                 "conv: strides must be powers of two");
+    VLFB_REQUIRE(batch == 1, "conv: batched launches must be plain GEMMs");
+  }
+  g.M = (int)M; g.Ncols = d->Cn; g.K = (int)K;
+  g.Tr = d->Tr; g.Hr = d->Hr; g.Wr = d->Wr; g.Ts = d->Ts; g.Hs = d->Hs; g.Ws = d->Ws; g.Cs = d->Cs;
+  g.kh = d->kh; g.kw = d->kw;
+  g.inv_khw = 1.0f / (float)(d->kh * d->kw); g.inv_kw = 1.0f / (float)d->kw; g.inv_kh = 1.0f / (float)d->kh;
+  g.st = d->st; g.sh = d->sh; g.sw = d->sw; g.pt = d->pt; g.ph = d->ph; g.pw = d->pw;
+  g.dt = d->dt; g.dh = d->dh; g.dw = d->dw;
+  g.lst = ilog2_exact(d->st); g.lsh = ilog2_exact(d->sh); g.lsw = ilog2_exact(d->sw);
+  g.cpt_shift = pl->ident ? 0 : ilog2_exact(cpt);
+  g.lda = d->lda ? d->lda : d->Cs;
+  g.ldb = d->ldb ? d->ldb : (int)K;
+  g.ldp = d->ldp ? d->ldp : d->Cn;
+  g.ldo = d->ldo ? d->ldo : (d->mode == VLFB_CONV_WGRAD ? (int)K : d->Cn);
+  g.ldr = d->ldr ? d->ldr : g.ldo;
+  g.a_bs = d->a_bstride; g.b_bs = d->b_bstride; g.o_bs = d->o_bstride; g.r_bs = d->r_bstride;
+  g.p_bs = d->p_bstride;
+  g.alpha = d->alpha; g.relu = d->relu; g.bias_mode = d->bias_mode; g.accumulate = d->accumulate;
+  VLFB_REQUIRE(g.lda % epc == 0 && g.ldb % epc == 0 && g.ldp % epc == 0,
+               "conv: leading dimensions must keep 16-byte alignment");
+
+  pl->splits = 1;
+  pl->ws_elems = 0;
+  if (d->mode != VLFB_CONV_WGRAD) {
+    pl->bm = 128;
+    pl->bn = d->Cn > 64 ? 128 : 64;
+    g.tiles_m = (int)((M + pl->bm - 1) / pl->bm);
+    g.tiles_n = (d->Cn + pl->bn - 1) / pl->bn;
+    pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
+  } else {
+    pl->bm = d->Cn > 64 ? 128 : 64;             // P tile (output rows)
+    pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
+    g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
+    g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
+    const int bk = 128 / es;
+    int splits = d->splits;
+    if (splits <= 0) {
+      long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
+      long long want = (1024 + tiles - 1) / tiles;      // ~4 workgroups per CU
+      long long maxs = (M + 8 * bk - 1) / (8 * bk);     // at least 8 k-tiles per split
+      splits = (int)(want < maxs ? want : maxs);
+      if (splits < 1) splits = 1;
+      if (batch > 1) splits = 1;
+    }
+    VLFB_REQUIRE(splits == 1 || batch == 1, "conv: split WGRAD cannot be batched");
+    long long kper = (M + splits - 1) / splits;
+    kper = (kper + bk - 1) / bk * bk;
+    splits = (int)((M + kper - 1) / kper);
+    g.kper = (int)kper;
+    g.splits = splits;
+    pl->splits = splits;
+    if (splits > 1) {
+      VLFB_REQUIRE(g.ldo == (int)K, "conv: split WGRAD needs a dense output (ldo == K)");
+      pl->ws_elems = (long long)splits * d->Cn * K;
+    }
+    pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
+  }
+  pl->lds = (size_t)2 * (pl->bm + pl->bn) * kRowBytes;
+  return VLFB_OK;
+}
+
+// every instance declares the LDS it needs once (64 KiB for the 128x128 tile)
+template <typename K>
+void launch_k(K kernel, const Plan& pl, hipStream_t s) {
+  static bool configured = false;  // per template instance
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    configured = true;
+  }
+  hipLaunchKernelGGL(kernel, pl.grid, dim3(kThreads), pl.lds, s, pl.gp);
+}
+template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
+void launch_nt(const Plan& pl, hipStream_t s) {
+  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW>, pl, s);
+  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW>, pl, s);
+}
+template <typename T, typename OutT, bool IDENT, bool PACKW>
+void launch_tn(const Plan& pl, hipStream_t s) {
+  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_kernel<T, OutT, 128, 128, IDENT, PACKW>, pl, s);
+  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_kernel<T, OutT, 64, 128, IDENT, PACKW>, pl, s);
+  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_kernel<T, OutT, 128, 64, IDENT, PACKW>, pl, s);
+  else launch_k(gemm_tn_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
+}
+
+template <typename T, typename OutT>
+int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
+  if (d->mode == VLFB_CONV_WGRAD) {
+    if (pl.ident) launch_tn<T, OutT, true, false>(pl, s);
+    else if (pl.packw) launch_tn<T, OutT, false, true>(pl, s);
+    else launch_tn<T, OutT, false, false>(pl, s);
+  } else if (d->mode == VLFB_CONV_DGRAD) {
+    if (pl.ident) launch_nt<T, OutT, true, false, false>(pl, s);
+    else launch_nt<T, OutT, false, true, false>(pl, s);
+  } else {
+    if (pl.ident) launch_nt<T, OutT, true, false, false>(pl, s);
+    else if (pl.packw) launch_nt<T, OutT, false, false, true>(pl, s);
+    else launch_nt<T, OutT, false, false, false>(pl, s);
+  }
+  return check_launch("conv kernel");
+}
+
+}  // namespace
+}  // namespace vlfb
+
+using namespace vlfb;
+
+extern "C" void vlfb_conv_desc_init(vlfb_conv_desc* d) {
+  ::memset(d, 0, sizeof(*d));
+  d->dtype = VLFB_BF16; d->out_dtype = VLFB_BF16;
+  d->N = d->Tr = d->Hr = d->Wr = 1;
+  d->Ts = d->Hs = d->Ws = 1;
+  d->kt = d->kh = d->kw = 1;
+  d->st = d->sh = d->sw = 1;
+  d->dt = d->dh = d->dw = 1;
+  d->batch = 1;
+  d->alpha = 1.0f;
+}
+
+extern "C" int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d) {
+  Plan pl;
+  if (make_plan(d, &pl) != VLFB_OK) return -1;
+  return pl.ws_elems * 4;
+}
+
+extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
+                             void* O, const float* bias, const float* rowscale, const void* R,
+                             const void* Mask, void* workspace, int64_t workspace_bytes,
+                             vlfb_stream_t stream) {
+  Plan pl;
+  int rc = make_plan(d, &pl);
+  if (rc != VLFB_OK) return rc;
+  VLFB_REQUIRE(A && O, "conv: A and O are required");
+  if (d->mode == VLFB_CONV_WGRAD) VLFB_REQUIRE(P != nullptr, "conv: WGRAD needs P");
+  else VLFB_REQUIRE(B != nullptr, "conv: FPROP/DGRAD need B");
+  VLFB_REQUIRE(d->bias_mode == VLFB_BIAS_NONE || bias != nullptr, "conv: bias_mode set but bias is NULL");
+  if (pl.ws_elems > 0 && (workspace == nullptr || workspace_bytes < pl.ws_elems * 4))
+    return set_error(VLFB_ERR_WORKSPACE, "conv: split WGRAD needs %lld workspace bytes, got %lld",
+                     (long long)pl.ws_elems * 4, (long long)workspace_bytes);
+  GP& g = pl.gp;
+  g.A = (const char*)A; g.B = (const char*)B; g.P = (const char*)P; g.O = (char*)O;
+  g.bias = bias; g.rowscale = rowscale; g.R = (const char*)R; g.Mask = (const char*)Mask;
+  g.ws = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
+  else if (d->out_dtype == VLFB_F32) rc = dispatch<bf16_t, float>(d, pl, s);
+  else rc = dispatch<bf16_t, bf16_t>(d, pl, s);
+  if (rc != VLFB_OK) return rc;
+  if (pl.splits > 1) {
+    const long long n = (long long)d->Cn * g.K;
+    VLFB_REQUIRE(n % 4 == 0, "conv: split WGRAD output size must be a multiple of 4");
+    int grid = grid_for(n / 4, 256);
+    if (d->out_dtype == VLFB_F32)
+      hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, g.ws, g.O,
+                         rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g.ws, g.O,
+                         rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate);
+    return check_launch("wgrad reduce");
+  }
+  return VLFB_OK;
+}

@@ -1,0 +1,460 @@
+// Head-side operators: LayerNorm, Dropout, FC, sigmoid cross-entropy, the one-query FBO-NL
+// attention core, and the fused solver step.  Shapes here are tiny (R RoIs x 512 / 2560), so these
+// are latency-bound; each is one launch with wave-level reductions.
+#include "vlfb_common.h"
+#include <math.h>
+
+namespace vlfb {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is 4 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---- LayerNorm (no affine), one wave per row ------------------------------------------------
+template <typename T>
+__global__ void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                     float* __restrict__ rstd, long long rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const T* xr = x + r * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += Elem<T>::ld(xr + c);
+    const float mean = wave_sum(s) / (float)cols;
+    float v = 0.f;
+    for (int c = lane; c < cols; c += 64) { float d = Elem<T>::ld(xr + c) - mean; v += d * d; }
+    const float var = wave_sum(v) / (float)cols;
+    const float rs = 1.0f / sqrtf(var + eps);
+    for (int c = lane; c < cols; c += 64) Elem<T>::st(y + r * cols + c, (Elem<T>::ld(xr + c) - mean) * rs);
+    if (lane == 0) rstd[r] = rs;
+  }
+}
+// dx = rstd * (dy - mean(dy) - y * mean(dy*y))
+template <typename T>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                     long long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const T* gr = dy + r * cols;
+    const T* yr = y + r * cols;
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+      float g = Elem<T>::ld(gr + c);
+      a += g;
+      b += g * Elem<T>::ld(yr + c);
+    }
+    a = wave_sum(a) / (float)cols;
+    b = wave_sum(b) / (float)cols;
+    const float rs = rstd[r];
+    for (int c = lane; c < cols; c += 64)
+      Elem<T>::st(dx + r * cols + c, rs * (Elem<T>::ld(gr + c) - a - Elem<T>::ld(yr + c) * b));
+  }
+}
+
+// ---- Dropout ------------------------------------------------------------------------------------
+// u(seed, i): two rounds of the murmur3 finaliser over (i, seed) -> 24-bit uniform in [0,1).
+// oracle/vlfb_oracle/rng.py implements the same function in numpy.
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ float dropout_uniform(uint64_t seed, uint64_t i) {
+  uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+  uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  uint32_t h = mix32(lo ^ s0);
+  h = mix32(h + 0x9e3779b9u + (hi ^ s1));
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+template <typename T>
+__global__ void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                   uint8_t* __restrict__ mask, long long rows, long long inner,
+                                   long long ch, float ratio, unsigned long long seed) {
+  const long long total = rows * inner * ch;
+  const float keep_scale = 1.0f / (1.0f - ratio);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    // storage index i = (r*inner + k)*ch + c ; reference index = (r*ch + c)*inner + k
+    const long long c = i % ch;
+    const long long rk = i / ch;
+    const long long k = rk % inner, r = rk / inner;
+    const unsigned long long ref = (unsigned long long)((r * ch + c) * inner + k);
+    const bool keep = dropout_uniform(seed, ref) >= ratio;
+    mask[i] = keep ? 1 : 0;
+    Elem<T>::st(y + i, keep ? Elem<T>::ld(x + i) * keep_scale : 0.f);
+  }
+}
+template <typename T>
+__global__ void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                   T* __restrict__ dx, long long n, float ratio) {
+  const float keep_scale = 1.0f / (1.0f - ratio);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    Elem<T>::st(dx + i, mask[i] ? Elem<T>::ld(dy + i) * keep_scale : 0.f);
+}
+
+// ---- FC ---------------------------------------------------------------------------------------
+// one wave per (row, class) pair
+template <typename T>
+__global__ void fc_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                              const float* __restrict__ b, float* __restrict__ logits,
+                              long long rows, int cin, int cout) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long total = rows * cout;
+  for (long long i = wave; i < total; i += nwaves) {
+    const long long r = i / cout;
+    const int k = (int)(i - r * cout);
+    const T* xr = x + r * cin;
+    const float* wk = w + (long long)k * cin;
+    float s = 0.f;
+    for (int c = lane; c < cin; c += 64) s += Elem<T>::ld(xr + c) * wk[c];
+    s = wave_sum(s);
+    if (lane == 0) logits[i] = s + (b ? b[k] : 0.f);
+  }
+}
+template <typename T>
+__global__ void fc_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dl,
+                                 T* __restrict__ dx, long long rows, int cin, int cout) {
+  const long long total = rows * cin;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cin;
+    const int c = (int)(i - r * cin);
+    float s = 0.f;
+    for (int k = 0; k < cout; ++k) s += dl[r * cout + k] * w[(long long)k * cin + c];
+    Elem<T>::st(dx + i, s);
+  }
+}
+template <typename T>
+__global__ void fc_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dl,
+                                 float* __restrict__ dw, float* __restrict__ db, long long rows,
+                                 int cin, int cout, int accumulate) {
+  const long long total = (long long)cout * cin;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / cin);
+    const int c = (int)(i - (long long)k * cin);
+    float s = 0.f;
+    for (long long r = 0; r < rows; ++r) s += dl[r * cout + k] * Elem<T>::ld(x + r * cin + c);
+    dw[i] = accumulate ? dw[i] + s : s;
+    if (c == 0 && db) {
+      float t = 0.f;
+      for (long long r = 0; r < rows; ++r) t += dl[r * cout + k];
+      db[k] = accumulate ? db[k] + t : t;
+    }
+  }
+}
+
+// ---- Sigmoid + SigmoidCrossEntropyLoss (Detectron module semantics) ----------
+__global__ void sigmoid_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                  float* __restrict__ prob, float* __restrict__ loss,
+                                  float* __restrict__ dlogits, long long n, float scale) {
+  __shared__ float red[4];
+  float cnt = 0.f, ls = 0.f;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float x = logits[i];
+    const int t = labels ? labels[i] : 0;
+    if (prob) prob[i] = 1.0f / (1.0f + expf(-x));
+    if (labels && t >= 0) {
+      cnt += 1.f;
+      const float pos = x >= 0.f ? 1.f : 0.f;
+      ls += -x * ((float)t - pos) + logf(1.0f + expf(x - 2.0f * x * pos));
+    }
+  }
+  if (!labels) return;
+  cnt = block_sum(cnt, red);
+  ls = block_sum(ls, red);
+  const float normalizer = fmaxf(cnt, 1e-5f);
+  if (threadIdx.x == 0 && loss) loss[0] = scale * ls / normalizer;
+  if (dlogits) {
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+      const int t = labels[i];
+      const float p = 1.0f / (1.0f + expf(-logits[i]));
+      dlogits[i] = t >= 0 ? scale * (p - (float)t) / normalizer : 0.f;
+    }
+  }
+}
+
+// ---- FBO-NL attention core, one query per row (lfb_helper.py:170-263) ----------------------------
+// one block (256 threads) per row r
+template <typename T>
+__global__ void fbo_attn_fwd_kernel(const T* __restrict__ theta, const T* __restrict__ phi,
+                                    const T* __restrict__ g, float* __restrict__ p, T* __restrict__ t,
+                                    int K, int D, long long ld, float scale) {
+  extern __shared__ float sm[];  // [K] logits/probs + 4 reduction slots
+  float* s = sm;
+  float* red = sm + K;
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* th = theta + (long long)r * D;
+  const T* ph = phi + (long long)r * K * ld;
+  const T* gg = g + (long long)r * K * ld;
+  for (int k = wave; k < K; k += 4) {
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a += Elem<T>::ld(th + d) * Elem<T>::ld(ph + (long long)k * ld + d);
+    a = wave_sum(a);
+    if (lane == 0) s[k] = a * scale;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, s[k]);
+  m = block_max(m, red);
+  float sum = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) sum += expf(s[k] - m);
+  sum = block_sum(sum, red);
+  const float inv = 1.0f / sum;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float pk = expf(s[k] - m) * inv;
+    s[k] = pk;
+    p[(long long)r * K + k] = pk;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += s[k] * Elem<T>::ld(gg + (long long)k * ld + d);
+    Elem<T>::st(t + (long long)r * D + d, a);
+  }
+}
+template <typename T>
+__global__ void fbo_attn_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ theta,
+                                    const T* __restrict__ phi, const T* __restrict__ g,
+                                    const float* __restrict__ p, T* __restrict__ dtheta,
+                                    T* __restrict__ dphi, T* __restrict__ dg, int K, int D,
+                                    long long ld, float scale) {
+  extern __shared__ float sm[];  // [K] ds + 4
+  float* ds = sm;
+  float* red = sm + K;
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* dtr = dt + (long long)r * D;
+  const T* th = theta + (long long)r * D;
+  const T* ph = phi + (long long)r * K * ld;
+  const T* gg = g + (long long)r * K * ld;
+  const float* pr = p + (long long)r * K;
+  // dp[k] = <dt, g[k]>
+  for (int k = wave; k < K; k += 4) {
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a += Elem<T>::ld(dtr + d) * Elem<T>::ld(gg + (long long)k * ld + d);
+    a = wave_sum(a);
+    if (lane == 0) ds[k] = a;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) dot += ds[k] * pr[k];
+  dot = block_sum(dot, red);
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) ds[k] = scale * pr[k] * (ds[k] - dot);
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += ds[k] * Elem<T>::ld(ph + (long long)k * ld + d);
+    Elem<T>::st(dtheta + (long long)r * D + d, a);
+  }
+  const long long kd = (long long)K * D;
+  for (long long i = threadIdx.x; i < kd; i += blockDim.x) {
+    const int k = (int)(i / D);
+    const int d = (int)(i - (long long)k * D);
+    Elem<T>::st(dphi + ((long long)r * K + k) * ld + d, ds[k] * Elem<T>::ld(th + d));
+    Elem<T>::st(dg + ((long long)r * K + k) * ld + d, pr[k] * Elem<T>::ld(dtr + d));
+  }
+}
+
+// ---- solver -------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                           long long n, float lr, float wd, float mu, int nesterov) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = g[i] + wd * pi;           // WeightedSum([g,1,p,wd]) model_builder_video.py:376-383
+    const float mo = m[i];
+    const float mn = mu * mo + lr * gi;        // MomentumSGDUpdate
+    const float step = nesterov ? (1.f + mu) * mn - mu * mo : mn;
+    g[i] = step;                               // Caffe2 writes the adjusted gradient back
+    m[i] = mn;
+    p[i] = pi - step;
+  }
+}
+__global__ void scale_kernel(float* x, long long n, float s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    x[i] *= s;
+}
+
+}  // namespace
+}  // namespace vlfb
+
+using namespace vlfb;
+
+#define DISPATCH_T(dtype, NAME, ...)                                             \
+  if ((dtype) == VLFB_F32) { NAME<float> __VA_ARGS__; }                          \
+  else if ((dtype) == VLFB_BF16) { NAME<bf16_t> __VA_ARGS__; }                   \
+  else return set_error(VLFB_ERR_ARG, "bad dtype %d", (int)(dtype));
+
+extern "C" int vlfb_layernorm_fwd(const void* x, void* y, float* rstd, int dtype, int64_t rows,
+                                  int64_t cols, float eps, vlfb_stream_t stream) {
+  VLFB_REQUIRE(x && y && rstd && rows > 0 && cols > 0, "layernorm_fwd: bad args");
+  int grid = grid_for(rows * 64, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rstd, (long long)rows, (int)cols, eps);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rstd, (long long)rows, (int)cols, eps);
+  else return set_error(VLFB_ERR_ARG, "layernorm_fwd: bad dtype");
+  return check_launch("layernorm_fwd");
+}
+extern "C" int vlfb_layernorm_bwd(const void* dy, const void* y, const float* rstd, void* dx,
+                                  int dtype, int64_t rows, int64_t cols, vlfb_stream_t stream) {
+  VLFB_REQUIRE(dy && y && rstd && dx && rows > 0 && cols > 0, "layernorm_bwd: bad args");
+  int grid = grid_for(rows * 64, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)y, rstd, (float*)dx, (long long)rows, (int)cols);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, rstd, (bf16_t*)dx, (long long)rows, (int)cols);
+  else return set_error(VLFB_ERR_ARG, "layernorm_bwd: bad dtype");
+  return check_launch("layernorm_bwd");
+}
+extern "C" int vlfb_dropout_fwd(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows,
+                                int64_t inner, int64_t ch, float ratio, uint64_t seed,
+                                vlfb_stream_t stream) {
+  VLFB_REQUIRE(x && y && mask && rows > 0 && inner > 0 && ch > 0, "dropout_fwd: bad args");
+  VLFB_REQUIRE(ratio >= 0.f && ratio < 1.f, "dropout_fwd: ratio must be in [0,1)");
+  int grid = grid_for(rows * inner * ch, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed);
+  else return set_error(VLFB_ERR_ARG, "dropout_fwd: bad dtype");
+  return check_launch("dropout_fwd");
+}
+extern "C" int vlfb_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dtype, int64_t n,
+                                float ratio, vlfb_stream_t stream) {
+  VLFB_REQUIRE(dy && mask && dx && n > 0, "dropout_bwd: bad args");
+  int grid = grid_for(n, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, mask, (float*)dx, (long long)n, ratio);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, mask, (bf16_t*)dx, (long long)n, ratio);
+  else return set_error(VLFB_ERR_ARG, "dropout_bwd: bad dtype");
+  return check_launch("dropout_bwd");
+}
+
+extern "C" int vlfb_fc_fwd(const void* x, int dtype, const float* w, const float* b, float* logits,
+                           int64_t rows, int64_t cin, int64_t cout, vlfb_stream_t stream) {
+  VLFB_REQUIRE(x && w && logits && rows > 0 && cin > 0 && cout > 0, "fc_fwd: bad args");
+  int grid = grid_for(rows * cout * 64, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(fc_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, b, logits, (long long)rows, (int)cin, (int)cout);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(fc_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, b, logits, (long long)rows, (int)cin, (int)cout);
+  else return set_error(VLFB_ERR_ARG, "fc_fwd: bad dtype");
+  return check_launch("fc_fwd");
+}
+extern "C" int vlfb_fc_bwd(const void* x, int dtype, const float* w, const float* dlogits, void* dx,
+                           float* dw, float* db, int64_t rows, int64_t cin, int64_t cout,
+                           int accumulate, vlfb_stream_t stream) {
+  VLFB_REQUIRE(x && w && dlogits && rows > 0 && cin > 0 && cout > 0, "fc_bwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype != VLFB_F32 && dtype != VLFB_BF16) return set_error(VLFB_ERR_ARG, "fc_bwd: bad dtype");
+  if (dx) {
+    int grid = grid_for(rows * cin, 256);
+    if (dtype == VLFB_F32)
+      hipLaunchKernelGGL(fc_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, s, w, dlogits, (float*)dx, (long long)rows, (int)cin, (int)cout);
+    else
+      hipLaunchKernelGGL(fc_bwd_dx_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, dlogits, (bf16_t*)dx, (long long)rows, (int)cin, (int)cout);
+  }
+  if (dw) {
+    int grid = grid_for(cout * cin, 256);
+    if (dtype == VLFB_F32)
+      hipLaunchKernelGGL(fc_bwd_dw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, dlogits, dw, db, (long long)rows, (int)cin, (int)cout, accumulate);
+    else
+      hipLaunchKernelGGL(fc_bwd_dw_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, dlogits, dw, db, (long long)rows, (int)cin, (int)cout, accumulate);
+  }
+  return check_launch("fc_bwd");
+}
+extern "C" int vlfb_sigmoid_ce(const float* logits, const int32_t* labels, float* prob, float* loss,
+                               float* dlogits, int64_t rows, int64_t cols, float scale,
+                               vlfb_stream_t stream) {
+  VLFB_REQUIRE(logits && rows > 0 && cols > 0, "sigmoid_ce: bad args");
+  VLFB_REQUIRE(labels || (!loss && !dlogits), "sigmoid_ce: loss/dlogits need labels");
+  hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     prob, loss, dlogits, (long long)(rows * cols), scale);
+  return check_launch("sigmoid_ce");
+}
+
+extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,
+                                 int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                                 vlfb_stream_t stream) {
+  VLFB_REQUIRE(theta && phi && g && p && t && r > 0 && k > 0 && d > 0 && ld >= d, "fbo_attn_fwd: bad args");
+  VLFB_REQUIRE(k <= 8192, "fbo_attn_fwd: bank too long for the LDS row buffer");
+  size_t lds = (size_t)(k + 4) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(fbo_attn_fwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)t, (int)k, (int)d, (long long)ld, scale);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(fbo_attn_fwd_kernel<bf16_t>, dim3((unsigned)r), dim3(256), lds, s, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, p, (bf16_t*)t, (int)k, (int)d, (long long)ld, scale);
+  else return set_error(VLFB_ERR_ARG, "fbo_attn_fwd: bad dtype");
+  return check_launch("fbo_attn_fwd");
+}
+extern "C" int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const void* g,
+                                 const float* p, void* dtheta, void* dphi, void* dg, int dtype,
+                                 int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                                 vlfb_stream_t stream) {
+  VLFB_REQUIRE(dt && theta && phi && g && p && dtheta && dphi && dg && r > 0 && k > 0 && d > 0 && ld >= d,
+               "fbo_attn_bwd: bad args");
+  VLFB_REQUIRE(k <= 8192, "fbo_attn_bwd: bank too long for the LDS row buffer");
+  size_t lds = (size_t)(k + 4) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(fbo_attn_bwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)dt, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)dtheta, (float*)dphi, (float*)dg, (int)k, (int)d, (long long)ld, scale);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(fbo_attn_bwd_kernel<bf16_t>, dim3((unsigned)r), dim3(256), lds, s, (const bf16_t*)dt, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, p, (bf16_t*)dtheta, (bf16_t*)dphi, (bf16_t*)dg, (int)k, (int)d, (long long)ld, scale);
+  else return set_error(VLFB_ERR_ARG, "fbo_attn_bwd: bad dtype");
+  return check_launch("fbo_attn_bwd");
+}
+
+extern "C" int vlfb_sgd_update(float* p, float* g, float* m, int64_t n, float lr, float wd, float mu,
+                               int nesterov, vlfb_stream_t stream) {
+  VLFB_REQUIRE(p && g && m && n > 0, "sgd_update: bad args");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     (long long)n, lr, wd, mu, nesterov);
+  return check_launch("sgd_update");
+}
+extern "C" int vlfb_scale_inplace(float* x, int64_t n, float sc, vlfb_stream_t stream) {
+  VLFB_REQUIRE(x && n > 0, "scale_inplace: bad args");
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)n, sc);
+  return check_launch("scale_inplace");
+}

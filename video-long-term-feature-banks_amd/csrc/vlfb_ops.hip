@@ -1,0 +1,702 @@
+// HBM-bound operators of the hot path: AffineNd (the reference's only native op), layout movers,
+// pools, row softmax, residual add / ReLU, column sums.  All are one-pass, 16-byte-per-lane
+// vectorised kernels; the roofline that bounds them is HBM bandwidth.
+#include "vlfb_common.h"
+#include <math.h>
+
+namespace vlfb {
+
+static thread_local char g_err[512] = "";
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// AffineNd: y[n][c][i] = x*s[c] + b[c]   (affine_nd_op.cu:31-44), dx = dy*s[c] (46-58)
+// grid.y walks the (n,c) rows so the per-row scale/bias are scalar loads.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_BIAS>
+__global__ void affine_nd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                 const float* __restrict__ bias, float* __restrict__ y,
+                                 long long rows, int C, long long inner) {
+  for (long long row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int c = (int)(row % C);
+    const float s = scale[c];
+    const float b = HAS_BIAS ? bias[c] : 0.f;
+    const float* xr = x + row * inner;
+    float* yr = y + row * inner;
+    const bool vec = ((inner & 3) == 0) && ((((uintptr_t)xr | (uintptr_t)yr) & 15) == 0);
+    if (vec) {
+      const long long n4 = inner >> 2;
+      for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+           i += (long long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(xr)[i];
+        v.x = v.x * s + b; v.y = v.y * s + b; v.z = v.z * s + b; v.w = v.w * s + b;
+        reinterpret_cast<float4*>(yr)[i] = v;
+      }
+    } else {
+      for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < inner;
+           i += (long long)gridDim.x * blockDim.x)
+        yr[i] = xr[i] * s + b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout movers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void ncthw_to_nthwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                      long long n, int c, long long thw, int c_pad) {
+  const long long total = n * thw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / thw, pos = i - b * thw;
+    const float* s = src + b * c * thw + pos;
+    T* d = dst + i * c_pad;
+    for (int k = 0; k < c_pad; ++k) Elem<T>::st(d + k, k < c ? s[(long long)k * thw] : 0.f);
+  }
+}
+template <typename T>
+__global__ void nthwc_to_ncthw_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                      long long n, int c, long long thw) {
+  const long long total = n * c * thw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long pos = i % thw;
+    const long long bc = i / thw;
+    const long long b = bc / c;
+    const int k = (int)(bc - b * c);
+    dst[i] = Elem<T>::ld(src + (b * thw + pos) * c + k);
+  }
+}
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    Elem<D>::st(dst + i, Elem<S>::ld(src + i));
+}
+template <typename T>
+__global__ void transpose2d_kernel(const T* __restrict__ src, T* __restrict__ dst, long long rows,
+                                   long long cols) {
+  __shared__ T tile[32][33];
+  const long long b = blockIdx.z;
+  const T* s = src + b * rows * cols;
+  T* d = dst + b * rows * cols;
+  const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    long long r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = s[r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    long long c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) d[c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+
+// w[Cout][taps][Cin] fp32 (+ scale[Cout]) -> fprop copy (same order) in T
+template <typename T>
+__global__ void weight_prep_fprop_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         T* __restrict__ out, long long per_cout, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float s = scale ? scale[i / per_cout] : 1.f;
+    Elem<T>::st(out + i, w[i] * s);
+  }
+}
+// -> dgrad copy [Cin][taps][Cout]; blockIdx.z = tap; 32x32 LDS tile transpose
+template <typename T>
+__global__ void weight_prep_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         T* __restrict__ out, int cout, int taps, int cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int co = co0 + j, ci = ci0 + threadIdx.x;
+    if (co < cout && ci < cin)
+      tile[j][threadIdx.x] = w[((long long)co * taps + tap) * cin + ci] * (scale ? scale[co] : 1.f);
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int ci = ci0 + j, co = co0 + threadIdx.x;
+    if (co < cout && ci < cin)
+      Elem<T>::st(out + ((long long)ci * taps + tap) * cout + co, tile[threadIdx.x][j]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pools (channels-last).  One thread = one position x one 16-byte channel chunk.
+// ---------------------------------------------------------------------------------------------
+struct PoolP {
+  int N, Ti, Hi, Wi, C, To, Ho, Wo;
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+};
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                   uint8_t* __restrict__ argmax, PoolP p) {
+  constexpr int V = Vec16<T>::N;
+  const int cchunks = p.C / V;
+  const long long total = (long long)p.N * p.To * p.Ho * p.Wo * cchunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long o = i / cchunks;
+    const int wo = (int)(o % p.Wo); long long r = o / p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int to = (int)(r % p.To);
+    const int n = (int)(r / p.To);
+    float best[V];
+    int arg[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; arg[k] = 0; }
+    for (int a = 0; a < p.kt; ++a) {
+      const int ti = to * p.st - p.pt + a;
+      if ((unsigned)ti >= (unsigned)p.Ti) continue;
+      for (int b = 0; b < p.kh; ++b) {
+        const int hi = ho * p.sh - p.ph + b;
+        if ((unsigned)hi >= (unsigned)p.Hi) continue;
+        for (int c = 0; c < p.kw; ++c) {
+          const int wi = wo * p.sw - p.pw + c;
+          if ((unsigned)wi >= (unsigned)p.Wi) continue;
+          float v[V];
+          Vec16<T>::load(x + ((((long long)n * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * p.C + cc * V, v);
+          const int tap = (a * p.kh + b) * p.kw + c;
+#pragma unroll
+          for (int k = 0; k < V; ++k)
+            if (v[k] > best[k]) { best[k] = v[k]; arg[k] = tap; }
+        }
+      }
+    }
+    Vec16<T>::store(y + o * p.C + cc * V, best);
+    if (argmax) {
+      uint8_t* am = argmax + o * p.C + cc * V;
+      if (V == 8) {
+        uint2 pk;
+        pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+        pk.y = arg[4 % V] | (arg[5 % V] << 8) | (arg[6 % V] << 16) | (arg[7 % V] << 24);
+        *reinterpret_cast<uint2*>(am) = pk;
+      } else {
+        *reinterpret_cast<uint32_t*>(am) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+      }
+    }
+  }
+}
+
+// gather formulation of the pool backward: every input position sums the output gradients
+// of the windows that (a) cover it and (b) for max pooling selected it.
+template <typename T, bool IS_MAX>
+__global__ void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                T* dx, const T* add, const T* __restrict__ mask, PoolP p,
+                                float inv_window) {
+  constexpr int V = Vec16<T>::N;
+  const int cchunks = p.C / V;
+  const long long total = (long long)p.N * p.Ti * p.Hi * p.Wi * cchunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long q = i / cchunks;
+    const int wi = (int)(q % p.Wi); long long r = q / p.Wi;
+    const int hi = (int)(r % p.Hi); r /= p.Hi;
+    const int ti = (int)(r % p.Ti);
+    const int n = (int)(r / p.Ti);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    // windows `to` with to*st - pt <= ti <= to*st - pt + kt - 1
+    const int t_lo = max(0, (ti + p.pt - p.kt + p.st) / p.st), t_hi = min(p.To - 1, (ti + p.pt) / p.st);
+    const int h_lo = max(0, (hi + p.ph - p.kh + p.sh) / p.sh), h_hi = min(p.Ho - 1, (hi + p.ph) / p.sh);
+    const int w_lo = max(0, (wi + p.pw - p.kw + p.sw) / p.sw), w_hi = min(p.Wo - 1, (wi + p.pw) / p.sw);
+    for (int to = t_lo; to <= t_hi; ++to) {
+      const int a = ti + p.pt - to * p.st;
+      if (a < 0 || a >= p.kt) continue;
+      for (int ho = h_lo; ho <= h_hi; ++ho) {
+        const int b = hi + p.ph - ho * p.sh;
+        if (b < 0 || b >= p.kh) continue;
+        for (int wo = w_lo; wo <= w_hi; ++wo) {
+          const int c = wi + p.pw - wo * p.sw;
+          if (c < 0 || c >= p.kw) continue;
+          const long long o = (((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+          float g[V];
+          Vec16<T>::load(dy + o * p.C + cc * V, g);
+          if (IS_MAX) {
+            const int tap = (a * p.kh + b) * p.kw + c;
+            const uint8_t* am = argmax + o * p.C + cc * V;
+            uint32_t w0 = *reinterpret_cast<const uint32_t*>(am);
+            uint32_t w1 = V == 8 ? *reinterpret_cast<const uint32_t*>(am + 4) : 0u;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+              const int sel = (int)(((k < 4 ? w0 : w1) >> (8 * (k & 3))) & 0xff);
+              if (sel == tap) acc[k] += g[k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += g[k] * inv_window;
+          }
+        }
+      }
+    }
+    const long long off = q * p.C + cc * V;
+    if (add) {
+      float a2[V];
+      Vec16<T>::load(add + off, a2);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += a2[k];
+    }
+    if (mask) {
+      float mk[V];
+      Vec16<T>::load(mask + off, mk);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] = mk[k] > 0.f ? acc[k] : 0.f;
+    }
+    Vec16<T>::store(dx + off, acc);
+  }
+}
+
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolP p) {
+  constexpr int V = Vec16<T>::N;
+  const int cchunks = p.C / V;
+  const long long total = (long long)p.N * p.To * p.Ho * p.Wo * cchunks;
+  const float inv = 1.0f / (float)(p.kt * p.kh * p.kw);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long o = i / cchunks;
+    const int wo = (int)(o % p.Wo); long long r = o / p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int to = (int)(r % p.To);
+    const int n = (int)(r / p.To);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int a = 0; a < p.kt; ++a)
+      for (int b = 0; b < p.kh; ++b)
+        for (int c = 0; c < p.kw; ++c) {
+          const int ti = to * p.st + a, hi = ho * p.sh + b, wi = wo * p.sw + c;
+          float v[V];
+          Vec16<T>::load(x + ((((long long)n * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * p.C + cc * V, v);
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[k] += v[k];
+        }
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] *= inv;
+    Vec16<T>::store(y + o * p.C + cc * V, acc);
+  }
+}
+
+// global average: y[n][c] = mean over `rows` positions.  block = (8 chunk lanes) x (32 row lanes)
+template <typename T>
+__global__ void global_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows,
+                                      int C) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[32][8 * 8 + 1];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int n = blockIdx.y;
+  const int c0 = (blockIdx.x * 8 + cl) * V;
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  if (c0 < C) {
+    const T* base = x + (long long)n * rows * C + c0;
+    for (long long r = rl; r < rows; r += 32) {
+      float v[V];
+      Vec16<T>::load(base + r * C, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[rl][cl * 8 + k] = acc[k];
+  __syncthreads();
+  if (rl == 0 && c0 < C) {
+    float inv = 1.0f / (float)rows;
+    float out[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += red[j][cl * 8 + k];
+      out[k] = s * inv;
+    }
+    Vec16<T>::store(y + (long long)n * C + c0, out);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row softmax (one wave per row; rows stay L1/L2-resident between the passes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename T>
+__global__ void softmax_fwd_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows,
+                                   int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const float* sr = s + r * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, sr[c] * scale);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += __expf(sr[c] * scale - m);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* pr = p + r * cols;
+    for (int c = lane; c < cols; c += 64) Elem<T>::st(pr + c, __expf(sr[c] * scale - m) * inv);
+  }
+}
+template <typename T>
+__global__ void softmax_bwd_kernel(const float* __restrict__ dp, const T* __restrict__ p,
+                                   T* __restrict__ ds, long long rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const float* dr = dp + r * cols;
+    const T* pr = p + r * cols;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot += dr[c] * Elem<T>::ld(pr + c);
+    dot = wave_sum(dot);
+    T* o = ds + r * cols;
+    for (int c = lane; c < cols; c += 64)
+      Elem<T>::st(o + c, scale * Elem<T>::ld(pr + c) * (dr[c] - dot));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small elementwise
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* y, const T* __restrict__ mask, long long n,
+                           int relu) {
+  constexpr int V = Vec16<T>::N;
+  const long long nv = n / V;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (long long)gridDim.x * blockDim.x) {
+    float x[V], z[V];
+    Vec16<T>::load(a + i * V, x);
+    if (b) {
+      Vec16<T>::load(b + i * V, z);
+#pragma unroll
+      for (int k = 0; k < V; ++k) x[k] += z[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) x[k] = fmaxf(x[k], 0.f);
+    }
+    if (mask) {
+      Vec16<T>::load(mask + i * V, z);
+#pragma unroll
+      for (int k = 0; k < V; ++k) x[k] = z[k] > 0.f ? x[k] : 0.f;
+    }
+    Vec16<T>::store(y + i * V, x);
+  }
+  // tail
+  for (long long i = nv * V + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float x = Elem<T>::ld(a + i) + (b ? Elem<T>::ld(b + i) : 0.f);
+    if (relu) x = fmaxf(x, 0.f);
+    if (mask) x = Elem<T>::ld(mask + i) > 0.f ? x : 0.f;
+    Elem<T>::st(y + i, x);
+  }
+}
+
+// column sums with a (64 channels) x (row slab) block; fp32 atomics onto a tiny output.
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ g, long long rows, int cols, long long ld,
+                              float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
+  const int c = blockIdx.x * 64 + cl;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float acc = 0.f;
+  if (c < cols)
+    for (long long r = r0 + rl; r < r1; r += 4) acc += Elem<T>::ld(g + r * ld + c);
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+__global__ void zero_kernel(float* p, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = 0.f;
+}
+
+PoolP to_poolp(const vlfb_pool_desc* d) {
+  PoolP p;
+  p.N = d->N; p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi; p.C = d->C;
+  p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.st = d->st; p.sh = d->sh; p.sw = d->sw;
+  p.pt = d->pt; p.ph = d->ph; p.pw = d->pw;
+  return p;
+}
+int check_pool(const vlfb_pool_desc* d) {
+  VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "pool: bad dtype");
+  const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  VLFB_REQUIRE(d->C % v == 0, "pool: C=%d must be a multiple of %d", d->C, v);
+  VLFB_REQUIRE(d->kt * d->kh * d->kw <= 255, "pool: window too large for uint8 argmax");
+  VLFB_REQUIRE(d->N > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0, "pool: empty output");
+  return VLFB_OK;
+}
+
+}  // namespace
+}  // namespace vlfb
+
+using namespace vlfb;
+
+extern "C" const char* vlfb_last_error(void) { return g_err; }
+extern "C" int vlfb_version(void) { return 100; }
+extern "C" int vlfb_dtype_size(int dtype) { return dtype == VLFB_F32 ? 4 : dtype == VLFB_BF16 ? 2 : 0; }
+
+extern "C" int vlfb_affine_nd_fwd(const float* x, const float* scale, const float* bias, float* y,
+                                  int64_t n, int64_t c, int64_t inner, vlfb_stream_t stream) {
+  VLFB_REQUIRE(x && scale && bias && y, "affine_nd_fwd: null pointer");
+  VLFB_REQUIRE(n > 0 && c > 0 && inner > 0, "affine_nd_fwd: empty tensor");
+  VLFB_REQUIRE(n * c * inner < (1ll << 31), "affine_nd_fwd: numel must stay below 2^31 (affine_nd_op.cu:69)");
+  const long long rows = n * c;
+  dim3 grid((unsigned)grid_for((inner + 3) / 4, 256, 64), (unsigned)(rows < 16384 ? rows : 16384));
+  hipLaunchKernelGGL(affine_nd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, scale, bias,
+                     y, rows, (int)c, (long long)inner);
+  return check_launch("affine_nd_fwd");
+}
+extern "C" int vlfb_affine_nd_bwd(const float* dy, const float* scale, float* dx, int64_t n,
+                                  int64_t c, int64_t inner, vlfb_stream_t stream) {
+  VLFB_REQUIRE(dy && scale && dx, "affine_nd_bwd: null pointer");
+  VLFB_REQUIRE(n > 0 && c > 0 && inner > 0, "affine_nd_bwd: empty tensor");
+  VLFB_REQUIRE(n * c * inner < (1ll << 31), "affine_nd_bwd: numel must stay below 2^31");
+  const long long rows = n * c;
+  dim3 grid((unsigned)grid_for((inner + 3) / 4, 256, 64), (unsigned)(rows < 16384 ? rows : 16384));
+  hipLaunchKernelGGL(affine_nd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, scale,
+                     (const float*)nullptr, dx, rows, (int)c, (long long)inner);
+  return check_launch("affine_nd_bwd");
+}
+
+extern "C" int vlfb_ncthw_to_nthwc(const float* src, void* dst, int dtype, int64_t n, int64_t c,
+                                   int64_t thw, int64_t c_pad, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && c_pad >= c && n > 0 && c > 0 && thw > 0, "ncthw_to_nthwc: bad args");
+  int grid = grid_for(n * thw, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(ncthw_to_nthwc_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       src, (float*)dst, (long long)n, (int)c, (long long)thw, (int)c_pad);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(ncthw_to_nthwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       src, (bf16_t*)dst, (long long)n, (int)c, (long long)thw, (int)c_pad);
+  else return set_error(VLFB_ERR_ARG, "ncthw_to_nthwc: bad dtype");
+  return check_launch("ncthw_to_nthwc");
+}
+extern "C" int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64_t n, int64_t c,
+                                   int64_t thw, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && n > 0 && c > 0 && thw > 0, "nthwc_to_ncthw: bad args");
+  int grid = grid_for(n * c * thw, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(nthwc_to_ncthw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, dst, (long long)n, (int)c, (long long)thw);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(nthwc_to_ncthw_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, dst, (long long)n, (int)c, (long long)thw);
+  else return set_error(VLFB_ERR_ARG, "nthwc_to_ncthw: bad dtype");
+  return check_launch("nthwc_to_ncthw");
+}
+extern "C" int vlfb_cast(const void* src, int sd, void* dst, int dd, int64_t n, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && n >= 0, "cast: bad args");
+  if (n == 0) return VLFB_OK;
+  int grid = grid_for(n, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (sd == VLFB_F32 && dd == VLFB_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, (long long)n);
+  else if (sd == VLFB_BF16 && dd == VLFB_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, (long long)n);
+  else if (sd == VLFB_F32 && dd == VLFB_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, (long long)n);
+  else if (sd == VLFB_BF16 && dd == VLFB_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long long)n);
+  else return set_error(VLFB_ERR_ARG, "cast: bad dtypes %d -> %d", sd, dd);
+  return check_launch("cast");
+}
+extern "C" int vlfb_transpose2d(const void* src, void* dst, int dtype, int64_t batch, int64_t rows,
+                                int64_t cols, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && batch > 0 && rows > 0 && cols > 0, "transpose2d: bad args");
+  VLFB_REQUIRE(batch < 65536 && (rows + 31) / 32 < 65536, "transpose2d: grid too large");
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+  dim3 block(32, 8);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(transpose2d_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, (float*)dst, (long long)rows, (long long)cols);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(transpose2d_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, (long long)rows, (long long)cols);
+  else return set_error(VLFB_ERR_ARG, "transpose2d: bad dtype");
+  return check_launch("transpose2d");
+}
+extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fprop, void* w_dgrad,
+                                int dtype, int64_t cout, int64_t taps, int64_t cin,
+                                vlfb_stream_t stream) {
+  VLFB_REQUIRE(w && (w_fprop || w_dgrad) && cout > 0 && taps > 0 && cin > 0, "weight_prep: bad args");
+  VLFB_REQUIRE(dtype == VLFB_F32 || dtype == VLFB_BF16, "weight_prep: bad dtype");
+  VLFB_REQUIRE(taps < 65536, "weight_prep: too many taps");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = cout * taps * cin;
+  if (w_fprop) {
+    int grid = grid_for(total, 256);
+    if (dtype == VLFB_F32)
+      hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, (float*)w_fprop, (long long)(taps * cin), total);
+    else
+      hipLaunchKernelGGL(weight_prep_fprop_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, scale, (bf16_t*)w_fprop, (long long)(taps * cin), total);
+  }
+  if (w_dgrad) {
+    dim3 grid((unsigned)((cin + 31) / 32), (unsigned)((cout + 31) / 32), (unsigned)taps);
+    if (dtype == VLFB_F32)
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<float>, grid, dim3(32, 8), 0, s, w, scale, (float*)w_dgrad, (int)cout, (int)taps, (int)cin);
+    else
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, scale, (bf16_t*)w_dgrad, (int)cout, (int)taps, (int)cin);
+  }
+  return check_launch("weight_prep");
+}
+
+extern "C" int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, uint8_t* argmax,
+                                vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(x && y, "maxpool_fwd: null pointer");
+  PoolP p = to_poolp(d);
+  const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  int grid = grid_for((long long)p.N * p.To * p.Ho * p.Wo * (p.C / v), 256);
+  if (d->dtype == VLFB_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, argmax, p);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, argmax, p);
+  return check_launch("maxpool_fwd");
+}
+extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const uint8_t* argmax,
+                                void* dx, const void* add, const void* mask, vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
+  PoolP p = to_poolp(d);
+  const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
+  if (d->dtype == VLFB_F32)
+    hipLaunchKernelGGL((pool_bwd_kernel<float, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, argmax, (float*)dx, (const float*)add, (const float*)mask, p, 1.f);
+  else
+    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, argmax, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, 1.f);
+  return check_launch("maxpool_bwd");
+}
+extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(x && y, "avgpool_fwd: null pointer");
+  VLFB_REQUIRE(d->pt == 0 && d->ph == 0 && d->pw == 0, "avgpool: padding is not supported (none in the reference)");
+  PoolP p = to_poolp(d);
+  const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  hipStream_t s = (hipStream_t)stream;
+  const bool global = p.To == 1 && p.Ho == 1 && p.Wo == 1 && p.kt == p.Ti && p.kh == p.Hi && p.kw == p.Wi;
+  if (global && p.N < 65536) {
+    dim3 grid((unsigned)((p.C / v + 7) / 8), (unsigned)p.N);
+    const long long rows = (long long)p.Ti * p.Hi * p.Wi;
+    if (d->dtype == VLFB_F32)
+      hipLaunchKernelGGL(global_avgpool_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, rows, p.C);
+    else
+      hipLaunchKernelGGL(global_avgpool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, p.C);
+  } else {
+    int grid = grid_for((long long)p.N * p.To * p.Ho * p.Wo * (p.C / v), 256);
+    if (d->dtype == VLFB_F32)
+      hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, p);
+    else
+      hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, p);
+  }
+  return check_launch("avgpool_fwd");
+}
+extern "C" int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* dx, const void* add,
+                                const void* mask, vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(dy && dx, "avgpool_bwd: null pointer");
+  VLFB_REQUIRE(d->pt == 0 && d->ph == 0 && d->pw == 0, "avgpool: padding is not supported");
+  PoolP p = to_poolp(d);
+  const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  const float inv = 1.0f / (float)(p.kt * p.kh * p.kw);
+  int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
+  if (d->dtype == VLFB_F32)
+    hipLaunchKernelGGL((pool_bwd_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const uint8_t*)nullptr, (float*)dx, (const float*)add, (const float*)mask, p, inv);
+  else
+    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const uint8_t*)nullptr, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, inv);
+  return check_launch("avgpool_bwd");
+}
+
+extern "C" int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows, int64_t cols,
+                                float scale, vlfb_stream_t stream) {
+  VLFB_REQUIRE(s && p && rows > 0 && cols > 0 && cols < (1ll << 31), "softmax_fwd: bad args");
+  int grid = grid_for(rows * 64, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (float*)p, (long long)rows, (int)cols, scale);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, (long long)rows, (int)cols, scale);
+  else return set_error(VLFB_ERR_ARG, "softmax_fwd: bad dtype");
+  return check_launch("softmax_fwd");
+}
+extern "C" int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dtype, int64_t rows,
+                                int64_t cols, float scale, vlfb_stream_t stream) {
+  VLFB_REQUIRE(dp && p && ds && rows > 0 && cols > 0 && cols < (1ll << 31), "softmax_bwd: bad args");
+  int grid = grid_for(rows * 64, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (const bf16_t*)p, (bf16_t*)ds, (long long)rows, (int)cols, scale);
+  else return set_error(VLFB_ERR_ARG, "softmax_bwd: bad dtype");
+  return check_launch("softmax_bwd");
+}
+
+extern "C" int vlfb_add(const void* a, const void* b, void* y, const void* mask, int dtype,
+                        int64_t n, int relu, vlfb_stream_t stream) {
+  VLFB_REQUIRE(a && y && n >= 0, "add: bad args");
+  if (n == 0) return VLFB_OK;
+  const int v = dtype == VLFB_F32 ? 4 : 8;
+  int grid = grid_for((n + v - 1) / v, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, (const float*)mask, (long long)n, relu);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (const bf16_t*)mask, (long long)n, relu);
+  else return set_error(VLFB_ERR_ARG, "add: bad dtype");
+  return check_launch("add");
+}
+extern "C" int vlfb_relu_fwd(const void* x, void* y, int dtype, int64_t n, vlfb_stream_t stream) {
+  return vlfb_add(x, nullptr, y, nullptr, dtype, n, 1, stream);
+}
+extern "C" int vlfb_relu_bwd(const void* dy, const void* yv, void* dx, int dtype, int64_t n,
+                             vlfb_stream_t stream) {
+  VLFB_REQUIRE(yv != nullptr, "relu_bwd: y is required");
+  return vlfb_add(dy, nullptr, dx, yv, dtype, n, 0, stream);
+}
+extern "C" int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld,
+                           float* out, int accumulate, vlfb_stream_t stream) {
+  VLFB_REQUIRE(g && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate)
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(cols, 256)), dim3(256), 0, s, out, (long long)cols);
+  int slabs = (int)((rows + 255) / 256);
+  if (slabs > 256) slabs = 256;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)slabs);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)g, (long long)rows, (int)cols, (long long)ld, out);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, (long long)rows, (int)cols, (long long)ld, out);
+  else return set_error(VLFB_ERR_ARG, "colsum: bad dtype");
+  return check_launch("colsum");
+}

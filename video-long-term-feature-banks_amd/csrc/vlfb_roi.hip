@@ -1,0 +1,195 @@
+// RoIAlign (legacy Caffe2 semantics, sampling_ratio = 0) fused with the 7x7 max pool that
+// follows it in the RoI head (lib/models/head_helper.py:88-123, lib/models/lfb_helper.py:130-152).
+//
+// Build note: this file is compiled with -ffp-contract=off.  The integer decisions of RoIAlign
+// (sampling-grid size, bilinear corner indices, the out-of-range predicate) depend on the exact
+// fp32 operation order of the Caffe2 operator; fused multiply-adds would
+// change roundings and therefore indices, and the parity bar for those is bit-exact.
+#include "vlfb_common.h"
+#include <math.h>
+
+namespace vlfb {
+namespace {
+
+struct RoiGeom {
+  int batch;
+  float start_w, start_h, bin_h, bin_w;
+  int grid_h, grid_w;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float spatial_scale, int pooled) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.start_w = roi[1] * spatial_scale;
+  g.start_h = roi[2] * spatial_scale;
+  const float end_w = roi[3] * spatial_scale;
+  const float end_h = roi[4] * spatial_scale;
+  const float roi_w = fmaxf(end_w - g.start_w, 1.0f);
+  const float roi_h = fmaxf(end_h - g.start_h, 1.0f);
+  g.bin_h = roi_h / (float)pooled;
+  g.bin_w = roi_w / (float)pooled;
+  g.grid_h = (int)ceilf(roi_h / (float)pooled);
+  g.grid_w = (int)ceilf(roi_w / (float)pooled);
+  return g;
+}
+
+struct Bilin {
+  int y_low, x_low, y_high, x_high;
+  float w1, w2, w3, w4;
+  bool inside;
+};
+
+__device__ __forceinline__ Bilin bilinear(float y, float x, int height, int width) {
+  Bilin b;
+  b.inside = !(y < -1.0f || y > (float)height || x < -1.0f || x > (float)width);
+  if (!b.inside) {
+    b.y_low = b.x_low = b.y_high = b.x_high = -1;
+    b.w1 = b.w2 = b.w3 = b.w4 = 0.f;
+    return b;
+  }
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  b.y_low = (int)y;
+  b.x_low = (int)x;
+  if (b.y_low >= height - 1) { b.y_high = b.y_low = height - 1; y = (float)b.y_low; }
+  else b.y_high = b.y_low + 1;
+  if (b.x_low >= width - 1) { b.x_high = b.x_low = width - 1; x = (float)b.x_low; }
+  else b.x_high = b.x_low + 1;
+  const float ly = y - (float)b.y_low, lx = x - (float)b.x_low;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+  return b;
+}
+
+// one block per RoI; each thread owns one 16-byte channel chunk (loops if C is larger)
+template <typename T>
+__global__ void roi_align_max_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ rois,
+                                         T* __restrict__ out, uint8_t* __restrict__ argbin,
+                                         int32_t* __restrict__ dbg, int H, int W, int C, int pooled,
+                                         float spatial_scale) {
+  constexpr int V = Vec16<T>::N;
+  const int r = blockIdx.x;
+  const RoiGeom g = roi_geom(rois + (long long)r * 5, spatial_scale, pooled);
+  const float count = (float)(g.grid_h * g.grid_w);
+  const T* fb = feat + (long long)g.batch * H * W * C;
+
+  if (dbg && threadIdx.x == 0) {
+    for (int ph = 0; ph < pooled; ++ph)
+      for (int pw = 0; pw < pooled; ++pw) {
+        const float y = g.start_h + (float)ph * g.bin_h + (0.5f * g.bin_h) / (float)g.grid_h;
+        const float x = g.start_w + (float)pw * g.bin_w + (0.5f * g.bin_w) / (float)g.grid_w;
+        const Bilin b = bilinear(y, x, H, W);
+        int32_t* d = dbg + (((long long)r * pooled + ph) * pooled + pw) * 8;
+        d[0] = g.batch; d[1] = g.grid_h; d[2] = g.grid_w;
+        d[3] = b.y_low; d[4] = b.x_low; d[5] = b.y_high; d[6] = b.x_high; d[7] = b.inside ? 1 : 0;
+      }
+  }
+
+  for (int c0 = threadIdx.x * V; c0 < C; c0 += blockDim.x * V) {
+    float best[V];
+    int arg[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; arg[k] = 0; }
+    for (int ph = 0; ph < pooled; ++ph)
+      for (int pw = 0; pw < pooled; ++pw) {
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+          const float y = g.start_h + (float)ph * g.bin_h + (((float)iy + 0.5f) * g.bin_h) / (float)g.grid_h;
+          for (int ix = 0; ix < g.grid_w; ++ix) {
+            const float x = g.start_w + (float)pw * g.bin_w + (((float)ix + 0.5f) * g.bin_w) / (float)g.grid_w;
+            const Bilin b = bilinear(y, x, H, W);
+            if (!b.inside) continue;
+            float v1[V], v2[V], v3[V], v4[V];
+            Vec16<T>::load(fb + ((long long)b.y_low * W + b.x_low) * C + c0, v1);
+            Vec16<T>::load(fb + ((long long)b.y_low * W + b.x_high) * C + c0, v2);
+            Vec16<T>::load(fb + ((long long)b.y_high * W + b.x_low) * C + c0, v3);
+            Vec16<T>::load(fb + ((long long)b.y_high * W + b.x_high) * C + c0, v4);
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += b.w1 * v1[k] + b.w2 * v2[k] + b.w3 * v3[k] + b.w4 * v4[k];
+          }
+        }
+        const int bin = ph * pooled + pw;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float v = acc[k] / count;
+          if (v > best[k]) { best[k] = v; arg[k] = bin; }
+        }
+      }
+    Vec16<T>::store(out + (long long)r * C + c0, best);
+#pragma unroll
+    for (int k = 0; k < V; ++k) argbin[(long long)r * C + c0 + k] = (uint8_t)arg[k];
+  }
+}
+
+// one thread per (roi, channel); scatters through the selected bin with fp32 atomics
+template <typename T>
+__global__ void roi_align_max_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+                                         const uint8_t* __restrict__ argbin, float* __restrict__ dfeat,
+                                         long long R, int H, int W, int C, int pooled,
+                                         float spatial_scale) {
+  const long long total = R * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const RoiGeom g = roi_geom(rois + r * 5, spatial_scale, pooled);
+    const float count = (float)(g.grid_h * g.grid_w);
+    const int bin = argbin[i];
+    const int ph = bin / pooled, pw = bin - ph * pooled;
+    const float gv = Elem<T>::ld(dout + i) / count;
+    float* fb = dfeat + (long long)g.batch * H * W * C + c;
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      const float y = g.start_h + (float)ph * g.bin_h + (((float)iy + 0.5f) * g.bin_h) / (float)g.grid_h;
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        const float x = g.start_w + (float)pw * g.bin_w + (((float)ix + 0.5f) * g.bin_w) / (float)g.grid_w;
+        const Bilin b = bilinear(y, x, H, W);
+        if (!b.inside) continue;
+        atomicAdd(fb + ((long long)b.y_low * W + b.x_low) * C, gv * b.w1);
+        atomicAdd(fb + ((long long)b.y_low * W + b.x_high) * C, gv * b.w2);
+        atomicAdd(fb + ((long long)b.y_high * W + b.x_low) * C, gv * b.w3);
+        atomicAdd(fb + ((long long)b.y_high * W + b.x_high) * C, gv * b.w4);
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace vlfb
+
+using namespace vlfb;
+
+extern "C" int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* rois, void* out,
+                                      uint8_t* argbin, int32_t* dbg, int64_t n, int64_t h, int64_t w,
+                                      int64_t c, int64_t r, int pooled, float spatial_scale,
+                                      vlfb_stream_t stream) {
+  VLFB_REQUIRE(feat && rois && out && argbin && n > 0 && h > 0 && w > 0 && c > 0 && r > 0, "roi_align_fwd: bad args");
+  VLFB_REQUIRE(pooled > 0 && pooled * pooled <= 255, "roi_align_fwd: pooled resolution out of range");
+  const int v = dtype == VLFB_F32 ? 4 : 8;
+  VLFB_REQUIRE(c % v == 0, "roi_align_fwd: C must be a multiple of %d", v);
+  int threads = (int)((c / v + 63) / 64 * 64);
+  if (threads > 256) threads = 256;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(roi_align_max_fwd_kernel<float>, dim3((unsigned)r), dim3(threads), 0, s, (const float*)feat, rois, (float*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(roi_align_max_fwd_kernel<bf16_t>, dim3((unsigned)r), dim3(threads), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
+  else return set_error(VLFB_ERR_ARG, "roi_align_fwd: bad dtype");
+  return check_launch("roi_align_max_fwd");
+}
+
+extern "C" int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois,
+                                      const uint8_t* argbin, float* dfeat, int64_t n, int64_t h,
+                                      int64_t w, int64_t c, int64_t r, int pooled, float spatial_scale,
+                                      vlfb_stream_t stream) {
+  VLFB_REQUIRE(dout && rois && argbin && dfeat && n > 0 && h > 0 && w > 0 && c > 0 && r > 0, "roi_align_bwd: bad args");
+  int grid = grid_for(r * c, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(roi_align_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(roi_align_max_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale);
+  else return set_error(VLFB_ERR_ARG, "roi_align_bwd: bad dtype");
+  return check_launch("roi_align_max_bwd");
+}

@@ -1,0 +1,181 @@
+"""ctypes binding of libvlfb_hip.so (include/vlfb.h).
+
+This is the whole Python<->native boundary: torch-ROCm tensors supply device memory
+(`data_ptr()`) and the stream (`torch.cuda.current_stream().cuda_stream`); every compute call
+lands in a hand-written HIP kernel.  There is deliberately NO fallback: if the shared library is
+missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+FPROP, DGRAD, WGRAD = 0, 1, 2
+BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlfb_hip.so")
+
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError("vlfb: unsupported dtype %r" % (t,))
+
+
+class VlfbError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("N", C.c_int32), ("Tr", C.c_int32), ("Hr", C.c_int32), ("Wr", C.c_int32),
+        ("Ts", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Cs", C.c_int32),
+        ("kt", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("st", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+        ("pt", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
+        ("dt", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32),
+        ("pack_w", C.c_int32), ("Cn", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
+        ("ldp", C.c_int32),
+        ("batch", C.c_int32),
+        ("a_bstride", C.c_int64), ("b_bstride", C.c_int64), ("o_bstride", C.c_int64),
+        ("r_bstride", C.c_int64), ("p_bstride", C.c_int64),
+        ("alpha", C.c_float), ("relu", C.c_int32), ("bias_mode", C.c_int32),
+        ("accumulate", C.c_int32), ("splits", C.c_int32),
+    ]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "N", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
+        "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_SIGS = {
+    "vlfb_last_error": (C.c_char_p, []),
+    "vlfb_version": (C.c_int, []),
+    "vlfb_dtype_size": (C.c_int, [C.c_int]),
+    "vlfb_affine_nd_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "vlfb_affine_nd_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "vlfb_conv_desc_init": (None, [C.POINTER(ConvDesc)]),
+    "vlfb_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
+    "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
+    "vlfb_nthwc_to_ncthw": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
+    "vlfb_cast": (C.c_int, [_P, C.c_int, _P, C.c_int, _I64, _P]),
+    "vlfb_transpose2d": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
+    "vlfb_weight_prep": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _P]),
+    "vlfb_maxpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
+    "vlfb_maxpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P, _P]),
+    "vlfb_avgpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "vlfb_avgpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P]),
+    "vlfb_softmax_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
+    "vlfb_softmax_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
+    "vlfb_add": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, C.c_int, _P]),
+    "vlfb_relu_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _P]),
+    "vlfb_relu_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _P]),
+    "vlfb_colsum": (C.c_int, [_P, C.c_int, _I64, _I64, _I64, _P, C.c_int, _P]),
+    "vlfb_layernorm_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
+    "vlfb_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _P]),
+    "vlfb_dropout_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, _I64, C.c_float, C.c_uint64, _P]),
+    "vlfb_dropout_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, C.c_float, _P]),
+    "vlfb_fc_fwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "vlfb_fc_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, _P]),
+    "vlfb_sigmoid_ce": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, _P]),
+    "vlfb_roi_align_max_fwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
+                                         C.c_int, C.c_float, _P]),
+    "vlfb_roi_align_max_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
+                                         C.c_int, C.c_float, _P]),
+    "vlfb_fbo_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
+    "vlfb_fbo_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64,
+                                    C.c_float, _P]),
+    "vlfb_sgd_update": (C.c_int, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+    "vlfb_scale_inplace": (C.c_int, [_P, _I64, C.c_float, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+
+_lib = None
+
+
+def lib():
+    """Load libvlfb_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VlfbError(
+                "libvlfb_hip.so is missing at %s -- run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or make -C video-long-term-feature-banks_amd/csrc). There is no "
+                "CPU/PyTorch fallback for the hot path." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise VlfbError("%s failed (%d): %s" % (what, rc, lib().vlfb_last_error().decode()))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call a status-returning entry point, appending the current HIP stream."""
+    fn = getattr(lib(), name)
+    _check(fn(*args, stream()), name)
+
+
+def conv_desc(**kw):
+    d = ConvDesc()
+    lib().vlfb_conv_desc_init(C.byref(d))
+    for k, v in kw.items():
+        if not hasattr(d, k):
+            raise AttributeError("ConvDesc has no field %s" % k)
+        setattr(d, k, v)
+    return d
+
+
+def conv_workspace_bytes(d):
+    n = lib().vlfb_conv_workspace_bytes(C.byref(d))
+    if n < 0:
+        raise VlfbError("conv_workspace_bytes: %s" % lib().vlfb_last_error().decode())
+    return n
+
+
+def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None):
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    rc = lib().vlfb_conv_run(C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale),
+                             ptr(R), ptr(mask), ptr(workspace), ws_bytes, stream())
+    _check(rc, "vlfb_conv_run")
+
+
+def pool_desc(dtype, N, Ti, Hi, Wi, Cc, To, Ho, Wo, k, s, p):
+    d = PoolDesc()
+    d.dtype, d.N, d.Ti, d.Hi, d.Wi, d.C, d.To, d.Ho, d.Wo = dtype, N, Ti, Hi, Wi, Cc, To, Ho, Wo
+    d.kt, d.kh, d.kw = k
+    d.st, d.sh, d.sw = s
+    d.pt, d.ph, d.pw = p
+    return d
