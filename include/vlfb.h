@@ -144,6 +144,10 @@ int vlfb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t 
 /* batched 2-D transpose of dtype elements: dst[b][j][i] = src[b][i][j], src is rows x cols */
 int vlfb_transpose2d(const void* src, void* dst, int dtype, int64_t batch, int64_t rows,
                      int64_t cols, vlfb_stream_t stream);
+/* strided 2-D copy of dtype elements (Concat axis=1 and its gradient, head_helper.py:55,82) */
+int vlfb_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int64_t rows,
+                int64_t cols, vlfb_stream_t stream);
+int vlfb_zero_f32(float* p, int64_t n, vlfb_stream_t stream);
 /* Weight preparation: fp32 master W[Cout][taps][Cin] (kernel K-order) and the frozen affine
  * scale s[Cout] (may be NULL = 1) -> operand copies in `dtype`:
  *   w_fprop[Cout][taps][Cin] = W*s          (B operand of FPROP)

@@ -435,6 +435,18 @@ __global__ void colsum_kernel(const T* __restrict__ g, long long rows, int cols,
   if (rl == 0 && c < cols) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
+// strided 2-D copy (Concat along channels and its backward): dst[r*ldd + c] = src[r*lds + c]
+template <typename T>
+__global__ void copy2d_kernel(const T* __restrict__ src, long long lds, T* __restrict__ dst,
+                              long long ldd, long long rows, long long cols) {
+  const long long total = rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols, c = i - r * cols;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+
 __global__ void zero_kernel(float* p, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
@@ -699,4 +711,22 @@ extern "C" int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols,
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, (long long)rows, (int)cols, (long long)ld, out);
   else return set_error(VLFB_ERR_ARG, "colsum: bad dtype");
   return check_launch("colsum");
+}
+
+extern "C" int vlfb_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype,
+                           int64_t rows, int64_t cols, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "copy2d: bad args");
+  int grid = grid_for(rows * cols, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(copy2d_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, (long long)lds, (float*)dst, (long long)ldd, (long long)rows, (long long)cols);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long long)lds, (bf16_t*)dst, (long long)ldd, (long long)rows, (long long)cols);
+  else return set_error(VLFB_ERR_ARG, "copy2d: bad dtype");
+  return check_launch("copy2d");
+}
+extern "C" int vlfb_zero_f32(float* p, int64_t n, vlfb_stream_t stream) {
+  VLFB_REQUIRE(p && n >= 0, "zero_f32: bad args");
+  if (n == 0) return VLFB_OK;
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, (long long)n);
+  return check_launch("zero_f32");
 }

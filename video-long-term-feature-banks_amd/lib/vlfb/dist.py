@@ -1,0 +1,41 @@
+"""Process-group helpers: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  Replaces the reference's single-process
+data_parallel_model.Parallelize_GPU(use_nccl=...) (lib/models/model_builder_video.py:142-157)."""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def initialized():
+    return td.is_available() and td.is_initialized()
+
+
+def world_size():
+    return td.get_world_size() if initialized() else 1
+
+
+def rank():
+    return td.get_rank() if initialized() else 0
+
+
+def local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+    if initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank())
+    td.init_process_group(backend=backend)
+
+
+def barrier():
+    if initialized():
+        td.barrier()

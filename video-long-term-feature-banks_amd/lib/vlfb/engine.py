@@ -1,0 +1,1357 @@
+"""Execution engine: lowers the op list recorded by `ModelBuilder` into fused HIP kernel steps
+and runs forward / backward / gradient all-reduce / solver on one MI355X per process.
+
+Design (MI355X-first):
+  * activations are channels-last matrices [positions][C] in bf16 (throughput) or fp32 (parity);
+    every Reshape / Transpose / Squeeze of the reference graph that only regroups positions is a
+    zero-cost view here (the grouped non-local block's transpose-reshape-transpose included);
+  * Conv -> AffineNd -> ReLU -> Sum -> ReLU chains become ONE implicit-GEMM launch: the frozen
+    affine scale is folded into the MFMA weight operand, the affine bias, the residual add and the
+    ReLU into its epilogue;  the backward applies ReLU masks and gradient accumulation in the
+    epilogue of whichever kernel contributes LAST to a tensor's gradient (decided at plan time);
+  * parameters live in flat fp32 buckets ordered by backward completion, so gradient all-reduce
+    (RCCL) can start per bucket on a side stream while backward continues, and the solver is one
+    kernel per bucket;
+  * shapes are static: every buffer is allocated once at plan time, nothing is allocated in the
+    step loop.
+There is no PyTorch/CPU fallback anywhere below: torch supplies memory, streams and the process
+group only.
+"""
+import ctypes as C
+import logging
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from core.config import config as cfg
+from vlfb import hip
+from vlfb import dist
+from vlfb.net import ssa_form
+from vlfb.rng import dropout_seed
+
+logger = logging.getLogger(__name__)
+
+
+def _prod(xs):
+    out = 1
+    for x in xs:
+        out *= int(x)
+    return out
+
+
+# ================================================================================================
+# values
+# ================================================================================================
+class Blob(object):
+    """One SSA value.  Storage order = logical dims with the channel axis `caxis` moved last."""
+
+    def __init__(self, name, shape, caxis, kind="act", root=None):
+        self.name = name
+        self.shape = tuple(int(s) for s in shape)
+        self.caxis = caxis
+        self.kind = kind              # 'act' (engine dtype) | 'f32' | 'i32'
+        self.root = root or self
+        self.tensor = None            # flat storage (root only)
+        self.relu = False             # values are post-ReLU: the finished gradient gets masked
+        self.needs_grad = False
+        self.detached = False
+        self.slot = None              # GradSlot (root only)
+        self.producer = None
+
+    @property
+    def numel(self):
+        return _prod(self.shape)
+
+    @property
+    def C(self):
+        return self.shape[self.caxis]
+
+    @property
+    def rows(self):
+        return self.numel // self.C
+
+    def storage(self):
+        return self.root.tensor
+
+    def ptr(self):
+        return self.root.tensor.data_ptr()
+
+    def view(self, name, shape, caxis):
+        v = Blob(name, shape, caxis, self.kind, self.root)
+        v.needs_grad = self.needs_grad
+        v.detached = self.detached
+        return v
+
+
+class GradSlot(object):
+    """Accumulates the gradient of one root blob.  Contributions arrive in backward order; the
+    last one also applies the ReLU mask of the blob (its forward values) when the blob is
+    post-ReLU, so no separate masking pass ever runs."""
+
+    def __init__(self, engine, blob):
+        self.engine = engine
+        self.blob = blob
+        self.expected = 0
+        self.buf = None
+        self.count = 0
+        self.cur = None
+
+    def reset(self):
+        self.count = 0
+        self.cur = None
+
+    def _flags(self):
+        self.count += 1
+        if self.count > self.expected:
+            raise RuntimeError("too many gradient contributions for %s" % self.blob.name)
+        last = self.count == self.expected
+        mask = self.blob.tensor if (last and self.blob.relu) else None
+        return self.cur, mask
+
+    def contribute(self, fn, supports_add=True, supports_mask=True):
+        """fn(out, add, mask) launches a kernel writing out = value (+ add), masked by mask > 0."""
+        add, mask = self._flags()
+        if (add is None or supports_add) and (mask is None or supports_mask):
+            fn(self.buf, add, mask)
+        else:
+            tmp = self.engine.scratch_act(self.buf.numel(), self.buf.dtype)
+            fn(tmp, None, None)
+            hip.call("vlfb_add", hip.ptr(tmp), hip.ptr(add), hip.ptr(self.buf), hip.ptr(mask),
+                     hip.dtype_code(self.buf.dtype), self.buf.numel(), 0)
+        self.cur = self.buf
+
+    def contribute_alias(self, t):
+        """the contribution is an existing tensor (identity branch of a Sum / ReLU)"""
+        add, mask = self._flags()
+        if add is None and mask is None:
+            self.cur = t
+            return
+        hip.call("vlfb_add", hip.ptr(t), hip.ptr(add), hip.ptr(self.buf), hip.ptr(mask),
+                 hip.dtype_code(self.buf.dtype), self.buf.numel(), 0)
+        self.cur = self.buf
+
+    def value(self):
+        if self.count != self.expected:
+            raise RuntimeError("gradient of %s read after %d of %d contributions"
+                               % (self.blob.name, self.count, self.expected))
+        return self.cur
+
+
+# ================================================================================================
+# steps
+# ================================================================================================
+class Step(object):
+    def __init__(self, eng):
+        self.eng = eng
+        self.inputs = []     # blobs whose gradient this step may produce
+        self.outputs = []
+        self.params = []     # trainable parameter names whose gradient this step produces
+
+    def fwd(self):
+        raise NotImplementedError
+
+    def bwd(self):
+        raise NotImplementedError
+
+    def grad_inputs(self):
+        """inputs that receive a gradient contribution from this step"""
+        return [b for b in self.inputs if b.needs_grad and not b.detached]
+
+    def out_grad(self, i=0):
+        return self.outputs[i].root.slot.value()
+
+
+class ConvStep(Step):
+    """ConvNd [+ AffineNd] [+ residual Sum] [+ ReLU] as one implicit-GEMM launch."""
+
+    def __init__(self, eng, x, out, wname, cbname, kernels, strides, pads, dils):
+        Step.__init__(self, eng)
+        self.x, self.out = x, out
+        self.inputs, self.outputs = [x], [out]
+        self.wname, self.cbname = wname, cbname
+        self.sname = self.bname = None
+        self.relu = False
+        self.residual = None
+        self.k, self.s, self.p, self.d = kernels, strides, pads, dils
+        self.stem = (x.C == 3)
+        self.eff_bias = None
+
+    def name(self):
+        return "conv:" + self.out.name
+
+    # -- geometry ------------------------------------------------------------------------------
+    def _geom(self):
+        k, s, p, d = self.k, self.s, self.p, self.d
+        return dict(kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
+                    dt=d[0], dh=d[1], dw=d[2])
+
+    def setup(self):
+        eng = self.eng
+        N, Cin, T, H, W = self.x.shape
+        _, Cout, To, Ho, Wo = self.out.shape
+        self.Cin_k = 4 if self.stem else Cin          # channels as the kernel sees them
+        self.pack = 8 if self.stem else 0
+        code = eng.code
+        common = dict(dtype=code, **self._geom())
+        self.d_f = hip.conv_desc(mode=hip.FPROP, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
+                                 Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, relu=int(self.relu),
+                                 bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, **common)
+        self.d_d = None
+        if self.x.needs_grad and not self.x.detached:
+            assert not self.stem
+            self.d_d = hip.conv_desc(mode=hip.DGRAD, out_dtype=code, N=N, Tr=T, Hr=H, Wr=W, Ts=To,
+                                     Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, **common)
+        self.d_w = None
+        if eng.is_trainable(self.wname):
+            self.d_w = hip.conv_desc(mode=hip.WGRAD, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
+                                     Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, **common)
+            eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
+        # operand copies
+        wshape = eng.kernel_shape(self.wname)
+        self.w_f = torch.empty(wshape, device=eng.device, dtype=eng.tdtype)
+        self.w_d = None
+        if self.d_d is not None:
+            self.w_d = torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype)
+        if self.cbname and self.sname:
+            self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
+        self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
+        if self.cbname and eng.is_trainable(self.cbname):
+            self.cb_tmp = torch.empty(Cout, device=eng.device, dtype=torch.float32)
+
+    def has_bias(self):
+        return bool(self.cbname or self.bname)
+
+    def taps(self):
+        return self.k[0] * self.k[1] * (8 if self.stem else self.k[2])
+
+    def refresh(self):
+        """rebuild the MFMA operand copies from the fp32 masters (after a solver step / feed)"""
+        eng = self.eng
+        Cout = self.out.shape[1]
+        w = eng.param_tensor(self.wname)
+        s = eng.param_tensor(self.sname) if self.sname else None
+        hip.call("vlfb_weight_prep", hip.ptr(w), hip.ptr(s), hip.ptr(self.w_f), hip.ptr(self.w_d),
+                 eng.code, Cout, self.taps(), self.Cin_k)
+        if self.eff_bias is not None:   # s*cb + b
+            hip.call("vlfb_affine_nd_fwd", hip.ptr(eng.param_tensor(self.cbname)), hip.ptr(s),
+                     hip.ptr(eng.param_tensor(self.bname)), hip.ptr(self.eff_bias), 1, Cout, 1)
+
+    def bias_tensor(self):
+        if self.eff_bias is not None:
+            return self.eff_bias
+        if self.cbname:
+            return self.eng.param_tensor(self.cbname)
+        if self.bname:
+            return self.eng.param_tensor(self.bname)
+        return None
+
+    def fwd(self):
+        R = self.residual.storage() if self.residual is not None else None
+        hip.conv_run(self.d_f, self.x.storage(), self.w_f, None, self.out.storage(),
+                     bias=self.bias_tensor(), R=R)
+
+    def bwd(self):
+        eng = self.eng
+        g = self.out_grad()
+        if self.residual is not None and self.residual.needs_grad and not self.residual.detached:
+            self.residual.root.slot.contribute_alias(g)
+        if self.d_w is not None:
+            s = eng.param_tensor(self.sname) if self.sname else None
+            hip.conv_run(self.d_w, self.x.storage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
+                         workspace=eng.workspace)
+            if self.stem:   # keep the zero padding of the packed stem weight exactly zero
+                gw = eng.grad_tensor(self.wname)
+                hip.call("vlfb_add", hip.ptr(gw), None, hip.ptr(gw), hip.ptr(eng.stem_mask), hip.F32,
+                         gw.numel(), 0)
+        if self.cbname and eng.is_trainable(self.cbname):
+            Cout = self.out.shape[1]
+            gb = eng.grad_tensor(self.cbname)
+            if self.sname:
+                hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
+                hip.call("vlfb_affine_nd_bwd", hip.ptr(self.cb_tmp), hip.ptr(eng.param_tensor(self.sname)),
+                         hip.ptr(gb), 1, Cout, 1)
+            else:
+                hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
+        if self.d_d is not None:
+            self.x.root.slot.contribute(
+                lambda out, add, mask: hip.conv_run(self.d_d, g, self.w_d, None, out, R=add, mask=mask))
+
+
+class PoolStep(Step):
+    def __init__(self, eng, x, out, kernels, strides, pads, is_max):
+        Step.__init__(self, eng)
+        self.x, self.out = x, out
+        self.inputs, self.outputs = [x], [out]
+        self.k, self.s, self.p, self.is_max = kernels, strides, pads, is_max
+
+    def name(self):
+        return ("maxpool:" if self.is_max else "avgpool:") + self.out.name
+
+    def setup(self):
+        eng = self.eng
+        N, Cc, T, H, W = self.x.shape
+        _, _, To, Ho, Wo = self.out.shape
+        self.desc = hip.pool_desc(eng.code, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
+        self.argmax = None
+        if self.is_max and eng.train:
+            self.argmax = torch.empty(self.out.numel, device=eng.device, dtype=torch.uint8)
+
+    def fwd(self):
+        if self.is_max:
+            hip.call("vlfb_maxpool_fwd", C.byref(self.desc), self.x.ptr(), self.out.ptr(), hip.ptr(self.argmax))
+        else:
+            hip.call("vlfb_avgpool_fwd", C.byref(self.desc), self.x.ptr(), self.out.ptr())
+
+    def bwd(self):
+        if not self.grad_inputs():
+            return
+        g = self.out_grad()
+        if self.is_max:
+            fn = lambda out, add, mask: hip.call("vlfb_maxpool_bwd", C.byref(self.desc), hip.ptr(g),
+                                                 hip.ptr(self.argmax), hip.ptr(out), hip.ptr(add), hip.ptr(mask))
+        else:
+            fn = lambda out, add, mask: hip.call("vlfb_avgpool_bwd", C.byref(self.desc), hip.ptr(g),
+                                                 hip.ptr(out), hip.ptr(add), hip.ptr(mask))
+        self.x.root.slot.contribute(fn)
+
+
+class AttentionStep(Step):
+    """BatchMatMul(trans_a) -> Scale -> Softmax(axis=2) -> BatchMatMul(trans_b)
+    (nonlocal_helper.py:94-121, lfb_helper.py:223-234) with theta/phi/g stored [B][L][Ci]."""
+
+    def __init__(self, eng, theta, phi, g, prob, out, scale):
+        Step.__init__(self, eng)
+        self.theta, self.phi, self.g, self.prob, self.out, self.scale = theta, phi, g, prob, out, scale
+        self.inputs, self.outputs = [theta, phi, g], [out]
+
+    def name(self):
+        return "attention:" + self.out.name
+
+    def setup(self):
+        eng = self.eng
+        B, Ci, L1 = self.theta.shape
+        L2 = self.phi.shape[2]
+        self.B, self.Ci, self.L1, self.L2 = B, Ci, L1, L2
+        code = eng.code
+        self.single = (L1 == 1)
+        if self.single:
+            return
+        gemm = lambda **kw: hip.conv_desc(mode=hip.FPROP, dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
+                                          Ws=L1, batch=B, **kw)
+        self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2)
+        self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci)
+        self.d_dp = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2)
+        self.d_dth = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci)
+        # contract over L1: out[L2][Ci] = sum_l P[l][L2] * A[l][Ci]
+        self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
+                                  Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
+                                  o_bstride=L2 * Ci, splits=1)
+        eng.need_scratch_f32(B * L1 * L2)
+        eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
+
+    def fwd(self):
+        eng = self.eng
+        B, Ci, L1, L2 = self.B, self.Ci, self.L1, self.L2
+        if self.single:
+            hip.call("vlfb_fbo_attn_fwd", self.theta.ptr(), self.phi.ptr(), self.g.ptr(), self.prob.ptr(),
+                     self.out.ptr(), eng.code, B, L2, Ci, Ci, self.scale)
+            return
+        S = eng.scratch_f32(B * L1 * L2)
+        hip.conv_run(self.d_s, self.theta.storage(), self.phi.storage(), None, S)
+        hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
+        gT = eng.scratch_act(B * Ci * L2)
+        hip.call("vlfb_transpose2d", self.g.ptr(), hip.ptr(gT), eng.code, B, L2, Ci)
+        hip.conv_run(self.d_y, self.prob.storage(), gT, None, self.out.storage())
+
+    def bwd(self):
+        eng = self.eng
+        B, Ci, L1, L2 = self.B, self.Ci, self.L1, self.L2
+        dY = self.out_grad()
+        th, ph, gg = self.theta.root.slot, self.phi.root.slot, self.g.root.slot
+        if self.single:
+            # single consumer each: the three gradients are written in one launch
+            for s in (th, ph, gg):
+                s._flags()
+                s.cur = s.buf
+            hip.call("vlfb_fbo_attn_bwd", hip.ptr(dY), self.theta.ptr(), self.phi.ptr(), self.g.ptr(),
+                     self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), eng.code, B, L2, Ci,
+                     Ci, self.scale)
+            return
+        dP = eng.scratch_f32(B * L1 * L2)
+        hip.conv_run(self.d_dp, dY, self.g.storage(), None, dP)
+        P = self.prob.storage()
+        gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
+                      supports_add=False, supports_mask=False)
+        act = eng.scratch_act(B * L1 * L2 + B * Ci * L2)
+        dS = act[:B * L1 * L2]
+        phT = act[B * L1 * L2:]
+        hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2, self.scale)
+        hip.call("vlfb_transpose2d", self.phi.ptr(), hip.ptr(phT), eng.code, B, L2, Ci)
+        th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
+                      supports_add=False, supports_mask=False)
+        ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, self.theta.storage(), None, dS, out),
+                      supports_add=False, supports_mask=False)
+
+
+class AddStep(Step):
+    """Sum([a, b]) [+ ReLU] that could not be folded into a conv epilogue"""
+
+    def __init__(self, eng, a, b, out, relu):
+        Step.__init__(self, eng)
+        self.a, self.b, self.out, self.relu = a, b, out, relu
+        self.inputs, self.outputs = [a, b], [out]
+
+    def name(self):
+        return "add:" + self.out.name
+
+    def setup(self):
+        pass
+
+    def fwd(self):
+        hip.call("vlfb_add", self.a.ptr(), self.b.ptr(), self.out.ptr(), None, self.eng.code,
+                 self.out.numel, int(self.relu))
+
+    def bwd(self):
+        g = self.out_grad()
+        for x in self.grad_inputs():
+            x.root.slot.contribute_alias(g)
+
+
+class ReluStep(Step):
+    def __init__(self, eng, x, out):
+        Step.__init__(self, eng)
+        self.x, self.out = x, out
+        self.inputs, self.outputs = [x], [out]
+
+    def name(self):
+        return "relu:" + self.out.name
+
+    def setup(self):
+        pass
+
+    def fwd(self):
+        hip.call("vlfb_relu_fwd", self.x.ptr(), self.out.ptr(), self.eng.code, self.out.numel)
+
+    def bwd(self):
+        if self.grad_inputs():
+            self.x.root.slot.contribute_alias(self.out_grad())   # already masked by out > 0
+
+
+class LayerNormStep(Step):
+    def __init__(self, eng, x, out, eps):
+        Step.__init__(self, eng)
+        self.x, self.out, self.eps = x, out, eps
+        self.inputs, self.outputs = [x], [out]
+
+    def name(self):
+        return "layernorm:" + self.out.name
+
+    def setup(self):
+        self.rows = self.x.shape[0]
+        self.cols = self.x.numel // self.rows
+        self.rstd = torch.empty(self.rows, device=self.eng.device, dtype=torch.float32)
+
+    def fwd(self):
+        hip.call("vlfb_layernorm_fwd", self.x.ptr(), self.out.ptr(), hip.ptr(self.rstd), self.eng.code,
+                 self.rows, self.cols, self.eps)
+
+    def bwd(self):
+        if not self.grad_inputs():
+            return
+        g = self.out_grad()
+        self.x.root.slot.contribute(
+            lambda out, add, mask: hip.call("vlfb_layernorm_bwd", hip.ptr(g), self.out.ptr(), hip.ptr(self.rstd),
+                                            hip.ptr(out), self.eng.code, self.rows, self.cols),
+            supports_add=False, supports_mask=False)
+
+
+class DropoutStep(Step):
+    def __init__(self, eng, x, out, ratio):
+        Step.__init__(self, eng)
+        self.x, self.out, self.ratio = x, out, ratio
+        self.inputs, self.outputs = [x], [out]
+
+    def name(self):
+        return "dropout:" + self.out.name
+
+    def setup(self):
+        self.mask = torch.empty(self.out.numel, device=self.eng.device, dtype=torch.uint8)
+        shp = self.x.shape
+        self.rows, self.ch = shp[0], shp[self.x.caxis]
+        self.inner = self.x.numel // (self.rows * self.ch)
+
+    def fwd(self):
+        seed = dropout_seed(self.eng.base_seed, self.out.name, self.eng.iteration)
+        hip.call("vlfb_dropout_fwd", self.x.ptr(), self.out.ptr(), hip.ptr(self.mask), self.eng.code, self.rows,
+                 self.inner, self.ch, self.ratio, seed)
+
+    def bwd(self):
+        if not self.grad_inputs():
+            return
+        g = self.out_grad()
+        self.x.root.slot.contribute(
+            lambda out, add, mask: hip.call("vlfb_dropout_bwd", hip.ptr(g), hip.ptr(self.mask), hip.ptr(out),
+                                            self.eng.code, self.out.numel, self.ratio),
+            supports_add=False, supports_mask=False)
+
+
+class RoiAlignMaxStep(Step):
+    """RoIAlign + resolution x resolution MaxPool (head_helper.py:101-116)"""
+
+    def __init__(self, eng, feat, rois, out, pooled, spatial_scale):
+        Step.__init__(self, eng)
+        self.feat, self.rois, self.out = feat, rois, out
+        self.pooled, self.spatial_scale = pooled, spatial_scale
+        self.inputs, self.outputs = [feat], [out]
+
+    def name(self):
+        return "roialign:" + self.out.name
+
+    def setup(self):
+        eng = self.eng
+        self.N, self.Cc, self.H, self.W = self.feat.shape
+        self.R = self.rois.shape[0]
+        self.argbin = torch.empty(self.R * self.Cc, device=eng.device, dtype=torch.uint8)
+        self.dbg = torch.zeros(self.R * self.pooled * self.pooled * 8, device=eng.device, dtype=torch.int32)
+        if eng.train:
+            self.dfeat = torch.empty(self.feat.numel, device=eng.device, dtype=torch.float32)
+
+    def fwd(self):
+        hip.call("vlfb_roi_align_max_fwd", self.feat.ptr(), self.eng.code, self.rois.ptr(), self.out.ptr(),
+                 hip.ptr(self.argbin), hip.ptr(self.dbg), self.N, self.H, self.W, self.Cc, self.R, self.pooled,
+                 self.spatial_scale)
+
+    def bwd(self):
+        if not self.grad_inputs():
+            return
+        eng = self.eng
+        g = self.out_grad()
+        hip.call("vlfb_zero_f32", hip.ptr(self.dfeat), self.dfeat.numel())
+        hip.call("vlfb_roi_align_max_bwd", hip.ptr(g), eng.code, self.rois.ptr(), hip.ptr(self.argbin),
+                 hip.ptr(self.dfeat), self.N, self.H, self.W, self.Cc, self.R, self.pooled, self.spatial_scale)
+        self.feat.root.slot.contribute(
+            lambda out, add, mask: hip.call("vlfb_cast", hip.ptr(self.dfeat), hip.F32, hip.ptr(out), eng.code,
+                                            self.dfeat.numel()),
+            supports_add=False, supports_mask=False)
+
+
+class ConcatStep(Step):
+    """Concat(axis=1) of (R, Ci, 1, 1, 1) blobs"""
+
+    def __init__(self, eng, parts, out):
+        Step.__init__(self, eng)
+        self.parts, self.out = parts, out
+        self.inputs, self.outputs = list(parts), [out]
+
+    def name(self):
+        return "concat:" + self.out.name
+
+    def setup(self):
+        self.rows = self.out.shape[0]
+        self.total = self.out.shape[1]
+
+    def fwd(self):
+        off = 0
+        es = self.eng.esize
+        for p in self.parts:
+            hip.call("vlfb_copy2d", p.ptr(), p.C, self.out.ptr() + off * es, self.total, self.eng.code,
+                     self.rows, p.C)
+            off += p.C
+
+    def bwd(self):
+        g = self.out_grad()
+        es = self.eng.esize
+        off = 0
+        for p in self.parts:
+            if p.needs_grad and not p.detached:
+                o = off
+                p.root.slot.contribute(
+                    lambda out, add, mask, o=o, p=p: hip.call("vlfb_copy2d", hip.ptr(g) + o * es, self.total,
+                                                              hip.ptr(out), p.C, self.eng.code, self.rows, p.C),
+                    supports_add=False, supports_mask=False)
+            off += p.C
+
+
+class FCStep(Step):
+    def __init__(self, eng, x, out, wname, bname):
+        Step.__init__(self, eng)
+        self.x, self.out, self.wname, self.bname = x, out, wname, bname
+        self.inputs, self.outputs = [x], [out]
+
+    def name(self):
+        return "fc:" + self.out.name
+
+    def setup(self):
+        self.rows = self.x.shape[0]
+        self.cin = self.x.numel // self.rows
+        self.cout = self.out.shape[1]
+        self.params = [n for n in (self.wname, self.bname) if self.eng.is_trainable(n)]
+
+    def fwd(self):
+        eng = self.eng
+        hip.call("vlfb_fc_fwd", self.x.ptr(), eng.code, hip.ptr(eng.param_tensor(self.wname)),
+                 hip.ptr(eng.param_tensor(self.bname)), self.out.ptr(), self.rows, self.cin, self.cout)
+
+    def bwd(self):
+        eng = self.eng
+        dl = self.out_grad()
+        w = eng.param_tensor(self.wname)
+        train = eng.is_trainable(self.wname)
+        dw = eng.grad_tensor(self.wname) if train else None
+        db = eng.grad_tensor(self.bname) if train else None
+        if dw is not None:
+            hip.call("vlfb_fc_bwd", self.x.ptr(), eng.code, hip.ptr(w), hip.ptr(dl), None, hip.ptr(dw), hip.ptr(db),
+                     self.rows, self.cin, self.cout, 0)
+        if self.grad_inputs():
+            self.x.root.slot.contribute(
+                lambda out, add, mask: hip.call("vlfb_fc_bwd", self.x.ptr(), eng.code, hip.ptr(w), hip.ptr(dl),
+                                                hip.ptr(out), None, None, self.rows, self.cin, self.cout, 0),
+                supports_add=False, supports_mask=False)
+
+
+class LossStep(Step):
+    """Sigmoid + SigmoidCrossEntropyLoss (resnet_video.py:333-338); test mode: Sigmoid only"""
+
+    def __init__(self, eng, logits, labels, prob, loss, scale):
+        Step.__init__(self, eng)
+        self.logits, self.labels, self.prob, self.loss, self.scale = logits, labels, prob, loss, scale
+        self.inputs = [logits]
+        self.outputs = [b for b in (prob, loss) if b is not None]
+
+    def name(self):
+        return "loss"
+
+    def setup(self):
+        self.rows, self.cols = self.logits.shape[0], self.logits.shape[1]
+        self.dlogits = None
+        if self.loss is not None:
+            self.dlogits = torch.empty(self.rows * self.cols, device=self.eng.device, dtype=torch.float32)
+
+    def fwd(self):
+        hip.call("vlfb_sigmoid_ce", self.logits.ptr(), self.labels.ptr() if self.labels is not None else None,
+                 self.prob.ptr() if self.prob is not None else None,
+                 self.loss.ptr() if self.loss is not None else None, hip.ptr(self.dlogits), self.rows, self.cols,
+                 self.scale)
+
+    def bwd(self):
+        self.logits.root.slot.contribute_alias(self.dlogits)
+
+
+# ================================================================================================
+# lowering
+# ================================================================================================
+class Lowering(object):
+    def __init__(self, eng, model, input_shapes):
+        self.eng, self.model = eng, model
+        self.env = {}
+        self.steps = []
+        self.uses = {}          # id(root blob) -> number of consumers seen so far
+        self.blobs = OrderedDict()
+        self.ssa = ssa_form(model.net.ops)
+        # number of readers of every (name, version)
+        self.readers = {}
+        for op, ins, outs in self.ssa:
+            for b in ins:
+                self.readers[b] = self.readers.get(b, 0) + 1
+        self.input_shapes = input_shapes
+        self.shape_blobs = {}
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def new_blob(self, name, shape, caxis, kind="act"):
+        b = Blob(name, shape, caxis, kind)
+        self.blobs[name + "#%d" % len(self.blobs)] = b
+        return b
+
+    def get(self, name):
+        if name not in self.env:
+            raise KeyError("blob %r is read before it is produced or fed" % name)
+        return self.env[name]
+
+    def add_step(self, step):
+        for o in step.outputs:
+            o.producer = step
+        self.steps.append(step)
+        return step
+
+    def is_param(self, name):
+        return name in self.model.param_init_net.fills and name in self.model.params
+
+    # ---- main loop -----------------------------------------------------------------------------
+    def run(self):
+        eng = self.eng
+        for name, shape in self.input_shapes.items():
+            if name.startswith("data"):
+                b = self.new_blob(name, shape, 1)            # stored NTHWC4
+                b.pad_c = 4
+            elif name.startswith("labels"):
+                b = self.new_blob(name, shape, len(shape) - 1, "i32")
+            elif name.startswith("proposals"):
+                b = self.new_blob(name, shape, 1, "f32")
+            elif name.startswith("lfb"):
+                b = self.new_blob(name, shape, 2)            # (R, K, D) row-major, D contiguous
+            else:
+                raise KeyError("unknown input blob %r" % name)
+            b.is_input = True
+            self.env[name] = b
+        ops = self.ssa
+        i = 0
+        n = len(ops)
+        while i < n:
+            op, ins, outs = ops[i]
+            handler = getattr(self, "lower_" + op.type, None)
+            if handler is None:
+                raise NotImplementedError("operator %s is not on the hot path (%r)" % (op.type, op))
+            i = handler(i)
+        return self.steps
+
+    def sole_reader_is_next(self, i, out_ref, types):
+        """the op after i reads out_ref, is the ONLY reader of it, and has one of `types`"""
+        if i + 1 >= len(self.ssa):
+            return False
+        op2, ins2, _ = self.ssa[i + 1]
+        return op2.type in types and out_ref in ins2 and self.readers.get(out_ref, 0) == 1
+
+    # ---- operators -----------------------------------------------------------------------------
+    def lower_StopGradient(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        v = x.view(op.outputs[0], x.shape, x.caxis)
+        v.detached = True
+        v.needs_grad = False
+        if getattr(x, "is_input", False):
+            v.is_input = True
+            v.pad_c = getattr(x, "pad_c", None)
+            v.root = x.root
+        self.env[op.outputs[0]] = v
+        return i + 1
+
+    def lower_Conv(self, i):
+        op, ins, outs = self.ssa[i]
+        eng = self.eng
+        x = self.get(op.inputs[0])
+        wname = op.inputs[1]
+        cbname = op.inputs[2] if len(op.inputs) > 2 else None
+        a = op.args
+        k, s, d = a["kernels"], a["strides"], a["dilations"]
+        p = a["pads"][:3]
+        assert list(a["pads"][:3]) == list(a["pads"][3:]), "asymmetric padding is not used by the builders"
+        if len(x.shape) != 5 or x.caxis != 1:
+            raise NotImplementedError("Conv input %s must be a 5-d channels-last blob" % x.name)
+        N, Cin, T, H, W = x.shape
+        wshape = self.model.param_init_net.fills[wname].shape
+        Cout = wshape[0]
+        assert wshape[1] == Cin, "conv %s: weight expects %d channels, input has %d" % (wname, wshape[1], Cin)
+        dims = [(n_ + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for n_, kk, ss, pp, dd in zip((T, H, W), k, s, p, d)]
+        out_name = op.outputs[0]
+        step = ConvStep(eng, x, None, wname, cbname, k, s, p, d)
+        j = i
+        cur = outs[0]
+        if self.sole_reader_is_next(j, cur, ("AffineNd",)):
+            op2, ins2, outs2 = self.ssa[j + 1]
+            step.sname, step.bname = op2.inputs[1], op2.inputs[2]
+            out_name, cur, j = op2.outputs[0], outs2[0], j + 1
+        if self.sole_reader_is_next(j, cur, ("Relu",)):
+            op2, ins2, outs2 = self.ssa[j + 1]
+            step.relu = True
+            out_name, cur, j = op2.outputs[0], outs2[0], j + 1
+        out = self.new_blob(out_name, (N, Cout) + tuple(dims), 1)
+        out.relu = step.relu
+        out.needs_grad = True
+        step.out = out
+        step.outputs = [out]
+        self.add_step(step)
+        self.env[out_name] = out
+        return j + 1
+
+    def lower_Sum(self, i):
+        op, ins, outs = self.ssa[i]
+        assert len(op.inputs) == 2, "Sum of two blobs expected"
+        a, b = self.get(op.inputs[0]), self.get(op.inputs[1])
+        out_name = op.outputs[0]
+        j = i
+        relu = False
+        if j + 1 < len(self.ssa):
+            op2, ins2, outs2 = self.ssa[j + 1]
+            if op2.type == "Relu" and outs[0] in ins2 and (self.readers.get(outs[0], 0) == 1 or op2.outputs[0] == op2.inputs[0]):
+                relu = True
+                out_name, j = op2.outputs[0], j + 1
+        # fold into the epilogue of the conv that produced one operand (first operand preferred)
+        for cand, other, ref in ((a, b, ins[0]), (b, a, ins[1])):
+            st = cand.producer
+            if (isinstance(st, ConvStep) and cand is st.out and not st.relu and st.residual is None
+                    and self.readers.get(ref, 0) == 1 and cand.shape == other.shape):
+                self.steps.remove(st)
+                cand.dead = True        # its storage is never allocated: the fused output replaces it
+                st.residual = other
+                st.relu = relu
+                st.inputs = [st.x, other]
+                out = self.new_blob(out_name, cand.shape, 1)
+                out.relu = relu
+                out.needs_grad = True
+                st.out = out
+                st.outputs = [out]
+                self.add_step(st)
+                self.env[out_name] = out
+                return j + 1
+        out = self.new_blob(out_name, a.shape, a.caxis)
+        out.relu = relu
+        out.needs_grad = a.needs_grad or b.needs_grad
+        self.add_step(AddStep(self.eng, a, b, out, relu))
+        self.env[out_name] = out
+        return j + 1
+
+    def lower_Relu(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        out = self.new_blob(op.outputs[0], x.shape, x.caxis)
+        out.relu = True
+        out.needs_grad = x.needs_grad
+        self.add_step(ReluStep(self.eng, x, out))
+        self.env[op.outputs[0]] = out
+        return i + 1
+
+    def _pool(self, i, is_max):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        a = op.args
+        k, s, p = list(a["kernels"]), list(a["strides"]), list(a["pads"])
+        if len(x.shape) != 5 or x.caxis != 1:
+            raise NotImplementedError("pool input %s must be a 5-d channels-last blob" % x.name)
+        p = p[:3]
+        N, Cc, T, H, W = x.shape
+        dims = [(n_ + 2 * pp - kk) // ss + 1 for n_, kk, ss, pp in zip((T, H, W), k, s, p)]
+        out = self.new_blob(op.outputs[0], (N, Cc) + tuple(dims), 1)
+        out.needs_grad = x.needs_grad
+        self.add_step(PoolStep(self.eng, x, out, k, s, p, is_max))
+        self.env[op.outputs[0]] = out
+        return i + 1
+
+    def lower_MaxPool(self, i):
+        return self._pool(i, True)
+
+    def lower_AveragePool(self, i):
+        return self._pool(i, False)
+
+    # -- views -----------------------------------------------------------------------------------
+    def lower_Transpose(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        axes = list(op.args["axes"])
+        keep_old = [ax for ax in range(len(x.shape)) if ax != x.caxis]
+        keep_new = [ax for ax in axes if ax != x.caxis]
+        if keep_old != keep_new:
+            raise NotImplementedError("Transpose %r of %s moves data (not a view in channels-last)" % (axes, x.name))
+        shape = tuple(x.shape[ax] for ax in axes)
+        v = x.view(op.outputs[0], shape, axes.index(x.caxis))
+        self.env[op.outputs[0]] = v
+        return i + 1
+
+    def lower_Reshape(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        if len(op.inputs) == 2:
+            shape = list(self.shape_blobs[op.inputs[1]])
+        else:
+            shape = list(op.args["shape"])
+        if -1 in shape:
+            known = _prod([s for s in shape if s != -1])
+            shape[shape.index(-1)] = x.numel // known
+        assert _prod(shape) == x.numel, "Reshape %s: %r -> %r" % (x.name, x.shape, shape)
+        Cc = x.C
+        cands = [ax for ax, s in enumerate(shape) if s == Cc]
+        if not cands:
+            raise NotImplementedError("Reshape of %s loses the channel axis" % x.name)
+        if x.caxis in cands and len(shape) == len(x.shape):
+            ca = x.caxis
+        elif 1 in cands:
+            ca = 1
+        else:
+            ca = cands[-1]
+        # rows before the channel axis must regroup without crossing it: in channels-last storage
+        # this is always a pure reinterpretation of the position index.
+        v = x.view(op.outputs[0], shape, ca)
+        self.env[op.outputs[0]] = v
+        if len(op.outputs) > 1:
+            self.shape_blobs[op.outputs[1]] = tuple(x.shape)
+        return i + 1
+
+    def lower_Squeeze(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        dims = sorted(op.args["dims"])
+        assert all(x.shape[d_] == 1 for d_ in dims) and x.caxis not in dims
+        shape = [s for ax, s in enumerate(x.shape) if ax not in dims]
+        ca = x.caxis - sum(1 for d_ in dims if d_ < x.caxis)
+        self.env[op.outputs[0]] = x.view(op.outputs[0], shape, ca)
+        return i + 1
+
+    # -- attention -------------------------------------------------------------------------------
+    def lower_BatchMatMul(self, i):
+        op, ins, outs = self.ssa[i]
+        if not op.args.get("trans_a"):
+            raise NotImplementedError("BatchMatMul outside the theta.phi / softmax / g pattern: %r" % op)
+        theta, phi = self.get(op.inputs[0]), self.get(op.inputs[1])
+        j = i + 1
+        scale = 1.0
+        if self.ssa[j][0].type == "Scale":
+            scale = float(self.ssa[j][0].args["scale"])
+            j += 1
+        sm = self.ssa[j][0]
+        assert sm.type == "Softmax" and sm.args.get("axis") == 2, "expected Softmax(axis=2) after the affinity"
+        prob_name = sm.outputs[0]
+        j += 1
+        mm = self.ssa[j][0]
+        assert mm.type == "BatchMatMul" and mm.args.get("trans_b"), "expected BatchMatMul(trans_b=1)"
+        g = self.get(mm.inputs[0])
+        for t in (theta, phi, g):
+            assert len(t.shape) == 3 and t.caxis == 1, "attention operand %s must be (B, C, L)" % t.name
+        B, Ci, L1 = theta.shape
+        L2 = phi.shape[2]
+        single = (L1 == 1)
+        prob = self.new_blob(prob_name, (B, L1, L2), 2, "f32" if single else "act")
+        out = self.new_blob(mm.outputs[0], (B, Ci, L1), 1)
+        out.needs_grad = True
+        self.add_step(AttentionStep(self.eng, theta, phi, g, prob, out, scale))
+        self.env[prob_name] = prob
+        self.env[mm.outputs[0]] = out
+        return j + 1
+
+    # -- head ------------------------------------------------------------------------------------
+    def lower_LayerNorm(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        assert op.args.get("axis", 1) == 1
+        out = self.new_blob(op.outputs[0], x.shape, x.caxis)
+        out.needs_grad = x.needs_grad
+        step = LayerNormStep(self.eng, x, out, float(op.args.get("epsilon", 1e-5)))
+        j = i
+        self.add_step(step)
+        self.env[op.outputs[0]] = out
+        return j + 1
+
+    def lower_Dropout(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        if op.args.get("is_test"):
+            self.env[op.outputs[0]] = x.view(op.outputs[0], x.shape, x.caxis)
+            return i + 1
+        out = self.new_blob(op.outputs[0], x.shape, x.caxis)
+        out.needs_grad = x.needs_grad
+        self.add_step(DropoutStep(self.eng, x, out, float(op.args["ratio"])))
+        self.env[op.outputs[0]] = out
+        return i + 1
+
+    def lower_RoIAlign(self, i):
+        op, ins, outs = self.ssa[i]
+        feat, rois = self.get(op.inputs[0]), self.get(op.inputs[1])
+        a = op.args
+        assert a["pooled_w"] == a["pooled_h"] and a.get("sampling_ratio", 0) == 0
+        res = a["pooled_w"]
+        assert len(feat.shape) == 4 and feat.caxis == 1
+        R = rois.shape[0]
+        nxt = self.ssa[i + 1][0] if i + 1 < len(self.ssa) else None
+        if res > 1:
+            if not (nxt is not None and nxt.type == "MaxPool" and list(nxt.args["kernels"]) == [res, res]
+                    and nxt.inputs[0] == op.outputs[0]):
+                raise NotImplementedError("RoIAlign must be followed by the %dx%d MaxPool of the RoI head" % (res, res))
+            out_name, j = nxt.outputs[0], i + 1
+        else:
+            out_name, j = op.outputs[0], i
+        out = self.new_blob(out_name, (R, feat.shape[1], 1, 1), 1)
+        out.needs_grad = feat.needs_grad
+        self.add_step(RoiAlignMaxStep(self.eng, feat, rois, out, res, float(a["spatial_scale"])))
+        self.env[out_name] = out
+        return j + 1
+
+    def lower_Concat(self, i):
+        op, ins, outs = self.ssa[i]
+        parts = [self.get(n) for n in op.inputs]
+        assert op.args.get("axis", 1) == 1
+        if len(parts) == 1:
+            p = parts[0]
+            self.env[op.outputs[0]] = p.view(op.outputs[0], p.shape, p.caxis)
+            return i + 1
+        for p in parts:
+            assert p.caxis == 1 and p.rows == p.shape[0], "Concat parts must be (R, C, 1, 1, 1)"
+        total = sum(p.C for p in parts)
+        out = self.new_blob(op.outputs[0], (parts[0].shape[0], total) + tuple(parts[0].shape[2:]), 1)
+        out.needs_grad = any(p.needs_grad for p in parts)
+        self.add_step(ConcatStep(self.eng, parts, out))
+        self.env[op.outputs[0]] = out
+        return i + 1
+
+    def lower_FC(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        wname, bname = op.inputs[1], op.inputs[2]
+        cout = self.model.param_init_net.fills[wname].shape[0]
+        out = self.new_blob(op.outputs[0], (x.shape[0], cout), 1, "f32")
+        out.needs_grad = True
+        self.add_step(FCStep(self.eng, x, out, wname, bname))
+        self.env[op.outputs[0]] = out
+        return i + 1
+
+    def lower_Sigmoid(self, i):
+        op, ins, outs = self.ssa[i]
+        logits = self.get(op.inputs[0])
+        prob = self.new_blob(op.outputs[0], logits.shape, 1, "f32")
+        nxt = self.ssa[i + 1][0] if i + 1 < len(self.ssa) else None
+        if nxt is not None and nxt.type == "SigmoidCrossEntropyLoss" and nxt.inputs[0] == op.inputs[0]:
+            labels = self.get(nxt.inputs[1])
+            loss = self.new_blob(nxt.outputs[0], (1,), 0, "f32")
+            self.add_step(LossStep(self.eng, logits, labels, prob, loss, float(nxt.args["scale"])))
+            self.env[nxt.outputs[0]] = loss
+            self.env[op.outputs[0]] = prob
+            return i + 2
+        self.add_step(LossStep(self.eng, logits, None, prob, None, 1.0))
+        self.env[op.outputs[0]] = prob
+        return i + 1
+
+    def lower_SigmoidCrossEntropyLoss(self, i):
+        op, ins, outs = self.ssa[i]
+        logits, labels = self.get(op.inputs[0]), self.get(op.inputs[1])
+        loss = self.new_blob(op.outputs[0], (1,), 0, "f32")
+        self.add_step(LossStep(self.eng, logits, labels, None, loss, float(op.args["scale"])))
+        self.env[op.outputs[0]] = loss
+        return i + 1
+
+
+# ================================================================================================
+# engine
+# ================================================================================================
+class Engine(object):
+    """One per-GPU replica: plan once, then forward()/backward()/allreduce()/sgd_step()."""
+
+    def __init__(self, model, dtype="bf16", device=None, base_seed=None, dry_run=False):
+        hip.lib()   # fail loudly if the native library is missing
+        self.dry_run = bool(dry_run)   # plan on the 'meta' device: shapes/fusion/bytes only, nothing runs
+        if not self.dry_run and not torch.cuda.is_available():
+            raise hip.VlfbError("vlfb.engine needs a GPU: there is no CPU fallback for the hot path")
+        self.model = model
+        self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[dtype]
+        self.code = hip.dtype_code(self.tdtype)
+        self.esize = 2 if self.tdtype == torch.bfloat16 else 4
+        self.device = torch.device("meta") if self.dry_run else torch.device(device or ("cuda:%d" % dist.local_rank()))
+        self.train = bool(model.train and not model.force_fw_only and model.loss_blob is not None)
+        self.base_seed = int(cfg.RNG_SEED if base_seed is None else base_seed)
+        self.iteration = 0
+        self.trainable = [p for p in model.params if p in model.param_to_grad] if self.train else []
+        self._trainable_set = set(self.trainable)
+        self.steps = None
+        self.workspace = None
+        self._ws_bytes = 0
+        self._sf32 = 0
+        self._sact = 0
+        self.lr = float(model.current_lr)
+        self.comm = None
+        model.engine = self
+
+    # ---- bookkeeping used by steps ------------------------------------------------------------
+    def is_trainable(self, name):
+        return name in self._trainable_set
+
+    def need_workspace(self, nbytes):
+        self._ws_bytes = max(self._ws_bytes, int(nbytes))
+
+    def need_scratch_f32(self, n):
+        self._sf32 = max(self._sf32, int(n))
+
+    def need_scratch_act(self, n):
+        self._sact = max(self._sact, int(n))
+
+    def scratch_f32(self, n):
+        assert n <= self._scratch_f32.numel()
+        return self._scratch_f32[:n]
+
+    def scratch_act(self, n, dtype=None):
+        if dtype is not None and dtype != self.tdtype:
+            assert dtype == torch.float32
+            return self.scratch_f32(n)
+        assert n <= self._scratch_act.numel(), "scratch too small: %d > %d" % (n, self._scratch_act.numel())
+        return self._scratch_act[:n]
+
+    def kernel_shape(self, wname):
+        """shape of a conv weight in kernel order [Cout][kt][kh][kw][Cin] (stem: [64][kt][kh][8][4])"""
+        co, ci, kt, kh, kw = self.model.param_init_net.fills[wname].shape
+        if ci == 3:
+            return (co, kt, kh, 8, 4)
+        return (co, kt, kh, kw, ci)
+
+    def param_tensor(self, name):
+        return self.param_views[name]
+
+    def grad_tensor(self, name):
+        return self.grad_views[name]
+
+    # ---- planning -----------------------------------------------------------------------------
+    def plan(self, input_shapes):
+        """input_shapes: {blob name: shape in the REFERENCE layout} for data/labels/proposals/lfb."""
+        if not self.dry_run:
+            torch.cuda.set_device(self.device)
+        low = Lowering(self, self.model, OrderedDict(input_shapes))
+        self.steps = low.run()
+        self.env = low.env
+        self.all_blobs = list(low.blobs.values())
+        self._plan_params()
+        self._analyse_grads()
+        for st in self.steps:
+            st.setup()
+        self._allocate()
+        if not self.dry_run:
+            self.refresh_operands(all_params=True)
+        return self
+
+    def _plan_params(self):
+        """flat fp32 buckets: trainables ordered by backward completion; frozen ones separately"""
+        fills = self.model.param_init_net.fills
+        order = []
+        seen = set()
+        for st in reversed(self.steps):
+            names = []
+            if isinstance(st, ConvStep):
+                names = [st.wname, st.cbname]
+            elif isinstance(st, FCStep):
+                names = [st.wname, st.bname]
+            for n in names:
+                if n and self.is_trainable(n) and n not in seen:
+                    seen.add(n)
+                    order.append(n)
+        missing = [p for p in self.trainable if p not in seen]
+        assert not missing, "trainable params without a producing step: %r" % missing
+        self.train_order = order
+        frozen = [p for p in self.model.params if p not in seen]
+
+        def sizes(names):
+            out, off = OrderedDict(), 0
+            for n in names:
+                shp = fills[n].shape
+                shape = self.kernel_shape(n) if len(shp) == 5 else tuple(shp)
+                cnt = _prod(shape)
+                out[n] = (off, cnt, shape)
+                off += (cnt + 63) // 64 * 64      # keep every view 256-byte aligned
+            return out, off
+        self.train_layout, ntrain = sizes(order)
+        self.frozen_layout, nfrozen = sizes(frozen)
+        dev = self.device
+        self.flat_param = torch.zeros(max(ntrain, 1), device=dev, dtype=torch.float32)
+        self.flat_frozen = torch.zeros(max(nfrozen, 1), device=dev, dtype=torch.float32)
+        self.param_views, self.grad_views = {}, {}
+        for n, (off, cnt, shape) in self.train_layout.items():
+            self.param_views[n] = self.flat_param[off:off + cnt].view(shape)
+        for n, (off, cnt, shape) in self.frozen_layout.items():
+            self.param_views[n] = self.flat_frozen[off:off + cnt].view(shape)
+        if self.train:
+            self.flat_grad = torch.zeros_like(self.flat_param)
+            self.flat_mom = torch.zeros_like(self.flat_param)
+            for n, (off, cnt, shape) in self.train_layout.items():
+                self.grad_views[n] = self.flat_grad[off:off + cnt].view(shape)
+            if "conv1_w" in self.train_layout:
+                shape = self.train_layout["conv1_w"][2]
+                m = torch.zeros(shape, dtype=torch.float32)
+                m[:, :, :, :7, :3] = 1.0
+                self.stem_mask = m.to(dev) if not self.dry_run else m
+
+    def _analyse_grads(self):
+        """needs_grad forward propagation + number of gradient contributions per root blob"""
+        for b in self.all_blobs:
+            b.slot = GradSlot(self, b)
+        if not self.train:
+            return
+        for st in self.steps:
+            names = []
+            if isinstance(st, ConvStep):
+                names = [st.wname, st.cbname]
+            elif isinstance(st, FCStep):
+                names = [st.wname, st.bname]
+            has_trainable = any(n and self.is_trainable(n) for n in names)
+            flows = any(b.needs_grad and not b.detached for b in st.inputs)
+            for o in st.outputs:
+                o.needs_grad = bool(has_trainable or flows) and o.kind != "i32"
+        # views created during lowering copied needs_grad early; refresh them from their roots
+        for name, b in self.env.items():
+            if b.root is not b and not b.detached:
+                b.needs_grad = b.root.needs_grad
+        for st in self.steps:
+            for b in st.inputs:
+                if b.root is not b and not b.detached:
+                    b.needs_grad = b.root.needs_grad
+        # backward reachability from the loss
+        loss = self.env.get(self.model.loss_blob)
+        live = {id(loss.root)}
+        self.bwd_steps = []
+        for st in reversed(self.steps):
+            if not any(id(o.root) in live for o in st.outputs):
+                continue
+            self.bwd_steps.append(st)
+            for b in st.grad_inputs():
+                live.add(id(b.root))
+                b.root.slot.expected += 1
+
+    def _allocate(self):
+        dev = self.device
+        for b in self.all_blobs:
+            if b.root is not b or getattr(b, "dead", False):
+                continue
+            if b.kind == "act":
+                n = b.numel
+                if getattr(b, "pad_c", None):
+                    n = b.numel // b.C * b.pad_c
+                b.tensor = torch.zeros(n, device=dev, dtype=self.tdtype)
+            elif b.kind == "f32":
+                b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.float32)
+            else:
+                b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.int32)
+            if self.train and b.slot.expected > 0:
+                b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=b.tensor.dtype)
+        self.workspace = torch.empty(max(self._ws_bytes // 4, 4), device=dev, dtype=torch.float32)
+        self._scratch_f32 = torch.empty(max(self._sf32, 4), device=dev, dtype=torch.float32)
+        biggest = max([b.tensor.numel() for b in self.all_blobs
+                       if b.root is b and b.kind == "act" and b.tensor is not None] + [4])
+        self._scratch_act = torch.empty(max(self._sact, biggest), device=dev, dtype=self.tdtype)
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def _to_kernel_layout(self, name, arr):
+        t = torch.as_tensor(np.asarray(arr), dtype=torch.float32)
+        if t.dim() == 5:
+            co, ci = t.shape[0], t.shape[1]
+            k = t.permute(0, 2, 3, 4, 1).contiguous()
+            if ci == 3:
+                packed = torch.zeros(self.kernel_shape(name), dtype=torch.float32)
+                packed[:, :, :, :7, :3] = k
+                return packed
+            return k
+        return t
+
+    def _from_kernel_layout(self, name, t):
+        t = t.detach().float().cpu()
+        if t.dim() == 5:
+            ref = self.model.param_init_net.fills[name].shape
+            if ref[1] == 3:
+                t = t[:, :, :, :7, :3]
+            return t.permute(0, 4, 1, 2, 3).contiguous().numpy()
+        return t.numpy()
+
+    def feed_params(self, params):
+        """{name: array in the reference layout (Cout,Cin,kT,kH,kW) / (out,in) / (C,)}"""
+        for name, arr in params.items():
+            if name not in self.param_views:
+                raise KeyError("unknown parameter %r" % name)
+            self.param_views[name].copy_(self._to_kernel_layout(name, arr).to(self.device))
+        self.refresh_operands(all_params=True)
+
+    def init_params(self, seed=None):
+        """run the recorded fillers (MSRAFill / GaussianFill / ConstantFill) deterministically"""
+        gen = np.random.default_rng(self.base_seed if seed is None else seed)
+        out = {}
+        for name in self.model.params:
+            f = self.model.param_init_net.fills[name]
+            shape = f.shape
+            if f.fill == "ConstantFill":
+                v = np.full(shape, f.kwargs.get("value", 0.0), dtype=np.float32)
+            elif f.fill == "GaussianFill":
+                v = gen.standard_normal(shape) * f.kwargs.get("std", 1.0) + f.kwargs.get("mean", 0.0)
+            elif f.fill == "MSRAFill":
+                fan_out = shape[0] * _prod(shape[2:])
+                v = gen.standard_normal(shape) * math.sqrt(2.0 / fan_out)
+            else:
+                raise NotImplementedError("filler %s" % f.fill)
+            out[name] = v.astype(np.float32)
+        self.feed_params(out)
+
+    def fetch_param(self, name):
+        return self._from_kernel_layout(name, self.param_views[name])
+
+    def fetch_grad(self, name):
+        return self._from_kernel_layout(name, self.grad_views[name])
+
+    def fetch_momentum(self, name):
+        off, cnt, shape = self.train_layout[name]
+        return self._from_kernel_layout(name, self.flat_mom[off:off + cnt].view(shape))
+
+    def refresh_operands(self, all_params=False):
+        for st in self.steps:
+            if isinstance(st, ConvStep) and (all_params or st.params):
+                st.refresh()
+
+    # ---- data ---------------------------------------------------------------------------------
+    def feed(self, name, arr):
+        """inputs in the reference layouts (data: (N,3,T,H,W) fp32, labels int32, proposals (R,5),
+        lfb (R,K,D) fp32)"""
+        b = self.env[name] if name in self.env else None
+        if b is None or not getattr(b.root, "is_input", False) and not getattr(b, "is_input", False):
+            raise KeyError("%r is not an input blob of this model" % name)
+        root = b.root
+        t = torch.as_tensor(np.asarray(arr))
+        assert tuple(t.shape) == tuple(root.shape), "feed %s: shape %r, planned %r" % (name, tuple(t.shape), root.shape)
+        if root.kind == "i32":
+            root.tensor.copy_(t.to(torch.int32).reshape(-1).to(self.device))
+        elif root.kind == "f32":
+            root.tensor.copy_(t.to(torch.float32).reshape(-1).to(self.device))
+        elif getattr(root, "pad_c", None):
+            src = t.to(torch.float32).contiguous().to(self.device)
+            N, Cc = root.shape[0], root.shape[1]
+            hip.call("vlfb_ncthw_to_nthwc", hip.ptr(src), root.ptr(), self.code, N, Cc, _prod(root.shape[2:]),
+                     root.pad_c)
+            torch.cuda.current_stream().synchronize()
+        else:   # row-major activation input (lfb)
+            src = t.to(torch.float32).contiguous().reshape(-1).to(self.device)
+            hip.call("vlfb_cast", hip.ptr(src), hip.F32, root.ptr(), self.code, src.numel())
+            torch.cuda.current_stream().synchronize()
+
+    def fetch(self, name):
+        """blob (or its gradient with suffix '_grad') as a float32 numpy array in the reference layout"""
+        grad = False
+        if name not in self.env and name.endswith("_grad"):
+            name, grad = name[:-5], True
+        b = self.env[name]
+        if getattr(b.root, "dead", False):
+            raise KeyError("blob %r was fused away (its value only exists inside a kernel epilogue)" % name)
+        src = b.root.slot.cur if grad else b.root.tensor
+        t = src.detach().float().cpu()
+        if getattr(b.root, "pad_c", None) and not grad:
+            t = t.view(-1, b.root.pad_c)[:, :b.C].reshape(-1)
+        order = [ax for ax in range(len(b.shape)) if ax != b.caxis] + [b.caxis]
+        stor = t[:b.numel].view([b.shape[ax] for ax in order])
+        inv = [order.index(ax) for ax in range(len(b.shape))]
+        return stor.permute(inv).contiguous().numpy()
+
+    # ---- execution ----------------------------------------------------------------------------
+    def forward(self):
+        for st in self.steps:
+            st.fwd()
+
+    def backward(self):
+        assert self.train, "backward() on a forward-only engine"
+        for b in self.all_blobs:
+            if b.root is b and b.slot is not None:
+                b.slot.reset()
+        for i, st in enumerate(self.bwd_steps):
+            st.bwd()
+            if self.comm is not None:
+                self.comm.after_step(i)
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+
+    def scale_momentum(self, factor):
+        hip.call("vlfb_scale_inplace", hip.ptr(self.flat_mom), self.flat_mom.numel(), float(factor))
+
+    def sgd_step(self, lr=None):
+        """WeightedSum + MomentumSGDUpdate over the flat bucket (model_builder_video.py:348-389)"""
+        if lr is not None:
+            self.lr = float(lr)
+        if self.comm is not None:
+            self.comm.wait()
+        sol = cfg.SOLVER
+        # '_bn' parameters would use WEIGHT_DECAY_BN, but affine params are frozen (no gradient)
+        hip.call("vlfb_sgd_update", hip.ptr(self.flat_param), hip.ptr(self.flat_grad), hip.ptr(self.flat_mom),
+                 self.flat_param.numel(), self.lr, float(sol.WEIGHT_DECAY), float(sol.MOMENTUM), int(bool(sol.NESTEROV)))
+        self.refresh_operands()
+        self.iteration += 1
+
+    def train_step(self, lr=None):
+        self.forward()
+        self.backward()
+        self.sgd_step(lr)

@@ -1,0 +1,80 @@
+"""The experiment definitions BASELINE.json names, as override trees over core.config defaults.
+
+The reference's configs/*.yaml load unmodified through core.config.cfg_from_file; these presets
+exist because /root/reference (and its configs/) is not present on the GPU box.  Only keys that
+differ from the defaults are listed; tests/test_config.py checks (where the reference tree is
+mounted) that every preset equals the corresponding YAML on all keys the hot path reads.
+"""
+from core import config as _config
+
+_COMMON = {
+    "NUM_GPUS": 8, "LOG_PERIOD": 10,
+    "MODEL": {"MODEL_NAME": "resnet_video", "BN_INIT_GAMMA": 0.0, "DEPTH": 50, "VIDEO_ARC_CHOICE": 2,
+              "MULTI_LABEL": True, "USE_AFFINE": True},
+    "RESNETS": {"NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "TRANS_FUNC": "bottleneck_transformation_3d"},
+    "TRAIN": {"DATA_TYPE": "train", "BATCH_SIZE": 16, "COMPUTE_PRECISE_BN": False, "CROP_SIZE": 224,
+              "VIDEO_LENGTH": 32, "DROPOUT_RATE": 0.3, "RESET_START_ITER": True},
+    "TEST": {"BATCH_SIZE": 16, "CROP_SIZE": 256, "SCALE": 256, "VIDEO_LENGTH": 32},
+    "SOLVER": {"MOMENTUM": 0.9, "NESTEROV": True, "WEIGHT_DECAY_BN": 0.0, "SCALE_MOMENTUM": True},
+    "NONLOCAL": {"USE_ZERO_INIT_CONV": True, "USE_BN": False, "USE_AFFINE": True,
+                 "CONV3_NONLOCAL": True, "CONV4_NONLOCAL": True, "USE_SCALE": True},
+}
+
+_CHARADES = {
+    "DATASET": "charades", "DATADIR": "data/charades/frames",
+    "MODEL": {"NUM_CLASSES": 157},
+    "TRAIN": {"EVAL_PERIOD": 4000, "JITTER_SCALES": [256, 320], "SAMPLE_RATE": 4, "DATASET_SIZE": 7811},
+    "TEST": {"DATA_TYPE": "val", "SAMPLE_RATE": 4, "DATASET_SIZE": 1814},
+    "SOLVER": {"BASE_LR": 0.02, "WEIGHT_DECAY": 0.0000125},
+    "CHECKPOINT": {"CHECKPOINT_PERIOD": 4000},
+}
+
+_AVA = {
+    "DATASET": "ava", "DATADIR": "data/ava/frames",
+    "MODEL": {"NUM_CLASSES": 80},
+    "TRAIN": {"EVAL_PERIOD": 8000, "JITTER_SCALES": [256, 320], "SAMPLE_RATE": 2, "DATASET_SIZE": 235,
+              "PARAMS_FILE": "pretrained_weights/r50_k400_pretrained.pkl"},
+    "TEST": {"DATA_TYPE": "val", "SAMPLE_RATE": 2, "DATASET_SIZE": 64},
+    "SOLVER": {"BASE_LR": 0.04, "STEP_SIZES": [100000, 20000, 20000], "LRS": [1, 0.1, 0.01, 0.001],
+               "MAX_ITER": 140000, "WEIGHT_DECAY": 0.000001,
+               "WARMUP": {"WARMUP_ON": True, "WARMUP_START_LR": 0.01, "WARMUP_END_ITER": 2000}},
+    "CHECKPOINT": {"CHECKPOINT_PERIOD": 4000, "CONVERT_MODEL": True},
+}
+
+PRESETS = {
+    "charades_r50_baseline": [_COMMON, _CHARADES, {
+        "TRAIN": {"PARAMS_FILE": "pretrained_weights/r50_k400_pretrained.pkl"},
+        "SOLVER": {"STEP_SIZES": [20000, 4000], "LRS": [1, 0.1], "MAX_ITER": 24000},
+        "CHECKPOINT": {"CONVERT_MODEL": True},
+    }],
+    "charades_r50_lfb_nl": [_COMMON, _CHARADES, {
+        "MODEL": {"FREEZE_BACKBONE": True},
+        "TRAIN": {"PARAMS_FILE": ""},
+        "SOLVER": {"STEP_SIZES": [10000, 2000], "LRS": [1, 0.1], "MAX_ITER": 12000},
+        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 20},
+        "FBO_NL": {"PRE_ACT": False},
+    }],
+    "ava_r50_baseline": [_COMMON, _AVA, {}],
+    "ava_r50_lfb_nl": [_COMMON, _AVA, {
+        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 60},
+    }],
+    "ava_r101_lfb_nl_3l": [_COMMON, _AVA, {
+        "MODEL": {"DEPTH": 101, "VIDEO_ARC_CHOICE": 4},
+        "TRAIN": {"PARAMS_FILE": "pretrained_weights/r101_k400_pretrained.pkl"},
+        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 60},
+        "FBO_NL": {"NUM_LAYERS": 3},
+    }],
+}
+
+
+def load_preset(name, overrides=None):
+    """Reset the global cfg, apply preset `name`, then `KEY VAL` style overrides, and infer."""
+    if name not in PRESETS:
+        raise KeyError("unknown preset %r (have: %s)" % (name, ", ".join(sorted(PRESETS))))
+    _config.reset_cfg()
+    for layer in PRESETS[name]:
+        _config.merge_dicts(layer, _config.config)
+    if overrides:
+        _config.cfg_from_list([str(x) for x in overrides])
+    _config.assert_and_infer_cfg()
+    return _config.config

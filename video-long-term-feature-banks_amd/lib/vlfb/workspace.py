@@ -1,0 +1,131 @@
+"""A `caffe2.python.workspace`-shaped facade over vlfb engines.
+
+tools/train_net.py, tools/test_net.py and tools/lfb_loader.py in the reference talk to the model
+through workspace.FeedBlob / FetchBlob / RunNetOnce / CreateNet / RunNet with scoped blob names
+(`gpu_0/data_train`, `gpu_0/pred`, ...).  The same calls work here: nets are ModelBuilder.net
+objects, blobs are device tensors owned by the model's Engine.
+"""
+import numpy as np
+
+_engines = {}      # id(net) -> engine
+_models = {}       # id(net) -> model
+_dtype = {"value": "bf16"}
+
+
+def set_compute_dtype(name):
+    """'bf16' (throughput path) or 'fp32' (parity path) for engines created afterwards"""
+    assert name in ("bf16", "fp32")
+    _dtype["value"] = name
+
+
+def register(model):
+    _models[id(model.net)] = model
+    return model
+
+
+def _unscoped(name):
+    name = str(name)
+    return name[name.rfind("/") + 1:]
+
+
+def _engine_for_blob(name):
+    scope = str(name).split("/")[0] + "/" if "/" in str(name) else None
+    for eng in _engines.values():
+        if scope is None or eng.model.scope == scope:
+            return eng
+    raise KeyError("no engine owns blob %r (CreateNet the model first)" % name)
+
+
+def CreateNet(net, input_shapes=None, dtype=None):
+    """Plan + allocate the engine behind `net` (a ModelBuilder.net).  `input_shapes` maps the
+    unscoped input blob names to their reference-layout shapes; if omitted they must have been
+    fed with FeedBlob before (their shapes are taken from the fed arrays)."""
+    from vlfb.engine import Engine
+    model = _models[id(net)]
+    eng = Engine(model, dtype or _dtype["value"])
+    shapes = dict(input_shapes or {})
+    for k, v in _pending.items():
+        if k in model.input_blob_names and k not in shapes:
+            shapes[k] = v.shape
+    missing = [b for b in model.input_blob_names if b not in shapes]
+    if missing:
+        raise KeyError("CreateNet: shapes of input blobs %r are unknown (FeedBlob them first)" % missing)
+    eng.plan({k: shapes[k] for k in model.input_blob_names})
+    eng.init_params()
+    _engines[id(net)] = eng
+    for k in list(_pending):
+        if k in model.input_blob_names:
+            eng.feed(k, _pending.pop(k))
+    return eng
+
+
+_pending = {}
+
+
+def RunNetOnce(net):
+    """param_init_net equivalent: (re)run the recorded fillers"""
+    eng = _engines.get(id(net))
+    if eng is not None:
+        eng.init_params()
+    return True
+
+
+def RunNet(net, num_iter=1):
+    """one (or more) forward[+backward+update] passes, like workspace.RunNet(model.net)"""
+    eng = _engines[id(net) if not isinstance(net, str) else next(k for k, e in _engines.items() if e.model.net.name == net)]
+    for _ in range(num_iter):
+        eng.forward()
+        if eng.train:
+            eng.backward()
+            if eng.comm is not None:
+                eng.comm.wait()
+            if eng.model.with_update:
+                eng.sgd_step()
+    return True
+
+
+def FeedBlob(name, arr):
+    arr = np.asarray(arr)
+    base = _unscoped(name)
+    for eng in _engines.values():
+        if base in eng.model.input_blob_names:
+            eng.feed(base, arr)
+            return True
+        if base in eng.param_views:
+            eng.feed_params({base: arr})
+            return True
+        if base == "lr":
+            eng.set_lr(float(arr))
+            return True
+    _pending[base] = arr
+    return True
+
+
+def FetchBlob(name):
+    base = _unscoped(name)
+    eng = _engine_for_blob(name)
+    if base in eng.param_views:
+        return eng.fetch_param(base)
+    if base.endswith("_momentum") and base[:-9] in eng.train_layout:
+        return eng.fetch_momentum(base[:-9])
+    if base.endswith("_grad") and base[:-5] in eng.grad_views:
+        return eng.fetch_grad(base[:-5])
+    if base == "lr":
+        return np.float32(eng.lr)
+    out = eng.fetch(base)
+    return out.reshape(()) if base == "loss" else out
+
+
+def HasBlob(name):
+    try:
+        FetchBlob(name)
+        return True
+    except KeyError:
+        return False
+
+
+def ResetWorkspace():
+    _engines.clear()
+    _models.clear()
+    _pending.clear()
+    return True
