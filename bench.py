@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/s of forward + backward (+ gradient all-reduce + solver step) of
+R50-I3D-NL + LFB-NL on synthetic 32 x 224^2 clips (BASELINE.json `metric`), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` is the whole-job clips/s with the inputs already resident in
+HBM (weak scaling: 8 clips per GPU, i.e. global batch 64 at 8 GPUs as the north star asks).
+`roofline` is the live HIP-event measurement of the dominant kernel family (the implicit-GEMM
+NT kernel: conv fprop + dgrad + the batched attention GEMMs): algorithmic FLOPs / summed launch
+time against the dense bf16 MFMA peak.  `cpu_baseline` is the fp32 CPU oracle (a port: the
+reference has no runnable CPU path) timed on this box's host cores on ONE clip.
+"""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+FWD_BWD_GFLOP_PER_CLIP = 1106.1                 # R50-I3D-NL backbone, 3x fwd - conv1 dgrad
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ava_r50_lfb_nl",
+                    help="ava_r50_lfb_nl (metric config) | charades_r50_baseline | charades_r50_lfb_nl | ava_r101_lfb_nl_3l")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--clips-per-gpu", type=int, default=8)
+    ap.add_argument("--rois-per-clip", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--crop", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, frames, crop, rois_per_clip):
+    """the fp32 torch-CPU oracle, 1 clip forward+backward on the host cores (bounded sample)"""
+    import torch
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from oracle import model as om
+    load_preset(workload, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", frames,
+                           "TRAIN.CROP_SIZE", crop])
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    inputs = om.synth_inputs(cfg, 1, "train", seed=2, rois_per_clip=[rois_per_clip] if cfg.DATASET == "ava" else None,
+                             crop=crop, frames=frames)
+    params = om.synth_params(cfg, seed=2)
+    times = []
+    budget = time.time() + 30.0
+    while len(times) < 3 and (not times or time.time() + times[-1] < budget):
+        t0 = time.time()
+        om.run(cfg, params, inputs, "train", torch.float32, True, lambda name: 1)
+        times.append(time.time() - t0)
+    best = sorted(times)[len(times) // 2]
+    return {"value": 1.0 / best, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "fp32 torch-CPU oracle, %d run(s) of 1 clip %dx%dx%d fwd+bwd, median %.2f s"
+                      % (len(times), frames, crop, crop, best)}
+
+
+def main():
+    args = parse()
+    import torch
+    from vlfb import dist
+    dist.init_from_env()
+    world, rank = dist.world_size(), dist.rank()
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
+    device = "cuda:%d" % dist.local_rank()
+    torch.cuda.set_device(device)
+
+    from vlfb import hip, synth
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb.engine import Engine
+    import utils.lr_policy as lr_policy
+
+    clips = args.clips_per_gpu
+    load_preset(args.workload, ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", clips * world,
+                                "TRAIN.VIDEO_LENGTH", args.frames, "TRAIN.CROP_SIZE", args.crop])
+    model = ModelBuilder(train=True, split="train", name="bench")
+    model.build_model(suffix="_train")
+    eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED)
+    batch = synth.inputs(cfg, clips, args.rois_per_clip, seed=cfg.RNG_SEED + rank, crop=args.crop, frames=args.frames)
+    eng.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in model.input_blob_names))
+    eng.feed_params(synth.params(model, seed=cfg.RNG_SEED))
+    for k, v in batch.items():
+        if k in model.input_blob_names:
+            eng.feed(k, v)
+    eng.enable_data_parallel(args.bucket_mb)
+    lr = float(lr_policy.get_lr_at_iter(0))
+
+    for _ in range(args.warmup):
+        eng.train_step(lr)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            hip.PROFILE = []          # HIP-event brackets around every GEMM launch of the last timed step
+        eng.train_step(lr)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
+    if world > 1:
+        import torch.distributed as td
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(eng.fetch("loss").reshape(-1)[0])
+
+    # ---- live roofline of the GEMM kernel families (this rank) -----------------------------------
+    fam = {"nt": [0.0, 0.0, 0], "tn": [0.0, 0.0, 0]}
+    for mode, flops, e0, e1 in prof or []:
+        f = fam["tn" if mode == hip.WGRAD else "nt"]
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    peak = PEAK_TFLOPS[args.dtype]
+
+    def roof(key, kernel):
+        fl, sec, n = fam[key]
+        ach = fl / sec / 1e12 if sec > 0 else 0.0
+        return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n,
+                "avg_launch_us": round(sec / max(n, 1) * 1e6, 2), "gflop_per_step": round(fl / 1e9, 1),
+                "ms_per_step": round(sec * 1e3, 3)}
+
+    clips_total = clips * world * args.steps
+    value = clips_total / elapsed
+    out = collections.OrderedDict([
+        ("metric", "clips/sec fwd+bwd R50-I3D-NL+LFB-NL, 32x224^2 synthetic"),
+        ("value", round(value, 3)), ("unit", "clips/s"), ("n_gpus", world), ("steps", args.steps),
+        ("warmup", args.warmup), ("ms_per_step", round(elapsed / args.steps * 1e3, 3)),
+        ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None), ("dtype", args.dtype),
+        ("data", "synthetic"),
+        ("config", {"workload": "%s fwd+bwd+allreduce+sgd, %d clips/GPU (global batch %d), %d RoIs/clip, %dx%dx%d clips"
+                                % (args.workload, clips, clips * world, args.rois_per_clip, args.frames, args.crop, args.crop),
+                    "parallelism": "dp%d" % world, "final_loss": loss}),
+        ("roofline", roof("nt", "gemm_nt_kernel (implicit-GEMM conv fprop+dgrad, attention NT GEMMs)")),
+        ("roofline_wgrad", roof("tn", "gemm_tn_kernel (implicit-GEMM conv wgrad, attention TN GEMMs)")),
+        ("model_flops_utilisation", round(value * FWD_BWD_GFLOP_PER_CLIP / 1e3 / (world * peak), 4)),
+    ])
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.frames, args.crop, args.rois_per_clip)
+            except Exception as e:  # the baseline is a report, never a gate
+                out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

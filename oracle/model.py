@@ -287,7 +287,8 @@ def _add_nonlocal(cx, x, prefix, dim_inner, group_size=None, pool_stride=None):
         else:
             xg = x
         yg = xg + _spacetime_nonlocal(cx, xg, prefix, dim_inner)
-        y = yg.transpose(1, 2).reshape(N, T, C, H, W).transpose(1, 2) if G > 1 else yg
+        cx.B[prefix + "_sum"] = yg   # the Sum blob lives in the grouped (N*G, C, 4, H, W) shape
+        return yg.transpose(1, 2).reshape(N, T, C, H, W).transpose(1, 2) if G > 1 else yg
     cx.B[prefix + "_sum"] = y
     return y
 

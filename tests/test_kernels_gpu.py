@@ -23,9 +23,27 @@ def setup_module(module):
     h.lib()
 
 
+_KEEP = []
+
+
 def gpu(t, dtype=None):
     t = t.to(dev())
     return t.to(dtype) if dtype is not None else t
+
+
+def gp(t, dtype=None):
+    """device copy of `t` kept alive until the end of the test; returns its device pointer.
+    (`gp(x)` inline would free the temporary before the kernel is even launched.)"""
+    g = gpu(t, dtype)
+    _KEEP.append(g)
+    return g.data_ptr()
+
+
+@pytest.fixture(autouse=True)
+def _release_kept_tensors():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -157,7 +175,7 @@ def test_conv_stem_packed(dtype):
     y_ref = F.conv3d(xd, wd, None, s, p, d)
     # NTHWC with C padded to 4 via the library's own mover
     X4 = torch.empty(N, T, H, W, 4, device=dev(), dtype=dtype)
-    hip.call("vlfb_ncthw_to_nthwc", hip.ptr(gpu(x)), hip.ptr(X4), code, N, 3, T * H * W, 4)
+    hip.call("vlfb_ncthw_to_nthwc", gp(x), hip.ptr(X4), code, N, 3, T * H * W, 4)
     assert torch.equal(X4[..., :3].float().cpu(), to_nthwc(x)) and float(X4[..., 3].abs().max()) == 0.0
     wp = torch.zeros(Cout, 5, 7, 8, 4)
     wp[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
@@ -211,7 +229,7 @@ def test_batched_gemms_of_the_nonlocal_block(dtype):
 
     # library transpose agrees with torch
     gT_dev = torch.empty(B, Ci, L2, device=dev(), dtype=dtype)
-    hip.call("vlfb_transpose2d", hip.ptr(gpu(g, dtype)), hip.ptr(gT_dev), code, B, L2, Ci)
+    hip.call("vlfb_transpose2d", gp(g, dtype), hip.ptr(gT_dev), code, B, L2, Ci)
     assert torch.equal(gT_dev.float().cpu(), gT)
 
     # dphi[b][m][c] = sum_l dS[b][l][m] * theta[b][l][c]   (TN, batched, direct epilogue)
@@ -273,8 +291,8 @@ def test_maxpool_fwd_bwd(name, dtype):
     (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
     add = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
     DX = torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype)
-    hip.call("vlfb_maxpool_bwd", C.byref(d), hip.ptr(gpu(to_nthwc(dy), dtype)), hip.ptr(AM), hip.ptr(DX),
-             hip.ptr(gpu(to_nthwc(add), dtype)), hip.ptr(X))
+    hip.call("vlfb_maxpool_bwd", C.byref(d), gp(to_nthwc(dy), dtype), hip.ptr(AM), hip.ptr(DX),
+             gp(to_nthwc(add), dtype), hip.ptr(X))
     ref = torch.where(x.double() > 0, gx + add.double(), torch.zeros_like(gx))
     assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
 
@@ -298,7 +316,7 @@ def test_avgpool_global_and_temporal(dtype):
         dy = q(torch.randn(N, Cc, To, Ho, Wo, generator=gen), dtype)
         (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
         DX = torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype)
-        hip.call("vlfb_avgpool_bwd", C.byref(d), hip.ptr(gpu(to_nthwc(dy), dtype)), hip.ptr(DX), None, hip.ptr(X))
+        hip.call("vlfb_avgpool_bwd", C.byref(d), gp(to_nthwc(dy), dtype), hip.ptr(DX), None, hip.ptr(X))
         ref = torch.where(x.double() > 0, gx, torch.zeros_like(gx))
         assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
 
@@ -320,7 +338,7 @@ def test_softmax_fwd_bwd(dtype):
     pq = P.float().cpu().double()
     ds_ref = scale * pq * (dp.double() - (dp.double() * pq).sum(1, keepdim=True))
     DS = torch.empty(rows, cols, device=dev(), dtype=dtype)
-    hip.call("vlfb_softmax_bwd", hip.ptr(gpu(dp)), hip.ptr(P), hip.ptr(DS), code, rows, cols, scale)
+    hip.call("vlfb_softmax_bwd", gp(dp), hip.ptr(P), hip.ptr(DS), code, rows, cols, scale)
     assert rel_err(DS.float(), ds_ref) < TOL[dtype]
 
 
@@ -333,13 +351,13 @@ def test_add_relu_colsum(dtype):
     b = q(torch.randn(n, generator=gen), dtype)
     m = q(torch.randn(n, generator=gen), dtype)
     Y = torch.empty(n, device=dev(), dtype=dtype)
-    hip.call("vlfb_add", hip.ptr(gpu(a, dtype)), hip.ptr(gpu(b, dtype)), hip.ptr(Y), hip.ptr(gpu(m, dtype)), code, n, 1)
+    hip.call("vlfb_add", gp(a, dtype), gp(b, dtype), hip.ptr(Y), gp(m, dtype), code, n, 1)
     ref = torch.where(m > 0, torch.relu(a + b), torch.zeros_like(a))
     assert rel_err(Y.float(), q(ref, dtype)) < 1e-6
     rows, cols = 1000, 96
     g = q(torch.randn(rows, cols, generator=gen), dtype)
     out = torch.empty(cols, device=dev(), dtype=torch.float32)
-    hip.call("vlfb_colsum", hip.ptr(gpu(g, dtype)), code, rows, cols, cols, hip.ptr(out), 0)
+    hip.call("vlfb_colsum", gp(g, dtype), code, rows, cols, cols, hip.ptr(out), 0)
     assert rel_err(out, g.double().sum(0)) < 1e-5
 
 
@@ -354,12 +372,12 @@ def test_layernorm_dropout(dtype):
     y_ref = F.layer_norm(xd, (cols,), eps=1e-5)
     Y = torch.empty(rows, cols, device=dev(), dtype=dtype)
     rstd = torch.empty(rows, device=dev(), dtype=torch.float32)
-    hip.call("vlfb_layernorm_fwd", hip.ptr(gpu(x, dtype)), hip.ptr(Y), hip.ptr(rstd), code, rows, cols, 1e-5)
+    hip.call("vlfb_layernorm_fwd", gp(x, dtype), hip.ptr(Y), hip.ptr(rstd), code, rows, cols, 1e-5)
     assert rel_err(Y.float(), y_ref) < TOL[dtype]
     dy = q(torch.randn(rows, cols, generator=gen), dtype)
     (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
     DX = torch.empty(rows, cols, device=dev(), dtype=dtype)
-    hip.call("vlfb_layernorm_bwd", hip.ptr(gpu(dy, dtype)), hip.ptr(Y), hip.ptr(rstd), hip.ptr(DX), code, rows, cols)
+    hip.call("vlfb_layernorm_bwd", gp(dy, dtype), hip.ptr(Y), hip.ptr(rstd), hip.ptr(DX), code, rows, cols)
     assert rel_err(DX.float(), gx) < (1e-4 if dtype == torch.float32 else 2e-2)
 
     # dropout: mask must equal the oracle's generator, defined over the REFERENCE (r, c, k) index
@@ -367,14 +385,14 @@ def test_layernorm_dropout(dtype):
     xs = q(torch.randn(R, K, Cc, generator=gen), dtype)  # stored [(r*K + k)*C + c]
     Yd = torch.empty(R, K, Cc, device=dev(), dtype=dtype)
     Md = torch.empty(R, K, Cc, device=dev(), dtype=torch.uint8)
-    hip.call("vlfb_dropout_fwd", hip.ptr(gpu(xs, dtype)), hip.ptr(Yd), hip.ptr(Md), code, R, K, Cc, ratio, seed)
+    hip.call("vlfb_dropout_fwd", gp(xs, dtype), hip.ptr(Yd), hip.ptr(Md), code, R, K, Cc, ratio, seed)
     keep_ref = orng.dropout_keep_mask(seed, (R, Cc, K), ratio)  # reference layout (R, C, K)
     keep_ref = torch.from_numpy(keep_ref).permute(0, 2, 1)
     assert torch.equal(Md.cpu().bool(), keep_ref)
     ref = torch.where(keep_ref, xs / (1 - ratio), torch.zeros_like(xs))
     assert rel_err(Yd.float(), q(ref, dtype)) < 1e-6 if dtype == torch.float32 else rel_err(Yd.float(), ref) < 4e-3
     DXd = torch.empty(R, K, Cc, device=dev(), dtype=dtype)
-    hip.call("vlfb_dropout_bwd", hip.ptr(gpu(xs, dtype)), hip.ptr(Md), hip.ptr(DXd), code, R * K * Cc, ratio)
+    hip.call("vlfb_dropout_bwd", gp(xs, dtype), hip.ptr(Md), hip.ptr(DXd), code, R * K * Cc, ratio)
     assert rel_err(DXd.float(), ref) < 4e-3
 
 
@@ -399,18 +417,18 @@ def test_fc_and_sigmoid_ce(dtype):
     gx, gw, gb = torch.autograd.grad(loss_ref, (xd, wd, bd))
     X = gpu(x, dtype)
     L = torch.empty(rows, cout, device=dev())
-    hip.call("vlfb_fc_fwd", hip.ptr(X), code, hip.ptr(gpu(w)), hip.ptr(gpu(b)), hip.ptr(L), rows, cin, cout)
+    hip.call("vlfb_fc_fwd", hip.ptr(X), code, gp(w), gp(b), hip.ptr(L), rows, cin, cout)
     assert rel_err(L, logits_ref) < 1e-5
     prob = torch.empty_like(L)
     loss = torch.empty(1, device=dev())
     dl = torch.empty_like(L)
-    hip.call("vlfb_sigmoid_ce", hip.ptr(L), hip.ptr(gpu(labels)), hip.ptr(prob), hip.ptr(loss), hip.ptr(dl), rows, cout, scale)
+    hip.call("vlfb_sigmoid_ce", hip.ptr(L), gp(labels), hip.ptr(prob), hip.ptr(loss), hip.ptr(dl), rows, cout, scale)
     assert rel_err(prob, torch.sigmoid(logits_ref)) < 1e-5
     assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
     DX = torch.empty(rows, cin, device=dev(), dtype=dtype)
     DW = torch.empty(cout, cin, device=dev())
     DB = torch.empty(cout, device=dev())
-    hip.call("vlfb_fc_bwd", hip.ptr(X), code, hip.ptr(gpu(w)), hip.ptr(dl), hip.ptr(DX), hip.ptr(DW), hip.ptr(DB), rows, cin, cout, 0)
+    hip.call("vlfb_fc_bwd", hip.ptr(X), code, gp(w), hip.ptr(dl), hip.ptr(DX), hip.ptr(DW), hip.ptr(DB), rows, cin, cout, 0)
     assert rel_err(DX.float(), gx) < TOL[dtype]
     assert rel_err(DW, gw) < 1e-4 and rel_err(DB, gb) < 1e-4
 
@@ -439,7 +457,7 @@ def test_fbo_attention_core(dtype):
     DTH = torch.empty(R, D, device=dev(), dtype=dtype)
     DPH = torch.empty(R, K, D, device=dev(), dtype=dtype)
     DG = torch.empty(R, K, D, device=dev(), dtype=dtype)
-    hip.call("vlfb_fbo_attn_bwd", hip.ptr(gpu(dt, dtype)), hip.ptr(TH), hip.ptr(PH), hip.ptr(G), hip.ptr(P),
+    hip.call("vlfb_fbo_attn_bwd", gp(dt, dtype), hip.ptr(TH), hip.ptr(PH), hip.ptr(G), hip.ptr(P),
              hip.ptr(DTH), hip.ptr(DPH), hip.ptr(DG), code, R, K, D, D, scale)
     assert rel_err(DTH.float(), gth) < TOL[dtype]
     assert rel_err(DPH.float(), gph) < TOL[dtype]
@@ -464,13 +482,13 @@ def test_sgd_weight_prep_cast():
         code = hip.dtype_code(dtype)
         wf = torch.empty(cout, taps, cin, device=dev(), dtype=dtype)
         wg = torch.empty(cin, taps, cout, device=dev(), dtype=dtype)
-        hip.call("vlfb_weight_prep", hip.ptr(gpu(w)), hip.ptr(gpu(s)), hip.ptr(wf), hip.ptr(wg), code, cout, taps, cin)
+        hip.call("vlfb_weight_prep", gp(w), gp(s), hip.ptr(wf), hip.ptr(wg), code, cout, taps, cin)
         ref = (w * s.view(-1, 1, 1)).to(dtype)
         assert torch.equal(wf.cpu(), ref)
         assert torch.equal(wg.cpu(), ref.permute(2, 1, 0).contiguous())
     x = torch.randn(1000, generator=gen)
     xb = torch.empty(1000, device=dev(), dtype=torch.bfloat16)
-    hip.call("vlfb_cast", hip.ptr(gpu(x)), hip.F32, hip.ptr(xb), hip.BF16, 1000)
+    hip.call("vlfb_cast", gp(x), hip.F32, hip.ptr(xb), hip.BF16, 1000)
     assert torch.equal(xb.cpu(), x.to(torch.bfloat16))  # round-to-nearest-even, same as torch
 
 
@@ -492,7 +510,7 @@ def test_roi_align_max_head(dtype):
     O = torch.empty(R, Cc, device=dev(), dtype=dtype)
     AB = torch.empty(R, Cc, device=dev(), dtype=torch.uint8)
     DBG = torch.empty(R, 7, 7, 8, device=dev(), dtype=torch.int32)
-    hip.call("vlfb_roi_align_max_fwd", hip.ptr(Fg), code, hip.ptr(gpu(rois)), hip.ptr(O), hip.ptr(AB), hip.ptr(DBG),
+    hip.call("vlfb_roi_align_max_fwd", hip.ptr(Fg), code, gp(rois), hip.ptr(O), hip.ptr(AB), hip.ptr(DBG),
              N, H, W, Cc, R, 7, 1.0 / 16)
     assert np.array_equal(DBG.cpu().numpy(), dbg_np), "RoIAlign integer decisions must be bit-exact"
     flat = torch.from_numpy(out_np).reshape(R, Cc, 49)
@@ -507,6 +525,6 @@ def test_roi_align_max_head(dtype):
     dout = q(torch.randn(R, Cc, generator=gen), dtype)
     (gf,) = torch.autograd.grad(sel, (fd,), dout.double())
     DF = torch.zeros(N, H, W, Cc, device=dev(), dtype=torch.float32)
-    hip.call("vlfb_roi_align_max_bwd", hip.ptr(gpu(dout, dtype)), code, hip.ptr(gpu(rois)), hip.ptr(AB), hip.ptr(DF),
+    hip.call("vlfb_roi_align_max_bwd", gp(dout, dtype), code, gp(rois), hip.ptr(AB), hip.ptr(DF),
              N, H, W, Cc, R, 7, 1.0 / 16)
     assert rel_err(DF.permute(0, 3, 1, 2), gf) < 1e-5

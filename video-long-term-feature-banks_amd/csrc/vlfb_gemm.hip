@@ -633,7 +633,8 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   g.a_bs = d->a_bstride; g.b_bs = d->b_bstride; g.o_bs = d->o_bstride; g.r_bs = d->r_bstride;
   g.p_bs = d->p_bstride;
   g.alpha = d->alpha; g.relu = d->relu; g.bias_mode = d->bias_mode; g.accumulate = d->accumulate;
-  VLFB_REQUIRE((pl->packw || g.lda % epc == 0) && g.ldb % epc == 0 && g.ldp % epc == 0,
+  VLFB_REQUIRE((pl->packw || g.lda % epc == 0) && (d->mode == VLFB_CONV_WGRAD || g.ldb % epc == 0) &&
+                   (d->mode != VLFB_CONV_WGRAD || g.ldp % epc == 0),
                "conv: leading dimensions must keep 16-byte alignment");
 
   pl->splits = 1;

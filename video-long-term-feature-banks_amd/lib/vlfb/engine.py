@@ -1108,6 +1108,7 @@ class Engine(object):
         fills = self.model.param_init_net.fills
         order = []
         seen = set()
+        self.param_step = {}
         for st in reversed(self.steps):
             names = []
             if isinstance(st, ConvStep):
@@ -1118,6 +1119,7 @@ class Engine(object):
                 if n and self.is_trainable(n) and n not in seen:
                     seen.add(n)
                     order.append(n)
+                    self.param_step[n] = st
         missing = [p for p in self.trainable if p not in seen]
         assert not missing, "trainable params without a producing step: %r" % missing
         self.train_order = order
@@ -1327,6 +1329,8 @@ class Engine(object):
         for b in self.all_blobs:
             if b.root is b and b.slot is not None:
                 b.slot.reset()
+        if self.comm is not None:
+            self.comm.begin()
         for i, st in enumerate(self.bwd_steps):
             st.bwd()
             if self.comm is not None:
@@ -1334,6 +1338,23 @@ class Engine(object):
 
     def set_lr(self, lr):
         self.lr = float(lr)
+
+    def enable_data_parallel(self, bucket_mb=32):
+        """clip-level data parallel over the current process group: identical weights on every rank
+        (broadcast from rank 0), bucketed sum-all-reduce of the flat gradient during backward"""
+        import torch.distributed as td
+        from vlfb.comm import GradComm
+        if not (self.train and dist.world_size() > 1):
+            return
+        td.broadcast(self.flat_param, 0)
+        td.broadcast(self.flat_frozen, 0)
+        self.refresh_operands(all_params=True)
+        index = {id(st): i for i, st in enumerate(self.bwd_steps)}
+        segments = []
+        for n in self.train_order:
+            off, cnt, _ = self.train_layout[n]
+            segments.append((off, cnt, index[id(self.param_step[n])]))
+        self.comm = GradComm(self.flat_grad, segments, int(bucket_mb) << 20)
 
     def scale_momentum(self, factor):
         hip.call("vlfb_scale_inplace", hip.ptr(self.flat_mom), self.flat_mom.numel(), float(factor))

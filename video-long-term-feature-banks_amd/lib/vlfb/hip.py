@@ -167,10 +167,34 @@ def conv_workspace_bytes(d):
     return n
 
 
+def conv_flops(d):
+    """ALGORITHMIC flops (2*MAC of the convolution / GEMM the launch stands for; padding of the
+    packed stem and masked-out taps of strided dgrads do not count)"""
+    taps = d.kt * d.kh * d.kw
+    batch = max(d.batch, 1)
+    if d.mode == DGRAD:      # rows = conv input positions; source = conv output (N,Ts,Hs,Ws,Cs=Cout)
+        return 2.0 * d.N * d.Ts * d.Hs * d.Ws * d.Cs * taps * d.Cn * batch
+    cin = 3 if d.pack_w else d.Cs
+    return 2.0 * d.N * d.Tr * d.Hr * d.Wr * d.Cn * taps * cin * batch
+
+
+# When a list, every conv_run is bracketed by HIP events on the launch stream and appended as
+# (mode, flops, start_event, end_event); bench.py uses it for the live roofline measurement.
+PROFILE = None
+
+
 def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None):
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    prof = PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib().vlfb_conv_run(C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale),
                              ptr(R), ptr(mask), ptr(workspace), ws_bytes, stream())
+    if prof is not None:
+        e1.record()
+        prof.append((d.mode, conv_flops(d), e0, e1))
     _check(rc, "vlfb_conv_run")
 
 
