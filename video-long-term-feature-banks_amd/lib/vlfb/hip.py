@@ -178,6 +178,12 @@ def conv_flops(d):
     return 2.0 * d.N * d.Tr * d.Hr * d.Wr * d.Cn * taps * cin * batch
 
 
+def conv_tag(d):
+    return "%s M=%d Cs=%d Cn=%d k%d%d%d s%d%d%d d%d b%d src%dx%dx%d" % (
+        ("fprop", "dgrad", "wgrad")[d.mode], d.N * d.Tr * d.Hr * d.Wr, d.Cs, d.Cn, d.kt, d.kh, d.kw,
+        d.st, d.sh, d.sw, d.dh, max(d.batch, 1), d.Ts, d.Hs, d.Ws)
+
+
 # When a list, every conv_run is bracketed by HIP events on the launch stream and appended as
 # (mode, flops, start_event, end_event); bench.py uses it for the live roofline measurement.
 PROFILE = None
@@ -194,7 +200,7 @@ def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspa
                              ptr(R), ptr(mask), ptr(workspace), ws_bytes, stream())
     if prof is not None:
         e1.record()
-        prof.append((d.mode, conv_flops(d), e0, e1))
+        prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d)))
     _check(rc, "vlfb_conv_run")
 
 
