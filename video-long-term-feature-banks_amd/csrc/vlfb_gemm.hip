@@ -51,6 +51,7 @@ struct GP {
   int relu, bias_mode, accumulate;
   int tiles_m, tiles_n;
   int splits, kper;
+  int vec_epi;        // NT: LDS-staged, fully coalesced epilogue is legal for this problem
 };
 
 struct RowC { int n, t, h, w; };
@@ -103,25 +104,23 @@ __device__ __forceinline__ TapC decode_tap(const GP& p, int kc) {
   return t;
 }
 
-// element offset of the source chunk, or -1 if it is padding. (non-PACKW)
+// element offset of the source chunk and whether it exists (false = padding). (non-PACKW)
 template <bool DGRAD>
-__device__ __forceinline__ long long src_offset(const GP& p, const RowC& r, const TapC& t) {
+__device__ __forceinline__ long long src_offset(const GP& p, const RowC& r, const TapC& t, bool& ok) {
   int ts, hs, ws;
-  bool ok;
   if (!DGRAD) {
     ts = r.t * p.st - p.pt + t.a * p.dt;
     hs = r.h * p.sh - p.ph + t.b * p.dh;
     ws = r.w * p.sw - p.pw + t.c * p.dw;
     ok = (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
   } else {
-    int nt = r.t + p.pt - t.a * p.dt;
-    int nh = r.h + p.ph - t.b * p.dh;
-    int nw = r.w + p.pw - t.c * p.dw;
-    ok = nt >= 0 && nh >= 0 && nw >= 0 && ((nt & (p.st - 1)) | (nh & (p.sh - 1)) | (nw & (p.sw - 1))) == 0;
+    const int nt = r.t + p.pt - t.a * p.dt;
+    const int nh = r.h + p.ph - t.b * p.dh;
+    const int nw = r.w + p.pw - t.c * p.dw;
+    ok = (nt | nh | nw) >= 0 && ((nt & (p.st - 1)) | (nh & (p.sh - 1)) | (nw & (p.sw - 1))) == 0;
     ts = nt >> p.lst; hs = nh >> p.lsh; ws = nw >> p.lsw;
     ok = ok && ts < p.Ts && hs < p.Hs && ws < p.Ws;
   }
-  if (!ok) return -1;
   return ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * p.lda + t.ci;
 }
 
@@ -131,37 +130,66 @@ __device__ __forceinline__ uint4 ld16(const char* base, long long byte_off) {
 __device__ __forceinline__ uint2 ld8(const char* base, long long byte_off) {
   return *reinterpret_cast<const uint2*>(base + byte_off);
 }
+// 16 bytes of zeros in HBM: the source of every padding / out-of-range chunk, so that gathers
+// need no select on the data (only on the address) and direct-to-LDS loads can write zeros.
+__device__ uint4 g_zero16;
+__device__ __forceinline__ const char* src_or_zero(const char* base, long long byte_off, bool ok) {
+  return ok ? base + byte_off : reinterpret_cast<const char*>(&g_zero16);
+}
+// async 16-byte global -> LDS copy (global_load_lds_dwordx4): per-lane source, destination =
+// wave-uniform `lds_wave_base` + lane * 16
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)src,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
-// One gathered 16-byte chunk of the activation operand.
+// Branch-free predicated loads: the load always executes (from offset 0 of the operand when the
+// element is padding / out of range) and the result is selected afterwards, so the gather of a
+// k-tile is one straight-line run of global loads instead of one basic block per element.
+__device__ __forceinline__ uint4 ld16_if(const char* base, long long byte_off, bool ok) {
+  return *reinterpret_cast<const uint4*>(src_or_zero(base, byte_off, ok));
+}
+__device__ __forceinline__ uint2 ld8_if(const char* base, long long byte_off, bool ok) {
+  return *reinterpret_cast<const uint2*>(src_or_zero(base, byte_off, ok));
+}
+
+// Source address of one gathered 16-byte chunk (zero page when it is padding); non-PACKW only.
+template <typename T, bool IDENT, bool DGRAD>
+__device__ __forceinline__ const char* act_chunk_ptr(const GP& p, const char* base, int m, bool m_ok,
+                                                     const RowC& r, const TapC& t, int kc) {
+  constexpr int EPC = Elem<T>::EPC;
+  if (IDENT)
+    return src_or_zero(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T), m_ok && t.ok);
+  bool ok;
+  const long long off = src_offset<DGRAD>(p, r, t, ok);
+  return src_or_zero(base, off * (long long)sizeof(T), ok && m_ok && t.ok);
+}
+
+// One gathered 16-byte chunk of the activation operand (branch-free).
 template <typename T, bool IDENT, bool DGRAD, bool PACKW>
 __device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, int m, bool m_ok,
                                                 const RowC& r, const TapC& t, int kc) {
   constexpr int EPC = Elem<T>::EPC;
-  uint4 z = make_uint4(0, 0, 0, 0);
   if (IDENT) {
-    if (!(m_ok && t.ok)) return z;
-    return ld16(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T));
+    return ld16_if(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T), m_ok && t.ok);
   } else if (PACKW) {
-    if (!(m_ok && t.ok)) return z;
-    int ts = r.t * p.st - p.pt + t.a * p.dt;
-    int hs = r.h * p.sh - p.ph + t.b * p.dh;
-    if (!((unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs)) return z;
-    int w0 = r.w * p.sw - p.pw + t.c;
-    long long rowoff = ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws) * 4;
+    const int ts = r.t * p.st - p.pt + t.a * p.dt;
+    const int hs = r.h * p.sh - p.ph + t.b * p.dh;
+    const bool ok = m_ok && t.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+    const int w0 = r.w * p.sw - p.pw + t.c;
+    const long long rowoff = ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws) * 4;
     if (sizeof(T) == 4) {  // one pixel (4 ch) per chunk
-      if (!((unsigned)w0 < (unsigned)p.Ws)) return z;
-      return ld16(base, (rowoff + (long long)w0 * 4) * 4);
+      return ld16_if(base, (rowoff + (long long)w0 * 4) * 4, ok && (unsigned)w0 < (unsigned)p.Ws);
     } else {  // two pixels per chunk, 8 bytes each
-      uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
-      if ((unsigned)w0 < (unsigned)p.Ws) lo = ld8(base, (rowoff + (long long)w0 * 4) * 2);
-      if ((unsigned)(w0 + 1) < (unsigned)p.Ws) hi = ld8(base, (rowoff + (long long)(w0 + 1) * 4) * 2);
+      const uint2 lo = ld8_if(base, (rowoff + (long long)w0 * 4) * 2, ok && (unsigned)w0 < (unsigned)p.Ws);
+      const uint2 hi = ld8_if(base, (rowoff + (long long)(w0 + 1) * 4) * 2, ok && (unsigned)(w0 + 1) < (unsigned)p.Ws);
       return make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
   } else {
-    if (!(m_ok && t.ok)) return z;
-    long long off = src_offset<DGRAD>(p, r, t);
-    if (off < 0) return z;
-    return ld16(base, off * (long long)sizeof(T));
+    bool ok;
+    const long long off = src_offset<DGRAD>(p, r, t, ok);
+    return ld16_if(base, off * (long long)sizeof(T), ok && m_ok && t.ok);
   }
 }
 
@@ -220,6 +248,28 @@ __device__ __forceinline__ void store4(char* base, long long idx, const float (&
   }
 }
 
+// N consecutive elements of T (N * sizeof(T) = 8 or 16 bytes, naturally aligned) as floats
+template <typename T, int N>
+__device__ __forceinline__ void load_elems(const T* p, float (&v)[N]) {
+  if (sizeof(T) == 4) {
+    static_assert(sizeof(T) != 4 || N == 4, "fp32 rows are read 4 at a time");
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2 % N] = t.z; v[3 % N] = t.w;
+  } else if (N == 8) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[(2 * i) % N] = __uint_as_float(w[i] << 16);
+      v[(2 * i + 1) % N] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  } else {  // 4 bf16 = 8 bytes
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2 % N] = __uint_as_float(t.y << 16); v[3 % N] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+
 // XCD-aware remap of a linear workgroup id: consecutive ids on one XCD share operand panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;
@@ -255,8 +305,15 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   const char* Ab = p.A + (long long)z * p.a_bs * (long long)sizeof(T);
   const char* Bb = p.B + (long long)z * p.b_bs * (long long)sizeof(T);
 
+  // Staging: thread t owns LDS slot (row = t/8 + 32*i, 16-byte slot t%8) of both operand tiles.
+  // GLDS (everything but the packed stem): the global->LDS copy is asynchronous DMA
+  // (global_load_lds_dwordx4, no VGPR round trip); a wave's 64 slots are 1 KiB contiguous, and
+  // because the LDS image is XOR-swizzled the lane fetches global chunk (slot ^ (row & 7)).
+  constexpr bool GLDS = !PACKW;
   const int cc = tid & 7;
   const int r0 = tid >> 3;
+  const int ccg = GLDS ? (cc ^ (r0 & 7)) : cc;   // global 16-byte chunk column fetched by this lane
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   RowC arow[A_IT];
   bool aok[A_IT];
@@ -270,31 +327,47 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   uint4 ra[A_IT], rb[B_IT];
   const int ktiles = (p.K * (int)sizeof(T) + kRowBytes - 1) / kRowBytes;
 
-  auto load_tile = [&](int kt) {
-    const int kc = kt * 8 + cc;
+  auto load_tile = [&](int kt, int buf) {
+    const int kc = kt * 8 + ccg;
     TapC tap;
     if (IDENT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
     else tap = decode_tap<T, PACKW>(p, kc);
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      ra[i] = load_act_chunk<T, IDENT, DGRAD, PACKW>(p, Ab, m0 + r0 + 32 * i, aok[i], arow[i], tap, kc);
     const bool kok = kc * EPC < p.K;
+    if (GLDS) {
+      char* xa = smem + buf * BUF + wave_u * 1024;
+      char* wb = smem + buf * BUF + BM * kRowBytes + wave_u * 1024;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int n = n0 + r0 + 32 * i;
-      if (kok && n < p.Ncols)
-        rb[i] = ld16(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T));
-      else
-        rb[i] = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < A_IT; ++i)
+        glds16(act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + 32 * i, aok[i], arow[i], tap, kc), xa + i * 4096);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        glds16(src_or_zero(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols),
+               wb + i * 4096);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i)
+        ra[i] = load_act_chunk<T, IDENT, DGRAD, PACKW>(p, Ab, m0 + r0 + 32 * i, aok[i], arow[i], tap, kc);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        rb[i] = ld16_if(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols);
+      }
     }
   };
   auto store_tile = [&](int buf) {
+    if (GLDS) return;
     char* xa = smem + buf * BUF;
     char* wb = xa + BM * kRowBytes;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(xa + lds_off(r0 + 32 * i, cc)) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(wb + lds_off(r0 + 32 * i, cc)) = rb[i];
+  };
+  auto tile_ready = [&]() {
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed
+    __syncthreads();
   };
 
   f32x4_v acc[FN][FM];
@@ -303,13 +376,13 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
 #pragma unroll
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
+  load_tile(0, 0);
   store_tile(0);
-  __syncthreads();
+  tile_ready();
 
   for (int kt = 0; kt < ktiles; ++kt) {
     const bool more = kt + 1 < ktiles;
-    if (more) load_tile(kt + 1);
+    if (more) load_tile(kt + 1, (kt + 1) & 1);
     const char* xa = smem + (kt & 1) * BUF;
     const char* wb = xa + BM * kRowBytes;
 #pragma unroll
@@ -325,13 +398,86 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
         for (int i = 0; i < FM; ++i) acc[j][i] = Mma<T>::mma(wf[j], xf[i], acc[j][i]);
     }
     if (more) store_tile((kt + 1) & 1);
-    __syncthreads();
+    tile_ready();
   }
 
-  // ---- epilogue: lane holds n = nb + 0..3 (consecutive) for row m ---------------------------
+  // ---- epilogue ------------------------------------------------------------------------------
   char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
+  constexpr int EPT = 16 / (int)sizeof(OutT);   // output elements per 16-byte store
+  if (p.vec_epi) {
+    // Coalesced path: the fp32 accumulator tile goes through LDS (16-byte chunks XOR-swizzled by
+    // row & 7, conflict-free for both the fragment-shaped writes and the row-shaped reads), then
+    // every lane handles EPT consecutive columns of one row: residual / mask are read and the
+    // result is written with full 16-byte accesses, whole rows of the tile per wavefront.
+    constexpr int CPR = BN / 4;          // 16-byte fp32 chunks per tile row
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm * WM + i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = (wn * WN + j * 16 + g * 4) >> 2;
+        *reinterpret_cast<float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4)) =
+            make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha,
+                        acc[j][i][3] * p.alpha);
+      }
+    }
+    __syncthreads();
+    constexpr int TPR = BN / EPT;        // lanes per tile row
+    constexpr int RPP = kThreads / TPR;  // rows per pass
+    const int tc = tid % TPR, tr = tid / TPR;
+    const int n = n0 + tc * EPT;
+    if (n < p.Ncols) {
+#pragma unroll 2
+      for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = pass * RPP + tr;
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        float v[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT / 4; ++q) {
+          const int c = tc * (EPT / 4) + q;
+          const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4));
+          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        if (p.bias_mode == VLFB_BIAS_COL) {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) v[e] += p.bias[n + e];
+        } else if (p.bias_mode == VLFB_BIAS_ROW) {
+          const float b = p.bias[m];
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) v[e] += b;
+        }
+        const long long ridx = (long long)m * p.ldr + n;
+        if (Rb) {
+          float r[EPT];
+          load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) v[e] += r[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (Mb) {
+          float r[EPT];
+          load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
+        }
+        OutT* o = reinterpret_cast<OutT*>(Ob) + (long long)m * p.ldo + n;
+        if (sizeof(OutT) == 4) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
+                                                    pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
+        }
+      }
+    }
+    return;
+  }
+  // Generic path (odd column counts / leading dimensions): lane holds n = nb + 0..3 for row m.
   const bool vec_ok = (p.ldo & 3) == 0;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -387,6 +533,53 @@ __device__ __forceinline__ void transpose_block(const uint4 (&in)[4], uint4 (&ou
   out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
 }
 
+// TN gather state of one staging block: the tap is fixed per thread, positions advance, so the
+// (n, t, h) part of the source address and its validity are cached and only refreshed when the
+// position wraps to a new output row -- no integer division inside the k loop.
+struct QRow {
+  int n, t, h, w;
+  long long base;   // pixel index of source row (n, ts, hs, 0)
+  bool hv;          // ts, hs inside the source
+};
+__device__ __forceinline__ void qrow_refresh(const GP& p, QRow& r, const TapC& tp) {
+  const int ts = r.t * p.st - p.pt + tp.a * p.dt;
+  const int hs = r.h * p.sh - p.ph + tp.b * p.dh;
+  r.hv = (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+  r.base = ((long long)(r.n * p.Ts + ts) * p.Hs + hs) * p.Ws;
+}
+__device__ __forceinline__ void qrow_next(const GP& p, QRow& r, const TapC& tp) {
+  if (++r.w == p.Wr) {
+    r.w = 0;
+    if (++r.h == p.Hr) {
+      r.h = 0;
+      if (++r.t == p.Tr) { r.t = 0; ++r.n; }
+    }
+    qrow_refresh(p, r, tp);
+  }
+}
+// r += (dn, dt, dh, dw) in the mixed radix (Tr, Hr, Wr)
+__device__ __forceinline__ void qrow_jump(const GP& p, QRow& r, const RowC& d, const TapC& tp) {
+  r.w += d.w; if (r.w >= p.Wr) { r.w -= p.Wr; ++r.h; }
+  r.h += d.h; if (r.h >= p.Hr) { r.h -= p.Hr; ++r.t; }
+  r.t += d.t; if (r.t >= p.Tr) { r.t -= p.Tr; ++r.n; }
+  r.n += d.n;
+  qrow_refresh(p, r, tp);
+}
+template <typename T, bool PACKW>
+__device__ __forceinline__ uint4 qrow_load(const GP& p, const char* base, const QRow& r, const TapC& tp, bool ok) {
+  ok = ok && tp.ok && r.hv;
+  if (PACKW) {
+    const int w0 = r.w * p.sw - p.pw + tp.c;
+    if (sizeof(T) == 4) return ld16_if(base, (r.base + w0) * 16, ok && (unsigned)w0 < (unsigned)p.Ws);
+    const uint2 lo = ld8_if(base, (r.base + w0) * 8, ok && (unsigned)w0 < (unsigned)p.Ws);
+    const uint2 hi = ld8_if(base, (r.base + w0 + 1) * 8, ok && (unsigned)(w0 + 1) < (unsigned)p.Ws);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  } else {
+    const int ws = r.w * p.sw - p.pw + tp.c * p.dw;
+    return ld16_if(base, ((r.base + ws) * p.lda + tp.ci) * (long long)sizeof(T), ok && (unsigned)ws < (unsigned)p.Ws);
+  }
+}
+
 template <typename T, typename OutT, int BP, int BQ, bool IDENT, bool PACKW>
 __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
   constexpr int EPC = Elem<T>::EPC;
@@ -403,10 +596,22 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
   const int l15 = lane & 15, g = lane >> 4;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = xcd_remap(blockIdx.x, nwg);
+  int bid, split;
+  if (p.splits > 1 && (p.splits & 7) == 0) {
+    // 1-D grid, XCD-grouped: workgroup id -> (xcd = id % 8, slot = id / 8).  All output tiles of
+    // one position-split run back to back on ONE XCD, so the P / X panels of that split are
+    // fetched from HBM once and re-used out of that XCD's L2 by the other tiles.
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    bid = slot % nwg;
+    split = (slot / nwg) * 8 + xcd;
+  } else {
+    bid = xcd_remap(blockIdx.x, nwg);
+    split = blockIdx.y;
+  }
   const int tile_p = bid / p.tiles_n, tile_q = bid - tile_p * p.tiles_n;
   const int p0 = tile_p * BP, q0 = tile_q * BQ;
-  const int split = blockIdx.y, z = blockIdx.z;
+  const int z = blockIdx.z;
 
   const char* Pb = p.P + (long long)z * p.p_bs * (long long)sizeof(T);
   const char* Ab = p.A + (long long)z * p.a_bs * (long long)sizeof(T);
@@ -430,6 +635,20 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
       else qtap[it] = decode_tap<T, PACKW>(p, kc);
     }
   }
+  // gather cursors (generic path): first position of the block in k-tile 0, and the BK jump
+  QRow qrow[ITER];
+  RowC jump;
+  if (!IDENT) {
+    jump = decode_row(p, BK - EPC);   // after a tile the cursor already moved EPC positions
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (blk_kind[it] == 1) {
+        const RowC r0 = decode_row(p, min(kbeg + blk_k[it] * EPC, p.M - 1));
+        qrow[it].n = r0.n; qrow[it].t = r0.t; qrow[it].h = r0.h; qrow[it].w = r0.w;
+        qrow_refresh(p, qrow[it], qtap[it]);
+      }
+    }
+  }
 
   uint4 stg[ITER][EPC];
 
@@ -443,20 +662,24 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
           const int k = kk + j;
-          if (cok && k < kend)
-            stg[it][j] = ld16(Pb, ((long long)k * p.ldp + pc) * (long long)sizeof(T));
-          else
-            stg[it][j] = make_uint4(0, 0, 0, 0);
+          stg[it][j] = ld16_if(Pb, ((long long)k * p.ldp + pc) * (long long)sizeof(T), cok && k < kend);
         }
       } else if (blk_kind[it] == 1) {
         const int kc = (q0 + blk_r[it] * EPC) / EPC;
-        RowC r;
-        if (!IDENT) r = decode_row(p, kk < kend ? kk : 0);
+        if (IDENT) {
+          RowC unused;
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) {
-          const int k = kk + j;
-          stg[it][j] = load_act_chunk<T, IDENT, false, PACKW>(p, Ab, k, k < kend, r, qtap[it], kc);
-          if (!IDENT) advance_row(p, r);
+          for (int j = 0; j < EPC; ++j) {
+            const int k = kk + j;
+            stg[it][j] = load_act_chunk<T, true, false, false>(p, Ab, k, k < kend, unused, qtap[it], kc);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) {
+            stg[it][j] = qrow_load<T, PACKW>(p, Ab, qrow[it], qtap[it], kk + j < kend);
+            qrow_next(p, qrow[it], qtap[it]);
+          }
+          qrow_jump(p, qrow[it], jump, qtap[it]);   // to this block's slot in the next k-tile
         }
       }
     }
@@ -645,6 +868,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     g.tiles_m = (int)((M + pl->bm - 1) / pl->bm);
     g.tiles_n = (d->Cn + pl->bn - 1) / pl->bn;
     pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
+    const int ept = d->out_dtype == VLFB_F32 ? 4 : 8;   // elements per 16-byte output store
+    g.vec_epi = (d->Cn % ept == 0) && (g.ldo % ept == 0) && (g.ldr % ept == 0) &&
+                (d->o_bstride % ept == 0) && (d->r_bstride % ept == 0);
   } else {
     pl->bm = d->Cn > 64 ? 128 : 64;             // P tile (output rows)
     pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
@@ -653,12 +879,23 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     const int bk = 128 / es;
     int splits = d->splits;
     if (splits <= 0) {
-      long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
-      long long want = (1024 + tiles - 1) / tiles;      // ~4 workgroups per CU
-      long long maxs = (M + 8 * bk - 1) / (8 * bk);     // at least 8 k-tiles per split
-      splits = (int)(want < maxs ? want : maxs);
-      if (splits < 1) splits = 1;
-      if (batch > 1) splits = 1;
+      // Two 64 KiB-LDS workgroups fit a CU, so one "wave" of the grid is 512 workgroups.  Pick the
+      // split count that fills whole waves best (every extra split costs one more fp32 slab
+      // pass), keeping at least 8 k-tiles of work per split.
+      const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
+      const long long slots = 512;
+      long long maxs = (M + 8 * bk - 1) / (8 * bk);
+      const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
+      if (maxs > slab_cap) maxs = slab_cap;
+      if (maxs > 1024) maxs = 1024;
+      if (batch > 1 || maxs < 1) maxs = 1;
+      double best = -1.0;
+      splits = 1;
+      for (long long sp = 1; sp <= maxs; sp = (sp < 8 ? sp + 1 : sp + 8)) {   // 1..8, then multiples of 8
+        const long long total = tiles * sp;
+        const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+        if (eff > best + 0.03) { best = eff; splits = (int)sp; }
+      }
     }
     VLFB_REQUIRE(splits == 1 || batch == 1, "conv: split WGRAD cannot be batched");
     long long kper = (M + splits - 1) / splits;
@@ -671,7 +908,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       VLFB_REQUIRE(g.ldo == (int)K, "conv: split WGRAD needs a dense output (ldo == K)");
       pl->ws_elems = (long long)splits * d->Cn * K;
     }
-    pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
+    if (splits > 1 && splits % 8 == 0)
+      pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n * splits), 1, 1);
+    else
+      pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
   }
   pl->lds = (size_t)2 * (pl->bm + pl->bn) * kRowBytes;
   return VLFB_OK;
