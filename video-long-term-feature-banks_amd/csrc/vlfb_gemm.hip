@@ -18,6 +18,7 @@
 // 4 consecutive output channels of one output row -> 8/16-byte epilogue stores.
 #include "vlfb_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace vlfb {
 namespace {
@@ -193,18 +194,24 @@ __device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, i
   }
 }
 
+// LDS tile rows are RB bytes of K (128: 8 chunks, XOR key row & 7; 64: 4 chunks, key (row >> 2) & 3
+// -- four 64-byte rows share one 256-byte bank row, so the key must change every 4 rows).
+template <int RB>
+__device__ __forceinline__ int swz_key(int row) { return RB == 128 ? (row & 7) : ((row >> 2) & 3); }
+template <int RB = 128>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * kRowBytes + ((chunk ^ (row & 7)) << 4);
+  return row * RB + ((chunk ^ swz_key<RB>(row)) << 4);
 }
 
 // ---- MFMA wrappers --------------------------------------------------------------------------
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-  static constexpr int KSTEPS = 2;
+  static constexpr int KSTEPS = 2;   // per 128-byte row (a 64-byte row is one k-step)
   struct Frag { bf16x8_v v; };
+  template <int RB = 128>
   __device__ static __forceinline__ Frag load(const char* tile, int row, int ks, int g) {
     Frag f;
-    f.v = *reinterpret_cast<const bf16x8_v*>(tile + lds_off(row, ks * 4 + g));
+    f.v = *reinterpret_cast<const bf16x8_v*>(tile + lds_off<RB>(row, ks * 4 + g));
     return f;
   }
   __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) {
@@ -214,7 +221,9 @@ template <> struct Mma<bf16_t> {
 template <> struct Mma<float> {
   static constexpr int KSTEPS = 1;
   struct Frag { float v[8]; };
+  template <int RB = 128>
   __device__ static __forceinline__ Frag load(const char* tile, int row, int /*ks*/, int g) {
+    static_assert(RB == 128, "the fp32 path keeps 128-byte tile rows");
     Frag f;
     float4 lo = *reinterpret_cast<const float4*>(tile + lds_off(row, 2 * g));
     float4 hi = *reinterpret_cast<const float4*>(tile + lds_off(row, 2 * g + 1));
@@ -282,13 +291,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // =============================================================================================
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
 // =============================================================================================
-template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW>
+template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB>
 __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  constexpr int CPRW = RB / 16;            // 16-byte chunks per tile row
+  constexpr int RPPS = kThreads / CPRW;    // tile rows staged per pass
+  constexpr int A_IT = BM / RPPS, B_IT = BN / RPPS;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int FM = WM / 16, FN = WN / 16;
-  constexpr int BUF = (BM + BN) * kRowBytes;
+  constexpr int BUF = (BM + BN) * RB;
+  constexpr int KSTEPS = sizeof(T) == 4 ? 1 : RB / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -310,48 +322,48 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   // (global_load_lds_dwordx4, no VGPR round trip); a wave's 64 slots are 1 KiB contiguous, and
   // because the LDS image is XOR-swizzled the lane fetches global chunk (slot ^ (row & 7)).
   constexpr bool GLDS = !PACKW;
-  const int cc = tid & 7;
-  const int r0 = tid >> 3;
-  const int ccg = GLDS ? (cc ^ (r0 & 7)) : cc;   // global 16-byte chunk column fetched by this lane
+  const int cc = tid % CPRW;
+  const int r0 = tid / CPRW;
+  const int ccg = GLDS ? (cc ^ swz_key<RB>(r0)) : cc;   // global 16-byte chunk column fetched by this lane
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   RowC arow[A_IT];
   bool aok[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + r0 + 32 * i;
+    int m = m0 + r0 + RPPS * i;
     aok[i] = m < p.M;
     if (!IDENT) arow[i] = decode_row(p, aok[i] ? m : 0);
   }
 
   uint4 ra[A_IT], rb[B_IT];
-  const int ktiles = (p.K * (int)sizeof(T) + kRowBytes - 1) / kRowBytes;
+  const int ktiles = (p.K * (int)sizeof(T) + RB - 1) / RB;
 
   auto load_tile = [&](int kt, int buf) {
-    const int kc = kt * 8 + ccg;
+    const int kc = kt * CPRW + ccg;
     TapC tap;
     if (IDENT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
     else tap = decode_tap<T, PACKW>(p, kc);
     const bool kok = kc * EPC < p.K;
     if (GLDS) {
       char* xa = smem + buf * BUF + wave_u * 1024;
-      char* wb = smem + buf * BUF + BM * kRowBytes + wave_u * 1024;
+      char* wb = smem + buf * BUF + BM * RB + wave_u * 1024;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        glds16(act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + 32 * i, aok[i], arow[i], tap, kc), xa + i * 4096);
+        glds16(act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc), xa + i * 4096);
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + RPPS * i;
         glds16(src_or_zero(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols),
                wb + i * 4096);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        ra[i] = load_act_chunk<T, IDENT, DGRAD, PACKW>(p, Ab, m0 + r0 + 32 * i, aok[i], arow[i], tap, kc);
+        ra[i] = load_act_chunk<T, IDENT, DGRAD, PACKW>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc);
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + RPPS * i;
         rb[i] = ld16_if(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols);
       }
     }
@@ -359,11 +371,11 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   auto store_tile = [&](int buf) {
     if (GLDS) return;
     char* xa = smem + buf * BUF;
-    char* wb = xa + BM * kRowBytes;
+    char* wb = xa + BM * RB;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(xa + lds_off(r0 + 32 * i, cc)) = ra[i];
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(xa + lds_off<RB>(r0 + RPPS * i, cc)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(wb + lds_off(r0 + 32 * i, cc)) = rb[i];
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(wb + lds_off<RB>(r0 + RPPS * i, cc)) = rb[i];
   };
   auto tile_ready = [&]() {
     if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed
@@ -384,14 +396,14 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
     const bool more = kt + 1 < ktiles;
     if (more) load_tile(kt + 1, (kt + 1) & 1);
     const char* xa = smem + (kt & 1) * BUF;
-    const char* wb = xa + BM * kRowBytes;
+    const char* wb = xa + BM * RB;
 #pragma unroll
-    for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
+    for (int ks = 0; ks < KSTEPS; ++ks) {
       typename Mma<T>::Frag xf[FM], wf[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) xf[i] = Mma<T>::load(xa, wm * WM + i * 16 + l15, ks, g);
+      for (int i = 0; i < FM; ++i) xf[i] = Mma<T>::template load<RB>(xa, wm * WM + i * 16 + l15, ks, g);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) wf[j] = Mma<T>::load(wb, wn * WN + j * 16 + l15, ks, g);
+      for (int j = 0; j < FN; ++j) wf[j] = Mma<T>::template load<RB>(wb, wn * WN + j * 16 + l15, ks, g);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -412,66 +424,76 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
     // every lane handles EPT consecutive columns of one row: residual / mask are read and the
     // result is written with full 16-byte accesses, whole rows of the tile per wavefront.
     constexpr int CPR = BN / 4;          // 16-byte fp32 chunks per tile row
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int row = wm * WM + i * 16 + l15;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int c = (wn * WN + j * 16 + g * 4) >> 2;
-        *reinterpret_cast<float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4)) =
-            make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha,
-                        acc[j][i][3] * p.alpha);
-      }
-    }
-    __syncthreads();
+    // the fp32 tile is staged in ONE pass when it fits the operand buffers, else in two halves
+    // (rows of wave-row 0, then of wave-row 1)
+    constexpr int EPI = (BM * BN * 4 > 2 * BUF) ? 2 : 1;
+    constexpr int EROWS = BM / EPI;
     constexpr int TPR = BN / EPT;        // lanes per tile row
     constexpr int RPP = kThreads / TPR;  // rows per pass
     const int tc = tid % TPR, tr = tid / TPR;
     const int n = n0 + tc * EPT;
-    if (n < p.Ncols) {
+#pragma unroll
+    for (int h = 0; h < EPI; ++h) {
+      if (h > 0) __syncthreads();
+      if (EPI == 1 || wm == h) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = (EPI == 1 ? wm * WM : 0) + i * 16 + l15;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int c = (wn * WN + j * 16 + g * 4) >> 2;
+            *reinterpret_cast<float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4)) =
+                make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha,
+                            acc[j][i][3] * p.alpha);
+          }
+        }
+      }
+      __syncthreads();
+      if (n < p.Ncols) {
 #pragma unroll 2
-      for (int pass = 0; pass < BM / RPP; ++pass) {
-        const int row = pass * RPP + tr;
-        const int m = m0 + row;
-        if (m >= p.M) break;
-        float v[EPT];
+        for (int pass = 0; pass < EROWS / RPP; ++pass) {
+          const int row = pass * RPP + tr;
+          const int m = m0 + h * EROWS + row;
+          if (m >= p.M) break;
+          float v[EPT];
 #pragma unroll
-        for (int q = 0; q < EPT / 4; ++q) {
-          const int c = tc * (EPT / 4) + q;
-          const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4));
-          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
-        if (p.bias_mode == VLFB_BIAS_COL) {
+          for (int q = 0; q < EPT / 4; ++q) {
+            const int c = tc * (EPT / 4) + q;
+            const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4));
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+          }
+          if (p.bias_mode == VLFB_BIAS_COL) {
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) v[e] += p.bias[n + e];
-        } else if (p.bias_mode == VLFB_BIAS_ROW) {
-          const float b = p.bias[m];
+            for (int e = 0; e < EPT; ++e) v[e] += p.bias[n + e];
+          } else if (p.bias_mode == VLFB_BIAS_ROW) {
+            const float b = p.bias[m];
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) v[e] += b;
-        }
-        const long long ridx = (long long)m * p.ldr + n;
-        if (Rb) {
-          float r[EPT];
-          load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
+            for (int e = 0; e < EPT; ++e) v[e] += b;
+          }
+          const long long ridx = (long long)m * p.ldr + n;
+          if (Rb) {
+            float r[EPT];
+            load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) v[e] += r[e];
-        }
-        if (p.relu) {
+            for (int e = 0; e < EPT; ++e) v[e] += r[e];
+          }
+          if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (Mb) {
-          float r[EPT];
-          load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
+            for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (Mb) {
+            float r[EPT];
+            load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
-        }
-        OutT* o = reinterpret_cast<OutT*>(Ob) + (long long)m * p.ldo + n;
-        if (sizeof(OutT) == 4) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
-                                                    pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
+            for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
+          }
+          OutT* o = reinterpret_cast<OutT*>(Ob) + (long long)m * p.ldo + n;
+          if (sizeof(OutT) == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
+                                                      pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
+          }
         }
       }
     }
@@ -798,6 +820,7 @@ struct Plan {
   bool ident, packw;
   int bm, bn;     // tile (NT: m x n; TN: p x q)
   int splits;
+  int rb;         // NT tile-row bytes (64 or 128)
   dim3 grid;
   size_t lds;
   long long ws_elems;
@@ -913,7 +936,12 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     else
       pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
   }
-  pl->lds = (size_t)2 * (pl->bm + pl->bn) * kRowBytes;
+  pl->rb = 128;
+  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16) {
+    static const int env_rb = [] { const char* e = getenv("VLFB_NT_RB"); return e ? atoi(e) : 128; }();
+    pl->rb = env_rb == 128 ? 128 : 64;
+  }
+  pl->lds = (size_t)2 * (pl->bm + pl->bn) * pl->rb;
   return VLFB_OK;
 }
 
@@ -930,8 +958,14 @@ void launch_k(K kernel, const Plan& pl, hipStream_t s) {
 }
 template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
-  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW>, pl, s);
-  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW>, pl, s);
+  if (sizeof(T) == 2 && pl.rb == 64) {
+    // 64-byte tile rows: half the LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU
+    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128>, pl, s);
+    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128>, pl, s);
+    return;
+  }
+  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128>, pl, s);
+  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128>, pl, s);
 }
 template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn(const Plan& pl, hipStream_t s) {

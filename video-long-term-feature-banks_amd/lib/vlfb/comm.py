@@ -41,6 +41,10 @@ class GradComm(object):
         self._next = 0
         self._works = []
 
+    def due(self, step_index):
+        """True when at least one bucket becomes ready after backward step `step_index`"""
+        return self._next < len(self.buckets) and self.buckets[self._next][2] <= step_index
+
     def after_step(self, step_index):
         """call after backward step `step_index` has been enqueued"""
         while self._next < len(self.buckets) and self.buckets[self._next][2] <= step_index:

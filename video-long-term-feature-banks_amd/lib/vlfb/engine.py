@@ -257,6 +257,17 @@ class ConvStep(Step):
         g = self.out_grad()
         if self.residual is not None and self.residual.needs_grad and not self.residual.detached:
             self.residual.root.slot.contribute_alias(g)
+        if self.d_w is not None or (self.cbname and eng.is_trainable(self.cbname)):
+            # weight / bias gradients are leaves of the backward graph: they run on the side stream
+            # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
+            with eng.on_side_stream():
+                self._param_grads(g)
+        if self.d_d is not None:
+            self.x.root.slot.contribute(
+                lambda out, add, mask: hip.conv_run(self.d_d, g, self.w_d, None, out, R=add, mask=mask))
+
+    def _param_grads(self, g):
+        eng = self.eng
         if self.d_w is not None:
             s = eng.param_tensor(self.sname) if self.sname else None
             hip.conv_run(self.d_w, self.x.storage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
@@ -274,9 +285,6 @@ class ConvStep(Step):
                          hip.ptr(gb), 1, Cout, 1)
             else:
                 hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
-        if self.d_d is not None:
-            self.x.root.slot.contribute(
-                lambda out, add, mask: hip.conv_run(self.d_d, g, self.w_d, None, out, R=add, mask=mask))
 
 
 class PoolStep(Step):
@@ -1046,7 +1054,40 @@ class Engine(object):
         self._sact = 0
         self.lr = float(model.current_lr)
         self.comm = None
+        self.side = None
+        self.side_dirty = False
         model.engine = self
+
+    # ---- side stream for parameter gradients ---------------------------------------------------
+    class _Side(object):
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            eng = self.eng
+            if eng.side is None:
+                return self
+            ev = torch.cuda.Event()
+            ev.record()                       # everything enqueued so far on the main stream
+            eng.side.wait_event(ev)
+            self.ctx = torch.cuda.stream(eng.side)
+            self.ctx.__enter__()
+            eng.side_dirty = True
+            return self
+
+        def __exit__(self, *exc):
+            if self.eng.side is not None:
+                self.ctx.__exit__(*exc)
+            return False
+
+    def on_side_stream(self):
+        return Engine._Side(self)
+
+    def join_side_stream(self):
+        """make the main stream wait for every parameter-gradient kernel issued so far"""
+        if self.side is not None and self.side_dirty:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_dirty = False
 
     # ---- bookkeeping used by steps ------------------------------------------------------------
     def is_trainable(self, name):
@@ -1101,6 +1142,9 @@ class Engine(object):
         self._allocate()
         if not self.dry_run:
             self.refresh_operands(all_params=True)
+            import os
+            if self.train and os.environ.get("VLFB_SIDE_STREAM", "1") != "0":
+                self.side = torch.cuda.Stream(device=self.device)
         return self
 
     def _plan_params(self):
@@ -1333,8 +1377,10 @@ class Engine(object):
             self.comm.begin()
         for i, st in enumerate(self.bwd_steps):
             st.bwd()
-            if self.comm is not None:
+            if self.comm is not None and self.comm.due(i):
+                self.join_side_stream()       # the bucket's gradients were produced on the side stream
                 self.comm.after_step(i)
+        self.join_side_stream()
 
     def set_lr(self, lr):
         self.lr = float(lr)
