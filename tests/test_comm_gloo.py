@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two processes over gloo drive the same GradComm class the GPU engine uses
+(bucketed, asynchronous sum-all-reduce of the flat gradient in backward-completion order)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "video-long-term-feature-banks_amd", "lib"))
+    from vlfb.comm import GradComm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [1000, 37, 5000, 64, 64, 20000, 3]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 63) // 64 * 64
+    flat = torch.zeros(off)
+    segs = [(o, n, i) for i, (o, n) in enumerate(zip(offs, sizes))]     # one backward step per tensor
+    comm = GradComm(flat, segs, bucket_bytes=16 * 1024)
+    assert len(comm.buckets) >= 3 and comm.buckets[0][0] == 0
+    for it in range(2):
+        flat.zero_()
+        comm.begin()
+        for i, (o, n) in enumerate(zip(offs, sizes)):
+            flat[o:o + n] = float(rank + 1) * (i + 1) + it       # "backward step i" writes gradient i
+            if comm.due(i):
+                comm.after_step(i)
+        comm.wait()
+        want = sum(r + 1 for r in range(world))
+        for i, (o, n) in enumerate(zip(offs, sizes)):
+            assert torch.allclose(flat[o:o + n], torch.full((n,), float(want * (i + 1) + world * it))), (it, i)
+    out[rank] = 1
+    td.destroy_process_group()
+
+
+def test_bucketed_allreduce_world_size_2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(out) == {0: 1, 1: 1}

@@ -897,6 +897,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   } else {
     pl->bm = d->Cn > 64 ? 128 : 64;             // P tile (output rows)
     pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
+    // few output rows (res2 / stem, Cout = 64): widen the Q tile so a workgroup still has
+    // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
+    if (pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
     g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
     g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
     const int bk = 128 / es;
@@ -951,7 +954,7 @@ void launch_k(K kernel, const Plan& pl, hipStream_t s) {
   static bool configured = false;  // per template instance
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     configured = true;
   }
   hipLaunchKernelGGL(kernel, pl.grid, dim3(kThreads), pl.lds, s, pl.gp);
@@ -970,6 +973,7 @@ void launch_nt(const Plan& pl, hipStream_t s) {
 template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn(const Plan& pl, hipStream_t s) {
   if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_kernel<T, OutT, 128, 128, IDENT, PACKW>, pl, s);
+  else if (pl.bm == 64 && pl.bn == 256) launch_k(gemm_tn_kernel<T, OutT, 64, 256, IDENT, PACKW>, pl, s);
   else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_kernel<T, OutT, 64, 128, IDENT, PACKW>, pl, s);
   else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_kernel<T, OutT, 128, 64, IDENT, PACKW>, pl, s);
   else launch_k(gemm_tn_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
