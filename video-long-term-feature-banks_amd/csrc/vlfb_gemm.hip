@@ -787,6 +787,188 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
   }
 }
 
+
+// =============================================================================================
+// TN kernel, bf16, DMA + LDS transpose-read variant.
+// The operand tiles are copied as they lie in HBM ([position][channel], 16-byte pieces by
+// global_load_lds) -- no VGPR staging, no register transposes, no ds_write -- and the MFMA fragments
+// (8 consecutive positions of one channel per lane) are produced by ds_read_b64_tr_b16, which
+// returns to lane i of a 16-lane group column i of a 4(k) x 16(channel) block.
+// LDS rows are RS = 2*B bytes (one position); the 32-byte segment index is XOR-ed with a key of
+// the row so that the 8 rows touched by a 32-lane half of a tr-read fall on 8 different 32-byte
+// bank segments (the DMA destination is lane-linear, so the XOR is applied on the SOURCE chunk).
+// =============================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4_v;
+
+template <int RS> __device__ __forceinline__ int tr_key(int row) {
+  return RS == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+// fragment: channels c0..c0+15 (lane -> c0 + (l & 15)), positions ks*32 + 8*(l>>4) .. +7
+template <int RS>
+__device__ __forceinline__ bf16x8_v tr_frag(const char* tile, int c0, int ks, int lane) {
+  const int g = lane >> 4, pl = lane & 15;
+  const int seg = c0 >> 4;
+  const int r0 = ks * 32 + 8 * g + (pl >> 2);
+  const int r1 = r0 + 4;
+  const s16x4_v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_v*)(tile + r0 * RS + ((seg ^ tr_key<RS>(r0)) << 5) + ((pl & 3) << 3)));
+  const s16x4_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_v*)(tile + r1 * RS + ((seg ^ tr_key<RS>(r1)) << 5) + ((pl & 3) << 3)));
+  union { struct { s16x4_v a, b; } s; bf16x8_v v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+template <typename OutT, int BP, int BQ, bool IDENT>
+__global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
+  typedef bf16_t T;
+  constexpr int BK = 64;                         // positions per k-tile
+  constexpr int RSP = BP * 2, RSQ = BQ * 2;      // LDS row bytes (one position)
+  constexpr int CP = BP / 8, CQ = BQ / 8;        // 16-byte chunks per row
+  constexpr int PI = BK * CP / kThreads, QI = BK * CQ / kThreads;   // DMA pieces per thread
+  constexpr int RPP_P = kThreads / CP, RPP_Q = kThreads / CQ;       // rows per pass
+  constexpr int WP = BP / 2, WQ = BQ / 2;
+  constexpr int FP = WP / 16, FQ = WQ / 16;
+  constexpr int BUF = BK * (RSP + RSQ);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wp = wave >> 1, wq = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid, split;
+  if (p.splits > 1 && (p.splits & 7) == 0) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    bid = slot % nwg;
+    split = (slot / nwg) * 8 + xcd;
+  } else {
+    bid = xcd_remap(blockIdx.x, nwg);
+    split = blockIdx.y;
+  }
+  const int tile_p = bid / p.tiles_n, tile_q = bid - tile_p * p.tiles_n;
+  const int p0 = tile_p * BP, q0 = tile_q * BQ;
+  const int z = blockIdx.z;
+  const char* Pb = p.P + (long long)z * p.p_bs * 2;
+  const char* Ab = p.A + (long long)z * p.a_bs * 2;
+  const int kbeg = split * p.kper;
+  const int kend = min(p.M, kbeg + p.kper);
+  const int ktiles = (kend - kbeg + BK - 1) / BK;
+
+  // ---- per-thread DMA assignment ---------------------------------------------------------------
+  const int pslot = tid % CP, prow = tid / CP;               // LDS slot (row, 16-byte slot) of the P tile
+  const int pc = (((pslot >> 1) ^ tr_key<RSP>(prow)) << 1) | (pslot & 1);   // global channel chunk
+  const int pch = p0 + pc * 8;
+  const bool pok = pch < p.Ncols;
+  const int qslot = tid % CQ, qrow0 = tid / CQ;
+  const int qc = (((qslot >> 1) ^ tr_key<RSQ>(qrow0)) << 1) | (qslot & 1);
+  const int kc = q0 / 8 + qc;                                 // global 16-byte chunk index along K
+  TapC qtap;
+  if (IDENT) { qtap.ok = kc * 8 < p.K; qtap.a = qtap.b = qtap.c = 0; qtap.ci = 0; }
+  else qtap = decode_tap<T, false>(p, kc);
+  QRow qcur[QI];
+  RowC jump;
+  if (!IDENT) {
+    jump = decode_row(p, BK);
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      const RowC r = decode_row(p, min(kbeg + qrow0 + RPP_Q * i, p.M - 1));
+      qcur[i].n = r.n; qcur[i].t = r.t; qcur[i].h = r.h; qcur[i].w = r.w;
+      qrow_refresh(p, qcur[i], qtap);
+    }
+  }
+
+  auto load_tile = [&](int kt, int buf) {
+    char* pt = smem + buf * BUF + wave_u * 1024;
+    char* qt = smem + buf * BUF + BK * RSP + wave_u * 1024;
+    const int kb = kbeg + kt * BK;
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+      const int k = kb + prow + RPP_P * i;
+      glds16(src_or_zero(Pb, ((long long)k * p.ldp + pch) * 2, pok && k < kend), pt + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      const int k = kb + qrow0 + RPP_Q * i;
+      const char* src;
+      if (IDENT) {
+        src = src_or_zero(Ab, ((long long)k * p.lda + (long long)kc * 8) * 2, qtap.ok && k < kend);
+      } else {
+        const int ws = qcur[i].w * p.sw - p.pw + qtap.c * p.dw;
+        const bool ok = qtap.ok && qcur[i].hv && k < kend && (unsigned)ws < (unsigned)p.Ws;
+        src = src_or_zero(Ab, ((qcur[i].base + ws) * p.lda + qtap.ci) * 2, ok);
+        qrow_jump(p, qcur[i], jump, qtap);
+      }
+      glds16(src, qt + i * 4096);
+    }
+  };
+
+  f32x4_v acc[FQ][FP];
+#pragma unroll
+  for (int a = 0; a < FQ; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  if (ktiles > 0) load_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + 1 < ktiles) load_tile(kt + 1, (kt + 1) & 1);
+    const char* pt = smem + (kt & 1) * BUF;
+    const char* qt = pt + BK * RSP;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_v pf[FP], qf[FQ];
+#pragma unroll
+      for (int i = 0; i < FP; ++i) pf[i] = tr_frag<RSP>(pt, wp * WP + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) qf[j] = tr_frag<RSQ>(qt, wq * WQ + j * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < FQ; ++j)
+#pragma unroll
+        for (int i = 0; i < FP; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[j][i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds qq = qb + 0..3 for output row pp (same as gemm_tn_kernel) ----------
+  const bool vec_ok = (p.ldo & 3) == 0;
+  const bool to_ws = p.splits > 1;
+#pragma unroll
+  for (int i = 0; i < FP; ++i) {
+    const int pp = p0 + wp * WP + i * 16 + l15;
+    if (pp >= p.Ncols) continue;
+    const float rs = (to_ws || !p.rowscale) ? 1.f : p.rowscale[pp];
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      const int qb = q0 + wq * WQ + j * 16 + g * 4;
+      if (qb >= p.K) continue;
+      const int cnt = (p.K - qb) < 4 ? (p.K - qb) : 4;
+      const long long idx = (long long)pp * p.ldo + qb;
+      float v[4];
+      if (to_ws) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r];
+        store4<float>(reinterpret_cast<char*>(p.ws),
+                      (long long)split * ((long long)p.Ncols * p.ldo) + idx, v, cnt, vec_ok);
+      } else {
+        char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[j][i][r] * p.alpha * rs;
+          if (p.accumulate && r < cnt) x += ld_elem<OutT>(Ob, idx + r);
+          v[r] = x;
+        }
+        store4<OutT>(Ob, idx, v, cnt, vec_ok);
+      }
+    }
+  }
+}
+
 template <typename OutT>
 __global__ void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale, long long n,
                                     int ldo, int splits, float alpha, int accumulate) {
@@ -821,6 +1003,7 @@ struct Plan {
   int bm, bn;     // tile (NT: m x n; TN: p x q)
   int splits;
   int rb;         // NT tile-row bytes (64 or 128)
+  int tn_tr;      // WGRAD: DMA + LDS transpose-read kernel (bf16, not the packed stem)
   dim3 grid;
   size_t lds;
   long long ws_elems;
@@ -885,6 +1068,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
 
   pl->splits = 1;
   pl->ws_elems = 0;
+  pl->tn_tr = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
     pl->bm = 128;
     pl->bn = d->Cn > 64 ? 128 : 64;
@@ -899,7 +1083,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
     // few output rows (res2 / stem, Cout = 64): widen the Q tile so a workgroup still has
     // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
-    if (pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
+    static const int env_tr = [] { const char* e = getenv("VLFB_TN_TR"); return e ? atoi(e) : 1; }();
+    pl->tn_tr = env_tr && d->dtype == VLFB_BF16 && !pl->packw && d->Cn % 8 == 0;
+    if (!pl->tn_tr && pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
     g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
     g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
     const int bk = 128 / es;
@@ -979,8 +1165,21 @@ void launch_tn(const Plan& pl, hipStream_t s) {
   else launch_k(gemm_tn_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
 }
 
+template <typename OutT, bool IDENT>
+void launch_tn_tr(const Plan& pl, hipStream_t s) {
+  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT>, pl, s);
+  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 64, 128, IDENT>, pl, s);
+  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<OutT, 128, 64, IDENT>, pl, s);
+  else launch_k(gemm_tn_tr_kernel<OutT, 64, 64, IDENT>, pl, s);
+}
+
 template <typename T, typename OutT>
 int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
+  if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn_tr) {
+    if (pl.ident) launch_tn_tr<OutT, true>(pl, s);
+    else launch_tn_tr<OutT, false>(pl, s);
+    return check_launch("conv wgrad (tr) kernel");
+  }
   if (d->mode == VLFB_CONV_WGRAD) {
     if (pl.ident) launch_tn<T, OutT, true, false>(pl, s);
     else if (pl.packw) launch_tn<T, OutT, false, true>(pl, s);

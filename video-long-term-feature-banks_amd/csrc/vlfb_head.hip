@@ -239,8 +239,15 @@ __global__ void fbo_attn_fwd_kernel(const T* __restrict__ theta, const T* __rest
   }
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < K; ++k) a += s[k] * Elem<T>::ld(gg + (long long)k * ld + d);
+    // 8 independent partial sums keep 8 loads in flight (the serial chain was latency-bound)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += s[k + u] * Elem<T>::ld(gg + (long long)(k + u) * ld + d);
+    }
+    float a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    for (; k < K; ++k) a += s[k] * Elem<T>::ld(gg + (long long)k * ld + d);
     Elem<T>::st(t + (long long)r * D + d, a);
   }
 }
@@ -275,8 +282,14 @@ __global__ void fbo_attn_bwd_kernel(const T* __restrict__ dt, const T* __restric
   for (int k = threadIdx.x; k < K; k += blockDim.x) ds[k] = scale * pr[k] * (ds[k] - dot);
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < K; ++k) a += ds[k] * Elem<T>::ld(ph + (long long)k * ld + d);
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += ds[k + u] * Elem<T>::ld(ph + (long long)(k + u) * ld + d);
+    }
+    float a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    for (; k < K; ++k) a += ds[k] * Elem<T>::ld(ph + (long long)k * ld + d);
     Elem<T>::st(dtheta + (long long)r * D + d, a);
   }
   const long long kd = (long long)K * D;
