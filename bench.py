@@ -113,8 +113,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1:
-            hip.PROFILE = []          # HIP-event brackets around every GEMM launch of the last timed step
+            # HIP-event brackets around every GEMM launch of the last timed step; that step runs
+            # single-stream so each bracket times its kernel alone (no overlap with the side stream)
+            hip.PROFILE = []
+            side, eng.side = eng.side, None
         eng.train_step(lr)
+    eng.side = side if args.steps > 0 else eng.side
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
