@@ -20,6 +20,10 @@ def rank():
 
 
 def local_rank():
+    """index of this process's GPU.  VLFB_FORCE_DEVICE pins every rank to one device (used by the
+    single-GPU multi-process test, which then has to run over gloo)."""
+    if "VLFB_FORCE_DEVICE" in os.environ:
+        return int(os.environ["VLFB_FORCE_DEVICE"])
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
@@ -30,7 +34,7 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("VLFB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local_rank())
     td.init_process_group(backend=backend)
