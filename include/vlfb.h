@@ -157,6 +157,19 @@ int vlfb_zero_f32(float* p, int64_t n, vlfb_stream_t stream);
 int vlfb_weight_prep(const float* w, const float* scale, void* w_fprop, void* w_dgrad, int dtype,
                      int64_t cout, int64_t taps, int64_t cin, vlfb_stream_t stream);
 
+/* The same for every convolution of the model in ONE launch.  `items_dev` is a device array sorted
+ * by tile_begin; item i owns tiles [tile_begin, tile_begin + taps*ceil(cout/32)*ceil(cin/32)). */
+typedef struct vlfb_wprep_item {
+  const void* w;        /* fp32 master [cout][taps][cin] */
+  const void* scale;    /* fp32 [cout] or NULL */
+  void* w_fprop;        /* dtype [cout][taps][cin] or NULL */
+  void* w_dgrad;        /* dtype [cin][taps][cout] or NULL */
+  int32_t cout, taps, cin;
+  int32_t tile_begin;
+} vlfb_wprep_item;
+int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_items, int total_tiles,
+                             int dtype, vlfb_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Pools (channels-last).  Replace Caffe2 MaxPool / AveragePool:
  * resnet_video.py:190,219; nonlocal_helper.py:49; head_helper.py:37,92,113; lfb_helper.py:112,124.
@@ -262,9 +275,11 @@ int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois, const
 int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,
                       int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
                       vlfb_stream_t stream);
+/* ds_ws: fp32 scratch of r*k elements (the softmax-input gradient handed from the per-row
+ * kernel to the chip-wide dphi/dg writer) */
 int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const void* g,
-                      const float* p, void* dtheta, void* dphi, void* dg, int dtype, int64_t r,
-                      int64_t k, int64_t d, int64_t ld, float scale, vlfb_stream_t stream);
+                      const float* p, void* dtheta, void* dphi, void* dg, float* ds_ws, int dtype,
+                      int64_t r, int64_t k, int64_t d, int64_t ld, float scale, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Solver.  Replaces WeightedSum + MomentumSGDUpdate(nesterov) per parameter

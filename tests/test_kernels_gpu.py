@@ -457,8 +457,9 @@ def test_fbo_attention_core(dtype):
     DTH = torch.empty(R, D, device=dev(), dtype=dtype)
     DPH = torch.empty(R, K, D, device=dev(), dtype=dtype)
     DG = torch.empty(R, K, D, device=dev(), dtype=dtype)
+    DSW = torch.empty(R, K, device=dev())
     hip.call("vlfb_fbo_attn_bwd", gp(dt, dtype), hip.ptr(TH), hip.ptr(PH), hip.ptr(G), hip.ptr(P),
-             hip.ptr(DTH), hip.ptr(DPH), hip.ptr(DG), code, R, K, D, D, scale)
+             hip.ptr(DTH), hip.ptr(DPH), hip.ptr(DG), hip.ptr(DSW), code, R, K, D, D, scale)
     assert rel_err(DTH.float(), gth) < TOL[dtype]
     assert rel_err(DPH.float(), gph) < TOL[dtype]
     assert rel_err(DG.float(), gg) < TOL[dtype]

@@ -255,7 +255,7 @@ template <typename T>
 __global__ void fbo_attn_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ theta,
                                     const T* __restrict__ phi, const T* __restrict__ g,
                                     const float* __restrict__ p, T* __restrict__ dtheta,
-                                    T* __restrict__ dphi, T* __restrict__ dg, int K, int D,
+                                    float* __restrict__ ds_out, int K, int D,
                                     long long ld, float scale) {
   extern __shared__ float sm[];  // [K] ds + 4
   float* ds = sm;
@@ -292,12 +292,31 @@ __global__ void fbo_attn_bwd_kernel(const T* __restrict__ dt, const T* __restric
     for (; k < K; ++k) a += ds[k] * Elem<T>::ld(ph + (long long)k * ld + d);
     Elem<T>::st(dtheta + (long long)r * D + d, a);
   }
-  const long long kd = (long long)K * D;
-  for (long long i = threadIdx.x; i < kd; i += blockDim.x) {
-    const int k = (int)(i / D);
-    const int d = (int)(i - (long long)k * D);
-    Elem<T>::st(dphi + ((long long)r * K + k) * ld + d, ds[k] * Elem<T>::ld(th + d));
-    Elem<T>::st(dg + ((long long)r * K + k) * ld + d, pr[k] * Elem<T>::ld(dtr + d));
+  // hand ds to the elementwise kernel (dphi / dg are written by the whole chip, not by R blocks)
+  for (int k = threadIdx.x; k < K; k += blockDim.x) ds_out[(long long)r * K + k] = ds[k];
+}
+// dphi[r][k][:] = ds[r][k] * theta[r][:],  dg[r][k][:] = p[r][k] * dt[r][:]  (16 bytes per lane)
+template <typename T>
+__global__ void fbo_attn_bwd_kv_kernel(const T* __restrict__ dt, const T* __restrict__ theta,
+                                       const float* __restrict__ p, const float* __restrict__ ds,
+                                       T* __restrict__ dphi, T* __restrict__ dg, long long R, int K,
+                                       int D, long long ld) {
+  constexpr int V = Vec16<T>::N;
+  const int dch = D / V;
+  const long long total = R * K * dch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int dc = (int)(i % dch);
+    const long long rk = i / dch;
+    const long long r = rk / K;
+    float th[V], dtv[V], a[V], b[V];
+    Vec16<T>::load(theta + r * D + dc * V, th);
+    Vec16<T>::load(dt + r * D + dc * V, dtv);
+    const float dsv = ds[rk], pv = p[rk];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { a[e] = dsv * th[e]; b[e] = pv * dtv[e]; }
+    Vec16<T>::store(dphi + rk * ld + dc * V, a);
+    Vec16<T>::store(dg + rk * ld + dc * V, b);
   }
 }
 
@@ -442,19 +461,24 @@ extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void*
   return check_launch("fbo_attn_fwd");
 }
 extern "C" int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const void* g,
-                                 const float* p, void* dtheta, void* dphi, void* dg, int dtype,
-                                 int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                                 const float* p, void* dtheta, void* dphi, void* dg, float* ds_ws,
+                                 int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
                                  vlfb_stream_t stream) {
-  VLFB_REQUIRE(dt && theta && phi && g && p && dtheta && dphi && dg && r > 0 && k > 0 && d > 0 && ld >= d,
+  VLFB_REQUIRE(dt && theta && phi && g && p && dtheta && dphi && dg && ds_ws && r > 0 && k > 0 && d > 0 && ld >= d,
                "fbo_attn_bwd: bad args");
   VLFB_REQUIRE(k <= 8192, "fbo_attn_bwd: bank too long for the LDS row buffer");
+  const int v = dtype == VLFB_F32 ? 4 : 8;
+  VLFB_REQUIRE(d % v == 0 && ld % v == 0, "fbo_attn_bwd: D and ld must be multiples of %d", v);
   size_t lds = (size_t)(k + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == VLFB_F32)
-    hipLaunchKernelGGL(fbo_attn_bwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)dt, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)dtheta, (float*)dphi, (float*)dg, (int)k, (int)d, (long long)ld, scale);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(fbo_attn_bwd_kernel<bf16_t>, dim3((unsigned)r), dim3(256), lds, s, (const bf16_t*)dt, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, p, (bf16_t*)dtheta, (bf16_t*)dphi, (bf16_t*)dg, (int)k, (int)d, (long long)ld, scale);
-  else return set_error(VLFB_ERR_ARG, "fbo_attn_bwd: bad dtype");
+  int grid2 = grid_for(r * k * (d / v), 256);
+  if (dtype == VLFB_F32) {
+    hipLaunchKernelGGL(fbo_attn_bwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)dt, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)dtheta, ds_ws, (int)k, (int)d, (long long)ld, scale);
+    hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<float>, dim3(grid2), dim3(256), 0, s, (const float*)dt, (const float*)theta, p, (const float*)ds_ws, (float*)dphi, (float*)dg, (long long)r, (int)k, (int)d, (long long)ld);
+  } else if (dtype == VLFB_BF16) {
+    hipLaunchKernelGGL(fbo_attn_bwd_kernel<bf16_t>, dim3((unsigned)r), dim3(256), lds, s, (const bf16_t*)dt, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, p, (bf16_t*)dtheta, ds_ws, (int)k, (int)d, (long long)ld, scale);
+    hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<bf16_t>, dim3(grid2), dim3(256), 0, s, (const bf16_t*)dt, (const bf16_t*)theta, p, (const float*)ds_ws, (bf16_t*)dphi, (bf16_t*)dg, (long long)r, (int)k, (int)d, (long long)ld);
+  } else return set_error(VLFB_ERR_ARG, "fbo_attn_bwd: bad dtype");
   return check_launch("fbo_attn_bwd");
 }
 

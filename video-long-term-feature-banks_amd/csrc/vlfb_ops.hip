@@ -131,6 +131,46 @@ __global__ void weight_prep_dgrad_kernel(const float* __restrict__ w, const floa
   }
 }
 
+// All convolutions of the model in ONE launch: blockIdx.x walks 32x32 (cout x cin) tiles of every
+// (layer, tap); the tile is read once (coalesced along cin) and written twice: fprop order
+// [cout][tap][cin] and dgrad order [cin][tap][cout] (transposed through LDS).
+template <typename T>
+__global__ void weight_prep_batched_kernel(const vlfb_wprep_item* __restrict__ items, int n_items) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_items - 1;          // last item whose first tile is <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const vlfb_wprep_item it = items[lo];
+  const int t = b - it.tile_begin;
+  const int tiles_ci = (it.cin + 31) >> 5, tiles_co = (it.cout + 31) >> 5;
+  const int ci0 = (t % tiles_ci) << 5;
+  const int co0 = ((t / tiles_ci) % tiles_co) << 5;
+  const int tap = t / (tiles_ci * tiles_co);
+  const float* w = reinterpret_cast<const float*>(it.w);
+  const float* scale = reinterpret_cast<const float*>(it.scale);
+  T* wf = reinterpret_cast<T*>(it.w_fprop);
+  T* wd = reinterpret_cast<T*>(it.w_dgrad);
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int co = co0 + j, ci = ci0 + threadIdx.x;
+    if (co < it.cout && ci < it.cin) {
+      const long long idx = ((long long)co * it.taps + tap) * it.cin + ci;
+      const float v = w[idx] * (scale ? scale[co] : 1.f);
+      tile[j][threadIdx.x] = v;
+      if (wf) Elem<T>::st(wf + idx, v);
+    }
+  }
+  if (!wd) return;
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int ci = ci0 + j, co = co0 + threadIdx.x;
+    if (co < it.cout && ci < it.cin)
+      Elem<T>::st(wd + ((long long)ci * it.taps + tap) * it.cout + co, tile[threadIdx.x][j]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pools (channels-last).  One thread = one position x one 16-byte channel chunk.
 // ---------------------------------------------------------------------------------------------
@@ -418,21 +458,38 @@ __global__ void add_kernel(const T* a, const T* b, T* y, const T* __restrict__ m
   }
 }
 
-// column sums with a (64 channels) x (row slab) block; fp32 atomics onto a tiny output.
+// column sums: block = 16-byte channel-chunk lanes x row lanes over one row slab; 16-byte loads,
+// LDS reduction over the row lanes, then one fp32 atomic per channel and slab.
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ g, long long rows, int cols, long long ld,
                               float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
-  const int c = blockIdx.x * 64 + cl;
+  constexpr int V = Vec16<T>::N;
+  constexpr int CL = 8;                 // chunk lanes (8 * V channels per block)
+  constexpr int RL = 256 / CL;          // row lanes
+  __shared__ float red[RL][CL * 8 + 1];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c0 = (blockIdx.x * CL + cl) * V;
   const long long per = (rows + gridDim.y - 1) / gridDim.y;
   const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
-  float acc = 0.f;
-  if (c < cols)
-    for (long long r = r0 + rl; r < r1; r += 4) acc += Elem<T>::ld(g + r * ld + c);
-  red[rl][cl] = acc;
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  if (c0 < cols) {
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      float v[V];
+      Vec16<T>::load(g + r * ld + c0, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[rl][cl * 8 + k] = acc[k];
   __syncthreads();
-  if (rl == 0 && c < cols) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  if (rl < V && c0 < cols) {            // row lane k sums channel k of this chunk
+    float sum = 0.f;
+    for (int j = 0; j < RL; ++j) sum += red[j][cl * 8 + rl];
+    atomicAdd(out + c0 + rl, sum);
+  }
 }
 
 // strided 2-D copy (Concat along channels and its backward): dst[r*ldd + c] = src[r*lds + c]
@@ -702,9 +759,14 @@ extern "C" int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols,
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate)
     hipLaunchKernelGGL(zero_kernel, dim3(grid_for(cols, 256)), dim3(256), 0, s, out, (long long)cols);
-  int slabs = (int)((rows + 255) / 256);
-  if (slabs > 256) slabs = 256;
-  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)slabs);
+  const int v = dtype == VLFB_F32 ? 4 : 8;
+  VLFB_REQUIRE(cols % v == 0 && ld % v == 0, "colsum: cols and ld must be multiples of %d", v);
+  const int cblocks = (int)((cols / v + 7) / 8);
+  int slabs = (int)((rows + 1023) / 1024);
+  const int want = (2048 + cblocks - 1) / cblocks;
+  if (slabs > want) slabs = want;
+  if (slabs < 1) slabs = 1;
+  dim3 grid((unsigned)cblocks, (unsigned)slabs);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)g, (long long)rows, (int)cols, (long long)ld, out);
   else if (dtype == VLFB_BF16)
@@ -729,4 +791,16 @@ extern "C" int vlfb_zero_f32(float* p, int64_t n, vlfb_stream_t stream) {
   if (n == 0) return VLFB_OK;
   hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, (long long)n);
   return check_launch("zero_f32");
+}
+
+extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_items, int total_tiles,
+                                        int dtype, vlfb_stream_t stream) {
+  VLFB_REQUIRE(items_dev && n_items > 0 && total_tiles > 0, "weight_prep_batched: bad args");
+  dim3 block(32, 8);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<float>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<bf16_t>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
+  return check_launch("weight_prep_batched");
 }

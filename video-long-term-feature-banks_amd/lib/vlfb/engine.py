@@ -234,8 +234,14 @@ class ConvStep(Step):
         s = eng.param_tensor(self.sname) if self.sname else None
         hip.call("vlfb_weight_prep", hip.ptr(w), hip.ptr(s), hip.ptr(self.w_f), hip.ptr(self.w_d),
                  eng.code, Cout, self.taps(), self.Cin_k)
+        self.refresh_bias()
+
+    def refresh_bias(self):
+        eng = self.eng
         if self.eff_bias is not None:   # s*cb + b
-            hip.call("vlfb_affine_nd_fwd", hip.ptr(eng.param_tensor(self.cbname)), hip.ptr(s),
+            Cout = self.out.shape[1]
+            hip.call("vlfb_affine_nd_fwd", hip.ptr(eng.param_tensor(self.cbname)),
+                     hip.ptr(eng.param_tensor(self.sname)),
                      hip.ptr(eng.param_tensor(self.bname)), hip.ptr(self.eff_bias), 1, Cout, 1)
 
     def bias_tensor(self):
@@ -345,6 +351,7 @@ class AttentionStep(Step):
         code = eng.code
         self.single = (L1 == 1)
         if self.single:
+            self.ds_ws = torch.empty(B * L2, device=eng.device, dtype=torch.float32)
             return
         gemm = lambda **kw: hip.conv_desc(mode=hip.FPROP, dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
                                           Ws=L1, batch=B, **kw)
@@ -384,8 +391,8 @@ class AttentionStep(Step):
                 s._flags()
                 s.cur = s.buf
             hip.call("vlfb_fbo_attn_bwd", hip.ptr(dY), self.theta.ptr(), self.phi.ptr(), self.g.ptr(),
-                     self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), eng.code, B, L2, Ci,
-                     Ci, self.scale)
+                     self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), hip.ptr(self.ds_ws),
+                     eng.code, B, L2, Ci, Ci, self.scale)
             return
         dP = eng.scratch_f32(B * L1 * L2)
         hip.conv_run(self.d_dp, dY, self.g.storage(), None, dP)
@@ -1316,10 +1323,43 @@ class Engine(object):
         off, cnt, shape = self.train_layout[name]
         return self._from_kernel_layout(name, self.flat_mom[off:off + cnt].view(shape))
 
+    def _build_wprep_tables(self):
+        """device tables for vlfb_weight_prep_batched: all convs / only those with trainable weights"""
+        import ctypes as C_
+        self._wprep = {}
+        for key in ("all", "trainable"):
+            items, tile = [], 0
+            for st in self.steps:
+                if not isinstance(st, ConvStep) or (key == "trainable" and not self.is_trainable(st.wname)):
+                    continue
+                cout, taps, cin = st.out.shape[1], st.taps(), st.Cin_k
+                it = hip.WPrepItem()
+                it.w = hip.ptr(self.param_tensor(st.wname))
+                it.scale = hip.ptr(self.param_tensor(st.sname)) if st.sname else None
+                it.w_fprop = hip.ptr(st.w_f)
+                it.w_dgrad = hip.ptr(st.w_d) if st.w_d is not None else None
+                it.cout, it.taps, it.cin, it.tile_begin = cout, taps, cin, tile
+                tile += taps * ((cout + 31) // 32) * ((cin + 31) // 32)
+                items.append(it)
+            if not items:
+                self._wprep[key] = None
+                continue
+            arr = (hip.WPrepItem * len(items))(*items)
+            raw = bytes(memoryview(arr))
+            dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._wprep[key] = (dev, len(items), tile)
+
     def refresh_operands(self, all_params=False):
+        """rebuild the MFMA operand copies (one batched launch) and the effective biases"""
+        if getattr(self, "_wprep", None) is None:
+            self._build_wprep_tables()
+        tab = self._wprep["all" if all_params else "trainable"]
+        if tab is not None:
+            dev, n, tiles = tab
+            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.code)
         for st in self.steps:
-            if isinstance(st, ConvStep) and (all_params or st.params):
-                st.refresh()
+            if isinstance(st, ConvStep) and st.eff_bias is not None and (all_params or st.params):
+                st.refresh_bias()
 
     # ---- data ---------------------------------------------------------------------------------
     def feed(self, name, arr):

@@ -52,6 +52,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WPrepItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("w_fprop", C.c_void_p), ("w_dgrad", C.c_void_p),
+                ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32), ("tile_begin", C.c_int32)]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
@@ -76,6 +81,7 @@ _SIGS = {
     "vlfb_copy2d": (C.c_int, [_P, _I64, _P, _I64, C.c_int, _I64, _I64, _P]),
     "vlfb_zero_f32": (C.c_int, [_P, _I64, _P]),
     "vlfb_weight_prep": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _P]),
+    "vlfb_weight_prep_batched": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vlfb_maxpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "vlfb_maxpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P, _P]),
     "vlfb_avgpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
@@ -98,7 +104,7 @@ _SIGS = {
     "vlfb_roi_align_max_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
                                          C.c_int, C.c_float, _P]),
     "vlfb_fbo_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
-    "vlfb_fbo_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64,
+    "vlfb_fbo_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64,
                                     C.c_float, _P]),
     "vlfb_sgd_update": (C.c_int, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
     "vlfb_scale_inplace": (C.c_int, [_P, _I64, C.c_float, _P]),
