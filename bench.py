@@ -131,15 +131,23 @@ def main():
     loss = float(eng.fetch("loss").reshape(-1)[0])
 
     # ---- live roofline of the GEMM kernel families (this rank) -----------------------------------
-    fam = {"nt": [0.0, 0.0, 0], "tn": [0.0, 0.0, 0]}
+    fam = {"nt": [0.0, 0.0, 0, 0.0], "tn": [0.0, 0.0, 0, 0.0]}
     rows = []
-    for mode, flops, e0, e1, tag in prof or []:
+    for mode, flops, e0, e1, tag, nbytes in prof or []:
         f = fam["tn" if mode == hip.WGRAD else "nt"]
         sec = e0.elapsed_time(e1) * 1e-3
         f[0] += flops
         f[1] += sec
         f[2] += 1
+        f[3] += nbytes
         rows.append((sec, flops, tag))
+    # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_hbm_traffic.txt): rocprofv3
+    # cannot run inside this process, so the counters of the SAME command are read from the profile
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if args.workload == "ava_r50_lfb_nl" and args.dtype == "bf16" and clips == 8 and os.path.exists(tpath):
+        t = json.load(open(tpath))
+        traffic = {"nt": t["gemm_nt"]["bytes_per_launch"], "tn": t["gemm_tn"]["bytes_per_launch"]}
     if args.detail and rank == 0:
         with open(args.detail, "w") as fh:
             agg = collections.OrderedDict()
@@ -152,10 +160,12 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
 
     def roof(key, kernel):
-        fl, sec, n = fam[key]
+        fl, sec, n, nb = fam[key]
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n,
+                "frac": round(ach / peak, 4), "traffic": traffic.get(key),
+                "algorithmic_bytes_per_launch": round(nb / max(n, 1)),
+                "algorithmic_GBps": round(nb / sec / 1e9, 1) if sec > 0 else 0.0, "launches_per_step": n,
                 "avg_launch_us": round(sec / max(n, 1) * 1e6, 2), "gflop_per_step": round(fl / 1e9, 1),
                 "ms_per_step": round(sec * 1e3, 3)}
 

@@ -180,13 +180,15 @@ typedef struct vlfb_pool_desc {
   int32_t To, Ho, Wo;
   int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
 } vlfb_pool_desc;
-/* y[N,To,Ho,Wo,C]; argmax (uint8 tap index inside the window, first maximum in t,h,w scan
- * order) may be NULL in inference. */
-int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, uint8_t* argmax,
+/* bytes per arg-max element: 1 (window <= 255 taps) or 2 (the FBO-max head pools 300 bank rows) */
+int vlfb_pool_argmax_bytes(const vlfb_pool_desc* d);
+/* y[N,To,Ho,Wo,C]; argmax (tap index inside the window, first maximum in t,h,w scan order; element
+ * size = vlfb_pool_argmax_bytes) may be NULL in inference. */
+int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, void* argmax,
                      vlfb_stream_t stream);
 /* dx = (accumulate ? add : 0) + scatter(dy) ; then dx = (mask > 0) ? dx : 0 when mask != NULL.
  * `add` may alias dx. Gather formulation: deterministic, no atomics. */
-int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const uint8_t* argmax, void* dx,
+int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax, void* dx,
                      const void* add, const void* mask, vlfb_stream_t stream);
 /* average over the window (pad 0 only, as every AveragePool in the reference) */
 int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream);

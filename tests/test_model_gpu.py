@@ -109,6 +109,25 @@ def test_forward_backward_matches_oracle(preset, dtype):
         assert p90 < 0.15 and worst[0][1] < 0.35, (p90, worst)
 
 
+@pytest.mark.parametrize("preset", ["charades_r50_lfb_avg", "ava_r50_lfb_max", "ava_r101_lfb_nl_3l"])
+def test_other_heads_and_depths_match_oracle_fp32(preset):
+    """FBO-avg / FBO-max heads (lfb_helper.py:106-127) and the R101 / 3-layer FBO-NL variant"""
+    from oracle import model as om
+    cfg, model, eng, inputs, params, seed_fn = build(preset, "fp32")
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    for name in ("pool5", "prob"):
+        got = eng.fetch(name)
+        assert rel(got, blobs[name].detach().numpy().reshape(got.shape)) < 1e-3, name
+    assert abs(float(eng.fetch("loss").reshape(-1)[0]) - float(blobs["loss"])) < 1e-3 * abs(float(blobs["loss"]))
+    assert set(grads) == set(eng.trainable)
+    gmax = max(float(g.norm()) for g in grads.values())
+    errs = [rel(eng.fetch_grad(n), grads[n].numpy()) for n in eng.trainable if float(grads[n].norm()) > 1e-9 * gmax]
+    assert np.median(errs) < 1e-3 and max(errs) < 5e-3, (np.median(errs), max(errs))
+
+
 def test_roi_head_integer_decisions_are_bit_exact():
     """RoIAlign batch index / sampling grid / bilinear corners inside the full AVA model"""
     from oracle import model as om

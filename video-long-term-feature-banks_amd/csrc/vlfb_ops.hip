@@ -179,9 +179,9 @@ struct PoolP {
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
 };
 
-template <typename T>
+template <typename T, typename IdxT>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                   uint8_t* __restrict__ argmax, PoolP p) {
+                                   IdxT* __restrict__ argmax, PoolP p) {
   constexpr int V = Vec16<T>::N;
   const int cchunks = p.C / V;
   const long long total = (long long)p.N * p.To * p.Ho * p.Wo * cchunks;
@@ -216,8 +216,12 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
       }
     }
     Vec16<T>::store(y + o * p.C + cc * V, best);
-    if (argmax) {
-      uint8_t* am = argmax + o * p.C + cc * V;
+    if (argmax && sizeof(IdxT) == 2) {
+      IdxT* am = argmax + o * p.C + cc * V;
+#pragma unroll
+      for (int k = 0; k < V; ++k) am[k] = (IdxT)arg[k];
+    } else if (argmax) {
+      uint8_t* am = reinterpret_cast<uint8_t*>(argmax) + o * p.C + cc * V;
       if (V == 8) {
         uint2 pk;
         pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
@@ -232,8 +236,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 
 // gather formulation of the pool backward: every input position sums the output gradients
 // of the windows that (a) cover it and (b) for max pooling selected it.
-template <typename T, bool IS_MAX>
-__global__ void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
+template <typename T, bool IS_MAX, typename IdxT>
+__global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict__ argmax,
                                 T* dx, const T* add, const T* __restrict__ mask, PoolP p,
                                 float inv_window) {
   constexpr int V = Vec16<T>::N;
@@ -266,9 +270,15 @@ __global__ void pool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restr
           const long long o = (((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
           float g[V];
           Vec16<T>::load(dy + o * p.C + cc * V, g);
-          if (IS_MAX) {
+          if (IS_MAX && sizeof(IdxT) == 2) {
             const int tap = (a * p.kh + b) * p.kw + c;
-            const uint8_t* am = argmax + o * p.C + cc * V;
+            const IdxT* am = argmax + o * p.C + cc * V;
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+              if ((int)am[k] == tap) acc[k] += g[k];
+          } else if (IS_MAX) {
+            const int tap = (a * p.kh + b) * p.kw + c;
+            const uint8_t* am = reinterpret_cast<const uint8_t*>(argmax) + o * p.C + cc * V;
             uint32_t w0 = *reinterpret_cast<const uint32_t*>(am);
             uint32_t w1 = V == 8 ? *reinterpret_cast<const uint32_t*>(am + 4) : 0u;
 #pragma unroll
@@ -522,7 +532,7 @@ int check_pool(const vlfb_pool_desc* d) {
   VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "pool: bad dtype");
   const int v = d->dtype == VLFB_F32 ? 4 : 8;
   VLFB_REQUIRE(d->C % v == 0, "pool: C=%d must be a multiple of %d", d->C, v);
-  VLFB_REQUIRE(d->kt * d->kh * d->kw <= 255, "pool: window too large for uint8 argmax");
+  VLFB_REQUIRE(d->kt * d->kh * d->kw <= 65535, "pool: window too large for a 16-bit argmax");
   VLFB_REQUIRE(d->N > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0, "pool: empty output");
   return VLFB_OK;
 }
@@ -639,32 +649,47 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
   return check_launch("weight_prep");
 }
 
-extern "C" int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, uint8_t* argmax,
+extern "C" int vlfb_pool_argmax_bytes(const vlfb_pool_desc* d) {
+  return d->kt * d->kh * d->kw <= 255 ? 1 : 2;
+}
+extern "C" int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, void* argmax,
                                 vlfb_stream_t stream) {
   int rc = check_pool(d);
   if (rc) return rc;
   VLFB_REQUIRE(x && y, "maxpool_fwd: null pointer");
   PoolP p = to_poolp(d);
   const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  const bool wide = vlfb_pool_argmax_bytes(d) == 2;
   int grid = grid_for((long long)p.N * p.To * p.Ho * p.Wo * (p.C / v), 256);
-  if (d->dtype == VLFB_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, argmax, p);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == VLFB_F32 && !wide)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float, uint8_t>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, (uint8_t*)argmax, p);
+  else if (d->dtype == VLFB_F32)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, (uint16_t*)argmax, p);
+  else if (!wide)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, uint8_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (uint8_t*)argmax, p);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, argmax, p);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, uint16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (uint16_t*)argmax, p);
   return check_launch("maxpool_fwd");
 }
-extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const uint8_t* argmax,
+extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax,
                                 void* dx, const void* add, const void* mask, vlfb_stream_t stream) {
   int rc = check_pool(d);
   if (rc) return rc;
   VLFB_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
   PoolP p = to_poolp(d);
   const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  const bool wide = vlfb_pool_argmax_bytes(d) == 2;
   int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
-  if (d->dtype == VLFB_F32)
-    hipLaunchKernelGGL((pool_bwd_kernel<float, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, argmax, (float*)dx, (const float*)add, (const float*)mask, p, 1.f);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == VLFB_F32 && !wide)
+    hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint8_t*)argmax, (float*)dx, (const float*)add, (const float*)mask, p, 1.f);
+  else if (d->dtype == VLFB_F32)
+    hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint16_t*)argmax, (float*)dx, (const float*)add, (const float*)mask, p, 1.f);
+  else if (!wide)
+    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const uint8_t*)argmax, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, 1.f);
   else
-    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, argmax, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, 1.f);
+    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const uint16_t*)argmax, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, 1.f);
   return check_launch("maxpool_bwd");
 }
 extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream) {
@@ -703,9 +728,9 @@ extern "C" int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* d
   const float inv = 1.0f / (float)(p.kt * p.kh * p.kw);
   int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
   if (d->dtype == VLFB_F32)
-    hipLaunchKernelGGL((pool_bwd_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const uint8_t*)nullptr, (float*)dx, (const float*)add, (const float*)mask, p, inv);
+    hipLaunchKernelGGL((pool_bwd_kernel<float, false, uint8_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const uint8_t*)nullptr, (float*)dx, (const float*)add, (const float*)mask, p, inv);
   else
-    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const uint8_t*)nullptr, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, inv);
+    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false, uint8_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const uint8_t*)nullptr, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, inv);
   return check_launch("avgpool_bwd");
 }
 

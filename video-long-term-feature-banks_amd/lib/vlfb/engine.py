@@ -310,7 +310,8 @@ class PoolStep(Step):
         self.desc = hip.pool_desc(eng.code, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
         self.argmax = None
         if self.is_max and eng.train:
-            self.argmax = torch.empty(self.out.numel, device=eng.device, dtype=torch.uint8)
+            nbytes = hip.lib().vlfb_pool_argmax_bytes(C.byref(self.desc))
+            self.argmax = torch.empty(self.out.numel * nbytes, device=eng.device, dtype=torch.uint8)
 
     def fwd(self):
         if self.is_max:

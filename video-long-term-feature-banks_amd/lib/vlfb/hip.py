@@ -82,6 +82,7 @@ _SIGS = {
     "vlfb_zero_f32": (C.c_int, [_P, _I64, _P]),
     "vlfb_weight_prep": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_weight_prep_batched": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "vlfb_pool_argmax_bytes": (C.c_int, [C.POINTER(PoolDesc)]),
     "vlfb_maxpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "vlfb_maxpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P, _P]),
     "vlfb_avgpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
@@ -184,6 +185,21 @@ def conv_flops(d):
     return 2.0 * d.N * d.Tr * d.Hr * d.Wr * d.Cn * taps * cin * batch
 
 
+def conv_bytes(d, has_r=False, has_mask=False):
+    """ALGORITHMIC HBM bytes of a launch: every operand read once, the output written once"""
+    es = 4 if d.dtype == F32 else 2
+    os_ = 4 if d.out_dtype == F32 else 2
+    batch = max(d.batch, 1)
+    taps = d.kt * d.kh * d.kw
+    k = d.kt * d.kh * d.pack_w * 4 if d.pack_w else taps * d.Cs
+    m = d.N * d.Tr * d.Hr * d.Wr
+    src = d.N * d.Ts * d.Hs * d.Ws * d.Cs * es
+    if d.mode == WGRAD:
+        return batch * (src + m * d.Cn * es + d.Cn * k * os_)
+    out = m * d.Cn
+    return batch * (src + d.Cn * k * es + out * os_ + (out * es if has_r else 0) + (out * es if has_mask else 0))
+
+
 def conv_tag(d):
     return "%s M=%d Cs=%d Cn=%d k%d%d%d s%d%d%d d%d b%d src%dx%dx%d" % (
         ("fprop", "dgrad", "wgrad")[d.mode], d.N * d.Tr * d.Hr * d.Wr, d.Cs, d.Cn, d.kt, d.kh, d.kw,
@@ -206,7 +222,7 @@ def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspa
                              ptr(R), ptr(mask), ptr(workspace), ws_bytes, stream())
     if prof is not None:
         e1.record()
-        prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d)))
+        prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d), conv_bytes(d, R is not None, mask is not None)))
     _check(rc, "vlfb_conv_run")
 
 

@@ -58,6 +58,16 @@ PRESETS = {
     "ava_r50_lfb_nl": [_COMMON, _AVA, {
         "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 60},
     }],
+    "charades_r50_lfb_avg": [_COMMON, _CHARADES, {
+        "MODEL": {"FREEZE_BACKBONE": True},
+        "TRAIN": {"PARAMS_FILE": ""},
+        "SOLVER": {"STEP_SIZES": [10000, 2000], "LRS": [1, 0.1], "MAX_ITER": 12000},
+        "LFB": {"ENABLED": True, "FBO_TYPE": "avg", "WRITE_LFB": True, "WINDOW_SIZE": 20},
+        "FBO_NL": {"PRE_ACT": False},
+    }],
+    "ava_r50_lfb_max": [_COMMON, _AVA, {
+        "LFB": {"ENABLED": True, "FBO_TYPE": "max", "WRITE_LFB": True, "WINDOW_SIZE": 60},
+    }],
     "ava_r101_lfb_nl_3l": [_COMMON, _AVA, {
         "MODEL": {"DEPTH": 101, "VIDEO_ARC_CHOICE": 4},
         "TRAIN": {"PARAMS_FILE": "pretrained_weights/r101_k400_pretrained.pkl"},
