@@ -128,6 +128,12 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
+    # host-side cost of enqueuing one step (untimed extra step): if this approaches ms_per_step the
+    # loop is launch-bound and wants HIP-graph capture
+    th0 = time.perf_counter()
+    eng.train_step(lr)
+    host_ms = (time.perf_counter() - th0) * 1e3
+    torch.cuda.synchronize()
     loss = float(eng.fetch("loss").reshape(-1)[0])
 
     # ---- live roofline of the GEMM kernel families (this rank) -----------------------------------
@@ -183,6 +189,7 @@ def main():
         ("roofline", roof("nt", "gemm_nt_kernel (implicit-GEMM conv fprop+dgrad, attention NT GEMMs)")),
         ("roofline_wgrad", roof("tn", "gemm_tn_kernel (implicit-GEMM conv wgrad, attention TN GEMMs)")),
         ("model_flops_utilisation", round(value * FWD_BWD_GFLOP_PER_CLIP / 1e3 / (world * peak), 4)),
+        ("host_enqueue_ms_per_step", round(host_ms, 2)),
     ])
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -78,7 +78,9 @@ int vlfb_affine_nd_bwd(const float* dy, const float* scale, float* dx,
  *              vlfb_conv_wgrad_reduce must follow (vlfb_conv_run does it when it is given
  *              a workspace).
  * pack_w:      stem mode (conv1, Cs = 4 padded RGB): the kw taps are packed with the channel
- *              dim into the contiguous K axis, K = kt*kh*(kw_pad*Cs); requires dw == 1.
+ *              dim into the contiguous K axis, K = kt*kh*(kw_pad*Cs); requires dw == 1 and an
+ *              input whose W rows are zero-padded (vlfb_ncthw_to_nthwc_wpad) so that
+ *              w*sw - pw + [0, kw_pad) is always inside [0, Ws).
  * epilogue (FPROP/DGRAD): v = alpha*acc + bias + R[m][n]; relu; then v = (Mask[m][n] > 0) ? v : 0
  * epilogue (WGRAD):       v = alpha * rowscale[p] * acc (+ O if accumulate)
  * ------------------------------------------------------------------------------------------ */
@@ -135,6 +137,12 @@ int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void* B, const v
  * to c_pad (zeros) in `dtype`. */
 int vlfb_ncthw_to_nthwc(const float* src, void* dst, int dtype, int64_t n, int64_t c, int64_t thw,
                         int64_t c_pad, vlfb_stream_t stream);
+/* The stem's input format: as above with `wpad_left` / (w_total - wpad_left - w) zero pixels on the
+ * two sides of every W row, [N][rows = T*H][w_total][c_pad].  With it the packed conv1 kernels
+ * (pack_w) never test w bounds; pass Ws = w_total and pw = pad_w - wpad_left in the conv desc. */
+int vlfb_ncthw_to_nthwc_wpad(const float* src, void* dst, int dtype, int64_t n, int64_t c, int64_t rows,
+                             int64_t w, int64_t c_pad, int64_t wpad_left, int64_t w_total,
+                             vlfb_stream_t stream);
 /* NTHWC `dtype` -> fp32 NCTHW (for FetchBlob of activations / gradients) */
 int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64_t n, int64_t c, int64_t thw,
                         vlfb_stream_t stream);

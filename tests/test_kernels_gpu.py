@@ -173,16 +173,22 @@ def test_conv_stem_packed(dtype):
     xd = x.double().requires_grad_(True)
     wd = w.double().requires_grad_(True)
     y_ref = F.conv3d(xd, wd, None, s, p, d)
-    # NTHWC with C padded to 4 via the library's own mover
-    X4 = torch.empty(N, T, H, W, 4, device=dev(), dtype=dtype)
-    hip.call("vlfb_ncthw_to_nthwc", gp(x), hip.ptr(X4), code, N, 3, T * H * W, 4)
-    assert torch.equal(X4[..., :3].float().cpu(), to_nthwc(x)) and float(X4[..., 3].abs().max()) == 0.0
+    # [N][T][H][W + 8][4]: C padded 3 -> 4 and 4 zero pixels on both sides of every row, via the
+    # library's own mover (the packed stem kernels rely on that padding instead of w-bounds tests)
+    WP = W + 8
+    X4 = torch.empty(N, T, H, WP, 4, device=dev(), dtype=dtype)
+    hip.call("vlfb_ncthw_to_nthwc_wpad", gp(x), hip.ptr(X4), code, N, 3, T * H, W, 4, 4, WP)
+    assert torch.equal(X4[:, :, :, 4:4 + W, :3].float().cpu(), to_nthwc(x))
+    assert float(X4[..., 3].abs().max()) == 0.0 and float(X4[:, :, :, :4].abs().max()) == 0.0 \
+        and float(X4[:, :, :, 4 + W:].abs().max()) == 0.0
     wp = torch.zeros(Cout, 5, 7, 8, 4)
     wp[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
     Bw = gpu(wp, dtype)
     O = torch.empty(N, To, Ho, Wo, Cout, device=dev(), dtype=dtype)
+    gk = geom_kwargs(k, s, p, d)
+    gk["pw"] = p[2] - 4
     desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo,
-                         Ts=T, Hs=H, Ws=W, Cs=4, Cn=Cout, pack_w=8, **geom_kwargs(k, s, p, d))
+                         Ts=T, Hs=H, Ws=WP, Cs=4, Cn=Cout, pack_w=8, **gk)
     hip.conv_run(desc, X4, Bw, None, O)
     assert rel_err(to_ncthw(O.float()), y_ref) < TOL[dtype]
     # wgrad in the packed layout
@@ -191,7 +197,7 @@ def test_conv_stem_packed(dtype):
     G = gpu(to_nthwc(dy), dtype)
     DW = torch.empty(Cout, 5, 7, 8, 4, device=dev(), dtype=torch.float32)
     desc = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo,
-                         Ts=T, Hs=H, Ws=W, Cs=4, Cn=Cout, pack_w=8, **geom_kwargs(k, s, p, d))
+                         Ts=T, Hs=H, Ws=WP, Cs=4, Cn=Cout, pack_w=8, **gk)
     ws = torch.empty(max(hip.conv_workspace_bytes(desc), 16) // 4, device=dev(), dtype=torch.float32)
     hip.conv_run(desc, X4, None, G, DW, workspace=ws)
     got = DW[:, :, :, :7, :3].permute(0, 4, 1, 2, 3)

@@ -53,6 +53,7 @@ struct GP {
   int tiles_m, tiles_n;
   int splits, kper;
   int vec_epi;        // NT: LDS-staged, fully coalesced epilogue is legal for this problem
+  int epi;            // NT: the fp32 tile is staged through LDS in this many passes (1 or 2)
 };
 
 struct RowC { int n, t, h, w; };
@@ -167,6 +168,20 @@ __device__ __forceinline__ const char* act_chunk_ptr(const GP& p, const char* ba
   return src_or_zero(base, off * (long long)sizeof(T), ok && m_ok && t.ok);
 }
 
+// Packed stem (conv1): the input is [N][T][H][W + 2*4][4] (RGB0 pixels, 4 zero pixels on both sides
+// of every row, written by vlfb_ncthw_to_nthwc_wpad), so a 16-byte chunk = 2 bf16 / 1 fp32 pixel(s)
+// of the (kw, c) run is always inside the row: only t / h padding needs the zero page.
+template <typename T>
+__device__ __forceinline__ const char* packw_chunk_ptr(const GP& p, const char* base, bool m_ok,
+                                                       const RowC& r, const TapC& t) {
+  const int ts = r.t * p.st - p.pt + t.a * p.dt;
+  const int hs = r.h * p.sh - p.ph + t.b * p.dh;
+  const bool ok = m_ok && t.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+  const int w0 = r.w * p.sw - p.pw + t.c;            // pw already includes the left padding
+  const long long pix = ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws) + w0;
+  return src_or_zero(base, pix * 4 * (long long)sizeof(T), ok);
+}
+
 // One gathered 16-byte chunk of the activation operand (branch-free).
 template <typename T, bool IDENT, bool DGRAD, bool PACKW>
 __device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, int m, bool m_ok,
@@ -175,18 +190,7 @@ __device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, i
   if (IDENT) {
     return ld16_if(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T), m_ok && t.ok);
   } else if (PACKW) {
-    const int ts = r.t * p.st - p.pt + t.a * p.dt;
-    const int hs = r.h * p.sh - p.ph + t.b * p.dh;
-    const bool ok = m_ok && t.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
-    const int w0 = r.w * p.sw - p.pw + t.c;
-    const long long rowoff = ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws) * 4;
-    if (sizeof(T) == 4) {  // one pixel (4 ch) per chunk
-      return ld16_if(base, (rowoff + (long long)w0 * 4) * 4, ok && (unsigned)w0 < (unsigned)p.Ws);
-    } else {  // two pixels per chunk, 8 bytes each
-      const uint2 lo = ld8_if(base, (rowoff + (long long)w0 * 4) * 2, ok && (unsigned)w0 < (unsigned)p.Ws);
-      const uint2 hi = ld8_if(base, (rowoff + (long long)(w0 + 1) * 4) * 2, ok && (unsigned)(w0 + 1) < (unsigned)p.Ws);
-      return make_uint4(lo.x, lo.y, hi.x, hi.y);
-    }
+    return *reinterpret_cast<const uint4*>(packw_chunk_ptr<T>(p, base, m_ok, r, t));
   } else {
     bool ok;
     const long long off = src_offset<DGRAD>(p, r, t, ok);
@@ -279,6 +283,22 @@ __device__ __forceinline__ void load_elems(const T* p, float (&v)[N]) {
   }
 }
 
+// the same from a 16-byte register image (prefetched epilogue operands; only N*sizeof(T) == 16)
+template <typename T, int N>
+__device__ __forceinline__ void unpack_elems(const uint4& t, float (&v)[N]) {
+  if (sizeof(T) == 4) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
+    v[2 % N] = __uint_as_float(t.z); v[3 % N] = __uint_as_float(t.w);
+  } else {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[(2 * i) % N] = __uint_as_float(w[i] << 16);
+      v[(2 * i + 1) % N] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+}
+
 // XCD-aware remap of a linear workgroup id: consecutive ids on one XCD share operand panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;
@@ -291,7 +311,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // =============================================================================================
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
 // =============================================================================================
-template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB>
+template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE>
 __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CPRW = RB / 16;            // 16-byte chunks per tile row
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   // GLDS (everything but the packed stem): the global->LDS copy is asynchronous DMA
   // (global_load_lds_dwordx4, no VGPR round trip); a wave's 64 slots are 1 KiB contiguous, and
   // because the LDS image is XOR-swizzled the lane fetches global chunk (slot ^ (row & 7)).
-  constexpr bool GLDS = !PACKW;
+  constexpr bool GLDS = true;
   const int cc = tid % CPRW;
   const int r0 = tid / CPRW;
   const int ccg = GLDS ? (cc ^ swz_key<RB>(r0)) : cc;   // global 16-byte chunk column fetched by this lane
@@ -350,7 +370,9 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
       char* wb = smem + buf * BUF + BM * RB + wave_u * 1024;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        glds16(act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc), xa + i * 4096);
+        glds16(PACKW ? packw_chunk_ptr<T>(p, Ab, aok[i], arow[i], tap)
+                     : act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc),
+               xa + i * 4096);
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int n = n0 + r0 + RPPS * i;
@@ -388,6 +410,30 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
 #pragma unroll
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 
+  // ---- epilogue operands (same for every path) ---------------------------------------------------
+  char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
+  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
+  const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
+  constexpr int EPT = 16 / (int)sizeof(OutT);   // output elements per 16-byte store
+  constexpr int TPR = BN / EPT;                 // lanes per tile row
+  constexpr int RPP = kThreads / TPR;           // rows per pass
+  constexpr int NPASS = BM / RPP;
+  const int tc = tid % TPR, tr = tid / TPR;
+  const int ncol = n0 + tc * EPT;
+  // PRE: thin-K launches are epilogue (HBM) bound, so the residual / mask rows of this lane are
+  // requested BEFORE the k-loop and arrive while the MFMAs run.
+  uint4 rpre[PRE ? NPASS : 1], mpre[PRE ? NPASS : 1];
+  if (PRE) {
+#pragma unroll
+    for (int gp = 0; gp < NPASS; ++gp) {
+      const int m = m0 + gp * RPP + tr;
+      const bool ok = m < p.M && ncol < p.Ncols;
+      const long long off = ((long long)m * p.ldr + ncol) * (long long)sizeof(T);
+      rpre[gp] = ld16_if(Rb ? Rb : Ab, off, ok && Rb != nullptr);
+      mpre[gp] = ld16_if(Mb ? Mb : Ab, off, ok && Mb != nullptr);
+    }
+  }
+
   load_tile(0, 0);
   store_tile(0);
   tile_ready();
@@ -414,31 +460,20 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------
-  char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
-  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
-  const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
-  constexpr int EPT = 16 / (int)sizeof(OutT);   // output elements per 16-byte store
   if (p.vec_epi) {
     // Coalesced path: the fp32 accumulator tile goes through LDS (16-byte chunks XOR-swizzled by
     // row & 7, conflict-free for both the fragment-shaped writes and the row-shaped reads), then
     // every lane handles EPT consecutive columns of one row: residual / mask are read and the
     // result is written with full 16-byte accesses, whole rows of the tile per wavefront.
+    // The tile is staged in one pass when it fits the LDS of this launch, else in two halves
+    // (rows of wave-row 0, then of wave-row 1): p.epi is 1 or 2.
     constexpr int CPR = BN / 4;          // 16-byte fp32 chunks per tile row
-    // the fp32 tile is staged in ONE pass when it fits the operand buffers, else in two halves
-    // (rows of wave-row 0, then of wave-row 1)
-    constexpr int EPI = (BM * BN * 4 > 2 * BUF) ? 2 : 1;
-    constexpr int EROWS = BM / EPI;
-    constexpr int TPR = BN / EPT;        // lanes per tile row
-    constexpr int RPP = kThreads / TPR;  // rows per pass
-    const int tc = tid % TPR, tr = tid / TPR;
-    const int n = n0 + tc * EPT;
-#pragma unroll
-    for (int h = 0; h < EPI; ++h) {
-      if (h > 0) __syncthreads();
-      if (EPI == 1 || wm == h) {
+    const int epi = p.epi;
+    auto stage = [&](int h) {
+      if (epi == 1 || wm == h) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-          const int row = (EPI == 1 ? wm * WM : 0) + i * 16 + l15;
+          const int row = (epi == 1 ? wm * WM : 0) + i * 16 + l15;
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
             const int c = (wn * WN + j * 16 + g * 4) >> 2;
@@ -448,52 +483,60 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
           }
         }
       }
-      __syncthreads();
-      if (n < p.Ncols) {
-#pragma unroll 2
-        for (int pass = 0; pass < EROWS / RPP; ++pass) {
-          const int row = pass * RPP + tr;
-          const int m = m0 + h * EROWS + row;
-          if (m >= p.M) break;
-          float v[EPT];
+    };
+    stage(0);
+    __syncthreads();
 #pragma unroll
-          for (int q = 0; q < EPT / 4; ++q) {
-            const int c = tc * (EPT / 4) + q;
-            const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4));
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-          }
-          if (p.bias_mode == VLFB_BIAS_COL) {
+    for (int gp = 0; gp < NPASS; ++gp) {
+      if (gp == NPASS / 2 && epi == 2) {
+        __syncthreads();
+        stage(1);
+        __syncthreads();
+      }
+      const int trow = gp * RPP + tr;                                   // row inside the tile
+      const int row = (epi == 2 && gp >= NPASS / 2) ? trow - BM / 2 : trow;   // row inside the staged half
+      const int m = m0 + trow;
+      if (m < p.M && ncol < p.Ncols) {
+        float v[EPT];
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) v[e] += p.bias[n + e];
-          } else if (p.bias_mode == VLFB_BIAS_ROW) {
-            const float b = p.bias[m];
+        for (int q = 0; q < EPT / 4; ++q) {
+          const int c = tc * (EPT / 4) + q;
+          const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4));
+          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        if (p.bias_mode == VLFB_BIAS_COL) {
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) v[e] += b;
-          }
-          const long long ridx = (long long)m * p.ldr + n;
-          if (Rb) {
-            float r[EPT];
-            load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
+          for (int e = 0; e < EPT; ++e) v[e] += p.bias[ncol + e];
+        } else if (p.bias_mode == VLFB_BIAS_ROW) {
+          const float b = p.bias[m];
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) v[e] += r[e];
-          }
-          if (p.relu) {
+          for (int e = 0; e < EPT; ++e) v[e] += b;
+        }
+        const long long ridx = (long long)m * p.ldr + ncol;
+        if (Rb) {
+          float r[EPT];
+          if (PRE) unpack_elems<T, EPT>(rpre[PRE ? gp : 0], r);
+          else load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (Mb) {
-            float r[EPT];
-            load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
+          for (int e = 0; e < EPT; ++e) v[e] += r[e];
+        }
+        if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
-          }
-          OutT* o = reinterpret_cast<OutT*>(Ob) + (long long)m * p.ldo + n;
-          if (sizeof(OutT) == 4) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
-                                                      pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
-          }
+          for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (Mb) {
+          float r[EPT];
+          if (PRE) unpack_elems<T, EPT>(mpre[PRE ? gp : 0], r);
+          else load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
+        }
+        OutT* o = reinterpret_cast<OutT*>(Ob) + (long long)m * p.ldo + ncol;
+        if (sizeof(OutT) == 4) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
+                                                    pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
         }
       }
     }
@@ -590,12 +633,9 @@ __device__ __forceinline__ void qrow_jump(const GP& p, QRow& r, const RowC& d, c
 template <typename T, bool PACKW>
 __device__ __forceinline__ uint4 qrow_load(const GP& p, const char* base, const QRow& r, const TapC& tp, bool ok) {
   ok = ok && tp.ok && r.hv;
-  if (PACKW) {
+  if (PACKW) {   // W-padded stem input: always inside the row
     const int w0 = r.w * p.sw - p.pw + tp.c;
-    if (sizeof(T) == 4) return ld16_if(base, (r.base + w0) * 16, ok && (unsigned)w0 < (unsigned)p.Ws);
-    const uint2 lo = ld8_if(base, (r.base + w0) * 8, ok && (unsigned)w0 < (unsigned)p.Ws);
-    const uint2 hi = ld8_if(base, (r.base + w0 + 1) * 8, ok && (unsigned)(w0 + 1) < (unsigned)p.Ws);
-    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return ld16_if(base, (r.base + w0) * 4 * (long long)sizeof(T), ok);
   } else {
     const int ws = r.w * p.sw - p.pw + tp.c * p.dw;
     return ld16_if(base, ((r.base + ws) * p.lda + tp.ci) * (long long)sizeof(T), ok && (unsigned)ws < (unsigned)p.Ws);
@@ -819,7 +859,7 @@ __device__ __forceinline__ bf16x8_v tr_frag(const char* tile, int c0, int ks, in
   return u.v;
 }
 
-template <typename OutT, int BP, int BQ, bool IDENT>
+template <typename OutT, int BP, int BQ, bool IDENT, bool PACKW>
 __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
   typedef bf16_t T;
   constexpr int BK = 64;                         // positions per k-tile
@@ -867,7 +907,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
   const int kc = q0 / 8 + qc;                                 // global 16-byte chunk index along K
   TapC qtap;
   if (IDENT) { qtap.ok = kc * 8 < p.K; qtap.a = qtap.b = qtap.c = 0; qtap.ci = 0; }
-  else qtap = decode_tap<T, false>(p, kc);
+  else qtap = decode_tap<T, PACKW>(p, kc);
   QRow qcur[QI];
   RowC jump;
   if (!IDENT) {
@@ -896,9 +936,14 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
       if (IDENT) {
         src = src_or_zero(Ab, ((long long)k * p.lda + (long long)kc * 8) * 2, qtap.ok && k < kend);
       } else {
-        const int ws = qcur[i].w * p.sw - p.pw + qtap.c * p.dw;
-        const bool ok = qtap.ok && qcur[i].hv && k < kend && (unsigned)ws < (unsigned)p.Ws;
-        src = src_or_zero(Ab, ((qcur[i].base + ws) * p.lda + qtap.ci) * 2, ok);
+        if (PACKW) {   // W-padded stem input: the two pixels of the chunk are always inside the row
+          const int w0 = qcur[i].w * p.sw - p.pw + qtap.c;
+          src = src_or_zero(Ab, (qcur[i].base + w0) * 8, qtap.ok && qcur[i].hv && k < kend);
+        } else {
+          const int ws = qcur[i].w * p.sw - p.pw + qtap.c * p.dw;
+          const bool ok = qtap.ok && qcur[i].hv && k < kend && (unsigned)ws < (unsigned)p.Ws;
+          src = src_or_zero(Ab, ((qcur[i].base + ws) * p.lda + qtap.ci) * 2, ok);
+        }
         qrow_jump(p, qcur[i], jump, qtap);
       }
       glds16(src, qt + i * 4096);
@@ -1003,7 +1048,8 @@ struct Plan {
   int bm, bn;     // tile (NT: m x n; TN: p x q)
   int splits;
   int rb;         // NT tile-row bytes (64 or 128)
-  int tn_tr;      // WGRAD: DMA + LDS transpose-read kernel (bf16, not the packed stem)
+  int tn_tr;      // WGRAD: DMA + LDS transpose-read kernel (bf16)
+  int pre;        // NT: prefetch residual / mask rows before the k-loop (thin-K, epilogue-bound launches)
   dim3 grid;
   size_t lds;
   long long ws_elems;
@@ -1084,7 +1130,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // few output rows (res2 / stem, Cout = 64): widen the Q tile so a workgroup still has
     // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
     static const int env_tr = [] { const char* e = getenv("VLFB_TN_TR"); return e ? atoi(e) : 1; }();
-    pl->tn_tr = env_tr && d->dtype == VLFB_BF16 && !pl->packw && d->Cn % 8 == 0;
+    pl->tn_tr = env_tr && d->dtype == VLFB_BF16 && d->Cn % 8 == 0;
     if (!pl->tn_tr && pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
     g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
     g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
@@ -1130,7 +1176,19 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     static const int env_rb = [] { const char* e = getenv("VLFB_NT_RB"); return e ? atoi(e) : 128; }();
     pl->rb = env_rb == 128 ? 128 : 64;
   }
-  pl->lds = (size_t)2 * (pl->bm + pl->bn) * pl->rb;
+  pl->pre = 0;
+  if (d->mode != VLFB_CONV_WGRAD) {
+    const long long ktiles = (K * es + pl->rb - 1) / pl->rb;
+    const size_t buf = (size_t)(pl->bm + pl->bn) * pl->rb;
+    pl->lds = (ktiles <= 1 ? 1 : 2) * buf;           // a single k-tile needs no second buffer
+    const size_t tile = (size_t)pl->bm * pl->bn * 4;
+    g.epi = (int)((tile + pl->lds - 1) / pl->lds);
+    if (g.epi > 2) { pl->lds = tile / 2; g.epi = 2; }
+    static const int env_pre = [] { const char* e = getenv("VLFB_NT_PRE"); return e ? atoi(e) : 1; }();
+    pl->pre = env_pre && g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
+  } else {
+    pl->lds = (size_t)2 * (pl->bm + pl->bn) * 128;
+  }
   return VLFB_OK;
 }
 
@@ -1147,14 +1205,20 @@ void launch_k(K kernel, const Plan& pl, hipStream_t s) {
 }
 template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
+  constexpr bool CAN_PRE = sizeof(T) == 2 && sizeof(OutT) == 2 && !PACKW;
   if (sizeof(T) == 2 && pl.rb == 64) {
     // 64-byte tile rows: half the LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU
-    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128>, pl, s);
-    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128>, pl, s);
+    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128, false>, pl, s);
+    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128, false>, pl, s);
     return;
   }
-  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128>, pl, s);
-  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128>, pl, s);
+  if (CAN_PRE && pl.pre) {
+    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE>, pl, s);
+    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE>, pl, s);
+    return;
+  }
+  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false>, pl, s);
+  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false>, pl, s);
 }
 template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn(const Plan& pl, hipStream_t s) {
@@ -1165,19 +1229,20 @@ void launch_tn(const Plan& pl, hipStream_t s) {
   else launch_k(gemm_tn_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
 }
 
-template <typename OutT, bool IDENT>
+template <typename OutT, bool IDENT, bool PACKW>
 void launch_tn_tr(const Plan& pl, hipStream_t s) {
-  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT>, pl, s);
-  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 64, 128, IDENT>, pl, s);
-  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<OutT, 128, 64, IDENT>, pl, s);
-  else launch_k(gemm_tn_tr_kernel<OutT, 64, 64, IDENT>, pl, s);
+  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW>, pl, s);
+  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 64, 128, IDENT, PACKW>, pl, s);
+  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<OutT, 128, 64, IDENT, PACKW>, pl, s);
+  else launch_k(gemm_tn_tr_kernel<OutT, 64, 64, IDENT, PACKW>, pl, s);
 }
 
 template <typename T, typename OutT>
 int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
   if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn_tr) {
-    if (pl.ident) launch_tn_tr<OutT, true>(pl, s);
-    else launch_tn_tr<OutT, false>(pl, s);
+    if (pl.ident) launch_tn_tr<OutT, true, false>(pl, s);
+    else if (pl.packw) launch_tn_tr<OutT, false, true>(pl, s);
+    else launch_tn_tr<OutT, false, false>(pl, s);
     return check_launch("conv wgrad (tr) kernel");
   }
   if (d->mode == VLFB_CONV_WGRAD) {
@@ -1237,6 +1302,7 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   g.bias = bias; g.rowscale = rowscale; g.R = (const char*)R; g.Mask = (const char*)Mask;
   g.ws = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
+  if (!R && !Mask) pl.pre = 0;
   if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
   else if (d->out_dtype == VLFB_F32) rc = dispatch<bf16_t, float>(d, pl, s);
   else rc = dispatch<bf16_t, bf16_t>(d, pl, s);

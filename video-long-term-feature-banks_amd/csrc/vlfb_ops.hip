@@ -63,6 +63,25 @@ __global__ void ncthw_to_nthwc_kernel(const float* __restrict__ src, T* __restri
     for (int k = 0; k < c_pad; ++k) Elem<T>::st(d + k, k < c ? s[(long long)k * thw] : 0.f);
   }
 }
+// the same with zero pixels on both sides of every W row (the stem kernels then never need a
+// w-bounds test: [N][rows][wl + W + wr][c_pad])
+template <typename T>
+__global__ void ncthw_to_nthwc_wpad_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                           long long n, int c, long long rows, int w, int c_pad,
+                                           int wl, int wtot) {
+  const long long total = n * rows * wtot;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % wtot);
+    const long long nr = i / wtot;
+    const long long b = nr / rows, r = nr - b * rows;
+    const int x = wp - wl;
+    const bool in = x >= 0 && x < w;
+    const float* sp = src + (b * c * rows + r) * w + x;
+    T* d = dst + i * c_pad;
+    for (int k = 0; k < c_pad; ++k) Elem<T>::st(d + k, (in && k < c) ? sp[(long long)k * rows * w] : 0.f);
+  }
+}
 template <typename T>
 __global__ void nthwc_to_ncthw_kernel(const T* __restrict__ src, float* __restrict__ dst,
                                       long long n, int c, long long thw) {
@@ -828,4 +847,18 @@ extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_
     hipLaunchKernelGGL(weight_prep_batched_kernel<bf16_t>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
   return check_launch("weight_prep_batched");
+}
+
+extern "C" int vlfb_ncthw_to_nthwc_wpad(const float* src, void* dst, int dtype, int64_t n, int64_t c,
+                                        int64_t rows, int64_t w, int64_t c_pad, int64_t wpad_left,
+                                        int64_t w_total, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && c_pad >= c && n > 0 && c > 0 && rows > 0 && w > 0 && wpad_left >= 0 &&
+               w_total >= wpad_left + w, "ncthw_to_nthwc_wpad: bad args");
+  int grid = grid_for(n * rows * w_total, 256);
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL(ncthw_to_nthwc_wpad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long long)n, (int)c, (long long)rows, (int)w, (int)c_pad, (int)wpad_left, (int)w_total);
+  else if (dtype == VLFB_BF16)
+    hipLaunchKernelGGL(ncthw_to_nthwc_wpad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n, (int)c, (long long)rows, (int)w, (int)c_pad, (int)wpad_left, (int)w_total);
+  else return set_error(VLFB_ERR_ARG, "ncthw_to_nthwc_wpad: bad dtype");
+  return check_launch("ncthw_to_nthwc_wpad");
 }

@@ -195,6 +195,12 @@ class ConvStep(Step):
         self.pack = 8 if self.stem else 0
         code = eng.code
         common = dict(dtype=code, **self._geom())
+        if self.stem:
+            # the data blob is stored with 4 zero pixels on both sides of every W row
+            wpad = getattr(self.x.root, "pad_w", 0) or getattr(self.x, "pad_w", 0)
+            assert wpad >= self.p[2] and wpad >= self.pack - self.k[2] + self.p[2], "stem needs a W-padded input"
+            W = W + 2 * wpad
+            common["pw"] = self.p[2] - wpad
         self.d_f = hip.conv_desc(mode=hip.FPROP, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
                                  Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, relu=int(self.relu),
                                  bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, **common)
@@ -699,8 +705,9 @@ class Lowering(object):
         eng = self.eng
         for name, shape in self.input_shapes.items():
             if name.startswith("data"):
-                b = self.new_blob(name, shape, 1)            # stored NTHWC4
+                b = self.new_blob(name, shape, 1)            # stored [N][T][H][W + 2*4][4]
                 b.pad_c = 4
+                b.pad_w = 4
             elif name.startswith("labels"):
                 b = self.new_blob(name, shape, len(shape) - 1, "i32")
             elif name.startswith("proposals"):
@@ -739,6 +746,7 @@ class Lowering(object):
         if getattr(x, "is_input", False):
             v.is_input = True
             v.pad_c = getattr(x, "pad_c", None)
+            v.pad_w = getattr(x, "pad_w", 0)
             v.root = x.root
         self.env[op.outputs[0]] = v
         return i + 1
@@ -1251,7 +1259,8 @@ class Engine(object):
             if b.kind == "act":
                 n = b.numel
                 if getattr(b, "pad_c", None):
-                    n = b.numel // b.C * b.pad_c
+                    wpad = getattr(b, "pad_w", 0)
+                    n = b.numel // b.C // b.shape[-1] * (b.shape[-1] + 2 * wpad) * b.pad_c
                 b.tensor = torch.zeros(n, device=dev, dtype=self.tdtype)
             elif b.kind == "f32":
                 b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.float32)
@@ -1379,8 +1388,10 @@ class Engine(object):
         elif getattr(root, "pad_c", None):
             src = t.to(torch.float32).contiguous().to(self.device)
             N, Cc = root.shape[0], root.shape[1]
-            hip.call("vlfb_ncthw_to_nthwc", hip.ptr(src), root.ptr(), self.code, N, Cc, _prod(root.shape[2:]),
-                     root.pad_c)
+            wpad = getattr(root, "pad_w", 0)
+            W = root.shape[-1]
+            hip.call("vlfb_ncthw_to_nthwc_wpad", hip.ptr(src), root.ptr(), self.code, N, Cc,
+                     _prod(root.shape[2:-1]), W, root.pad_c, wpad, W + 2 * wpad)
             torch.cuda.current_stream().synchronize()
         else:   # row-major activation input (lfb)
             src = t.to(torch.float32).contiguous().reshape(-1).to(self.device)
@@ -1398,7 +1409,9 @@ class Engine(object):
         src = b.root.slot.cur if grad else b.root.tensor
         t = src.detach().float().cpu()
         if getattr(b.root, "pad_c", None) and not grad:
-            t = t.view(-1, b.root.pad_c)[:, :b.C].reshape(-1)
+            wpad = getattr(b.root, "pad_w", 0)
+            W = b.shape[-1]
+            t = t.view(-1, W + 2 * wpad, b.root.pad_c)[:, wpad:wpad + W, :b.C].reshape(-1)
         order = [ax for ax in range(len(b.shape)) if ax != b.caxis] + [b.caxis]
         stor = t[:b.numel].view([b.shape[ax] for ax in order])
         inv = [order.index(ax) for ax in range(len(b.shape))]

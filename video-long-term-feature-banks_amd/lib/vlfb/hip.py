@@ -75,6 +75,7 @@ _SIGS = {
     "vlfb_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
     "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
+    "vlfb_ncthw_to_nthwc_wpad": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "vlfb_nthwc_to_ncthw": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_cast": (C.c_int, [_P, C.c_int, _P, C.c_int, _I64, _P]),
     "vlfb_transpose2d": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
