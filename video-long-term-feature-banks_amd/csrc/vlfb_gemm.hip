@@ -311,20 +311,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // =============================================================================================
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
 // =============================================================================================
-template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE>
-__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
+template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
+  // NW = 4: waves 2 (m) x 2 (n), 64 x (BN/2) each.  NW = 8: waves 2 x 4, 64 x (BN/4) each -- twice the
+  // wavefronts per CU on the same LDS footprint (more latency hiding, 1.5x the LDS fragment reads).
+  constexpr int NTHR = 64 * NW;
+  constexpr int NWN = NW / 2;              // waves along n
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CPRW = RB / 16;            // 16-byte chunks per tile row
-  constexpr int RPPS = kThreads / CPRW;    // tile rows staged per pass
+  constexpr int RPPS = NTHR / CPRW;        // tile rows staged per pass
   constexpr int A_IT = BM / RPPS, B_IT = BN / RPPS;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WM = BM / 2, WN = BN / NWN;
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int BUF = (BM + BN) * RB;
   constexpr int KSTEPS = sizeof(T) == 4 ? 1 : RB / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int l15 = lane & 15, g = lane >> 4;
 
   const int nwg = p.tiles_m * p.tiles_n;
@@ -372,12 +376,12 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
       for (int i = 0; i < A_IT; ++i)
         glds16(PACKW ? packw_chunk_ptr<T>(p, Ab, aok[i], arow[i], tap)
                      : act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc),
-               xa + i * 4096);
+               xa + i * (RPPS * RB));
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int n = n0 + r0 + RPPS * i;
         glds16(src_or_zero(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols),
-               wb + i * 4096);
+               wb + i * (RPPS * RB));
       }
     } else {
 #pragma unroll
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GP p) {
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
   constexpr int EPT = 16 / (int)sizeof(OutT);   // output elements per 16-byte store
   constexpr int TPR = BN / EPT;                 // lanes per tile row
-  constexpr int RPP = kThreads / TPR;           // rows per pass
+  constexpr int RPP = NTHR / TPR;               // rows per pass
   constexpr int NPASS = BM / RPP;
   const int tc = tid % TPR, tr = tid / TPR;
   const int ncol = n0 + tc * EPT;
@@ -1050,6 +1054,7 @@ struct Plan {
   int rb;         // NT tile-row bytes (64 or 128)
   int tn_tr;      // WGRAD: DMA + LDS transpose-read kernel (bf16)
   int pre;        // NT: prefetch residual / mask rows before the k-loop (thin-K, epilogue-bound launches)
+  int threads;    // workgroup size (NT: 256 or 512)
   dim3 grid;
   size_t lds;
   long long ws_elems;
@@ -1141,7 +1146,8 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       // split count that fills whole waves best (every extra split costs one more fp32 slab
       // pass), keeping at least 8 k-tiles of work per split.
       const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
-      const long long slots = 512;
+      static const int env_slots = [] { const char* e = getenv("VLFB_WGRAD_SLOTS"); return e ? atoi(e) : 512; }();
+      const long long slots = env_slots > 0 ? env_slots : 512;
       long long maxs = (M + 8 * bk - 1) / (8 * bk);
       const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
       if (maxs > slab_cap) maxs = slab_cap;
@@ -1177,6 +1183,11 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->rb = env_rb == 128 ? 128 : 64;
   }
   pl->pre = 0;
+  pl->threads = kThreads;
+  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16 && pl->bn == 128 && pl->rb == 128) {
+    static const int env_nw = [] { const char* e = getenv("VLFB_NT_WAVES"); return e ? atoi(e) : 8; }();
+    if (env_nw == 8) pl->threads = 512;
+  }
   if (d->mode != VLFB_CONV_WGRAD) {
     const long long ktiles = (K * es + pl->rb - 1) / pl->rb;
     const size_t buf = (size_t)(pl->bm + pl->bn) * pl->rb;
@@ -1201,24 +1212,30 @@ void launch_k(K kernel, const Plan& pl, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     configured = true;
   }
-  hipLaunchKernelGGL(kernel, pl.grid, dim3(kThreads), pl.lds, s, pl.gp);
+  hipLaunchKernelGGL(kernel, pl.grid, dim3(pl.threads), pl.lds, s, pl.gp);
 }
 template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
-  constexpr bool CAN_PRE = sizeof(T) == 2 && sizeof(OutT) == 2 && !PACKW;
-  if (sizeof(T) == 2 && pl.rb == 64) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr bool CAN_PRE = BF && sizeof(OutT) == 2 && !PACKW;
+  if (BF && pl.rb == 64) {
     // 64-byte tile rows: half the LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU
-    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128, false>, pl, s);
-    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, sizeof(T) == 2 ? 64 : 128, false>, pl, s);
+    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, BF ? 64 : 128, false, 4>, pl, s);
+    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, BF ? 64 : 128, false, 4>, pl, s);
+    return;
+  }
+  if (BF && pl.threads == 512) {   // 8 waves per workgroup (bf16, 128-wide tiles)
+    if (CAN_PRE && pl.pre) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>, pl, s);
+    else launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>, pl, s);
     return;
   }
   if (CAN_PRE && pl.pre) {
-    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE>, pl, s);
-    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE>, pl, s);
+    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>, pl, s);
+    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>, pl, s);
     return;
   }
-  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false>, pl, s);
-  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false>, pl, s);
+  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, 4>, pl, s);
+  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, 4>, pl, s);
 }
 template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn(const Plan& pl, hipStream_t s) {
