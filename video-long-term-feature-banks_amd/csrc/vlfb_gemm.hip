@@ -1018,17 +1018,44 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
   }
 }
 
-template <typename OutT>
-__global__ void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale, long long n,
-                                    int ldo, int splits, float alpha, int accumulate) {
-  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const long long stride = (long long)gridDim.x * blockDim.x * 4;
-  for (; i < n; i += stride) {
-    float4 s = *reinterpret_cast<const float4*>(ws + i);
-    for (int k = 1; k < splits; ++k) {
-      float4 t = *reinterpret_cast<const float4*>(ws + (long long)k * n + i);
+// split-K slab reduction: one wave covers 64 float4 columns, the G waves of a workgroup stride over
+// the splits (4 loads in flight each) and fold through LDS; wave 0 applies the epilogue
+template <typename OutT, int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale,
+                                                              long long n, int ldo, int splits, float alpha,
+                                                              int accumulate) {
+  __shared__ float4 part[G > 1 ? (G - 1) * 64 : 1];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long i = ((long long)blockIdx.x * 64 + lane) * 4;
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const float* src = ws + i;
+    int k = g;
+    for (; k + 3 * G < splits; k += 4 * G) {
+      float4 t0 = *reinterpret_cast<const float4*>(src + (long long)k * n);
+      float4 t1 = *reinterpret_cast<const float4*>(src + (long long)(k + G) * n);
+      float4 t2 = *reinterpret_cast<const float4*>(src + (long long)(k + 2 * G) * n);
+      float4 t3 = *reinterpret_cast<const float4*>(src + (long long)(k + 3 * G) * n);
+      s.x += (t0.x + t1.x) + (t2.x + t3.x); s.y += (t0.y + t1.y) + (t2.y + t3.y);
+      s.z += (t0.z + t1.z) + (t2.z + t3.z); s.w += (t0.w + t1.w) + (t2.w + t3.w);
+    }
+    for (; k < splits; k += G) {
+      float4 t = *reinterpret_cast<const float4*>(src + (long long)k * n);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
+  }
+  if (G > 1) {
+    if (g > 0) part[(g - 1) * 64 + lane] = s;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < G - 1; ++j) {
+        float4 t = part[j * 64 + lane];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    }
+  }
+  if (g == 0 && i < n) {
     float rs = alpha * (rowscale ? rowscale[i / ldo] : 1.f);
     float v[4] = {s.x * rs, s.y * rs, s.z * rs, s.w * rs};
     if (accumulate) {
@@ -1327,13 +1354,17 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   if (pl.splits > 1) {
     const long long n = (long long)d->Cn * g.K;
     VLFB_REQUIRE(n % 4 == 0, "conv: split WGRAD output size must be a multiple of 4");
-    int grid = grid_for(n / 4, 256);
-    if (d->out_dtype == VLFB_F32)
-      hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, g.ws, g.O,
-                         rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate);
-    else
-      hipLaunchKernelGGL(wgrad_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g.ws, g.O,
-                         rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate);
+    const unsigned grid = (unsigned)((n / 4 + 63) / 64);
+    const int G = pl.splits >= 32 ? 16 : pl.splits >= 8 ? 4 : 1;
+#define VLFB_REDUCE(OT, GG)                                                                         \
+  hipLaunchKernelGGL((wgrad_reduce_kernel<OT, GG>), dim3(grid), dim3(64 * GG), 0, s, g.ws, g.O,    \
+                     rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate)
+    if (d->out_dtype == VLFB_F32) {
+      if (G == 16) VLFB_REDUCE(float, 16); else if (G == 4) VLFB_REDUCE(float, 4); else VLFB_REDUCE(float, 1);
+    } else {
+      if (G == 16) VLFB_REDUCE(bf16_t, 16); else if (G == 4) VLFB_REDUCE(bf16_t, 4); else VLFB_REDUCE(bf16_t, 1);
+    }
+#undef VLFB_REDUCE
     return check_launch("wgrad reduce");
   }
   return VLFB_OK;
