@@ -198,8 +198,10 @@ def main():
             except Exception as e:  # the baseline is a report, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dist.barrier()
+    if dist.initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

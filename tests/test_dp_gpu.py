@@ -101,3 +101,49 @@ def test_two_replicas_match_one_process_with_both_clips():
     for n in ("pred_w", "res5_2_branch2c_w", "res3_1_branch2b_w", "conv1_w"):
         assert np.array_equal(results[0][n], results[1][n]), "ranks disagree after all-reduce: " + n
         assert rel(results[0][n], eng.fetch_grad(n)) < 2e-4, (n, rel(results[0][n], eng.fetch_grad(n)))
+
+
+def _nccl_worker(port, q):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      VLFB_DIST_FORCE="1", VLFB_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from vlfb import dist
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from oracle import model as om
+    dist.init_from_env()
+    assert torch.distributed.get_backend() == "nccl"
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1] + OV)
+    inputs = om.synth_inputs(cfg, 1, "train", seed=2, crop=64, frames=16)
+    params = om.synth_params(cfg, seed=2)
+    eng = _run_replica(1, 0, 1, inputs, params)
+    assert eng.comm is not None and len(eng.comm.buckets) > 5
+    q.put({n: eng.fetch_grad(n) for n in ("pred_w", "res3_1_branch2b_w", "conv1_w")})
+    dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_bucketed_allreduce_one_rank():
+    """the RCCL (backend "nccl") leg of GradComm on the one visible GPU: communicator set-up, weight
+    broadcast, async bucket all-reduces issued during backward, solver-side wait.  A one-rank sum is
+    the identity, so the gradients must equal those of a run without a process group."""
+    import torch.multiprocessing as mp
+    _setup_paths()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from oracle import model as om
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1] + OV)
+    inputs = om.synth_inputs(cfg, 1, "train", seed=2, crop=64, frames=16)
+    params = om.synth_params(cfg, seed=2)
+    eng = _run_replica(1, 0, 1, inputs, params)
+    assert eng.comm is None
+    for n, g in got.items():
+        assert np.array_equal(g, eng.fetch_grad(n)), n

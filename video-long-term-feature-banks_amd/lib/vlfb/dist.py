@@ -27,10 +27,21 @@ def local_rank():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def forced():
+    return os.environ.get("VLFB_DIST_FORCE", "0") == "1"
+
+
 def init_from_env(backend=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
-    if initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).
+    A one-rank job skips the process group unless VLFB_DIST_FORCE=1 (lets a single-GPU box drive the
+    RCCL code path: communicator set-up, bucketed all-reduce, stream hand-over)."""
+    if initialized():
         return
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not forced():
+        return
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:

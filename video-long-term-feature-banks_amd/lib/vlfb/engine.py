@@ -1444,7 +1444,7 @@ class Engine(object):
         (broadcast from rank 0), bucketed sum-all-reduce of the flat gradient during backward"""
         import torch.distributed as td
         from vlfb.comm import GradComm
-        if not (self.train and dist.world_size() > 1):
+        if not (self.train and (dist.world_size() > 1 or (dist.forced() and dist.initialized()))):
             return
         td.broadcast(self.flat_param, 0)
         td.broadcast(self.flat_frozen, 0)
