@@ -26,6 +26,7 @@ for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT)
         sys.path.insert(0, _p)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0                           # HBM3E spec peak (same guide; ~6.3 TB/s measured copy)
 FWD_BWD_GFLOP_PER_CLIP = 1106.1                 # R50-I3D-NL backbone, 3x fwd - conv1 dgrad
 
 
@@ -137,7 +138,7 @@ def main():
     loss = float(eng.fetch("loss").reshape(-1)[0])
 
     # ---- live roofline of the GEMM kernel families (this rank) -----------------------------------
-    fam = {"nt": [0.0, 0.0, 0, 0.0], "tn": [0.0, 0.0, 0, 0.0]}
+    fam = {"nt": [0.0, 0.0, 0, 0.0, 0.0], "tn": [0.0, 0.0, 0, 0.0, 0.0]}
     rows = []
     for mode, flops, e0, e1, tag, nbytes in prof or []:
         f = fam["tn" if mode == hip.WGRAD else "nt"]
@@ -146,6 +147,8 @@ def main():
         f[1] += sec
         f[2] += 1
         f[3] += nbytes
+        # per-launch attainable time: whichever of the MFMA and the HBM roof binds THIS launch
+        f[4] += max(flops / (PEAK_TFLOPS[args.dtype] * 1e12), nbytes / (HBM_PEAK_GBPS * 1e9))
         rows.append((sec, flops, tag))
     # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_hbm_traffic.txt): rocprofv3
     # cannot run inside this process, so the counters of the SAME command are read from the profile
@@ -166,14 +169,18 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
 
     def roof(key, kernel):
-        fl, sec, n, nb = fam[key]
+        fl, sec, n, nb, att = fam[key]
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic.get(key),
                 "algorithmic_bytes_per_launch": round(nb / max(n, 1)),
                 "algorithmic_GBps": round(nb / sec / 1e9, 1) if sec > 0 else 0.0, "launches_per_step": n,
                 "avg_launch_us": round(sec / max(n, 1) * 1e6, 2), "gflop_per_step": round(fl / 1e9, 1),
-                "ms_per_step": round(sec * 1e3, 3)}
+                "ms_per_step": round(sec * 1e3, 3),
+                # sum over launches of max(flops/MFMA peak, algorithmic bytes/HBM peak): what the same
+                # launch list would take with every launch on its own roof (thin-K layers are HBM-bound)
+                "attainable_ms_per_step": round(att * 1e3, 3),
+                "frac_of_attainable": round(att / sec, 4) if sec > 0 else 0.0}
 
     clips_total = clips * world * args.steps
     value = clips_total / elapsed
