@@ -42,3 +42,64 @@ def test_train_net_style_loop_through_the_facade():
     workspace.FeedBlob("gpu_0/pred_w", new)
     assert np.array_equal(workspace.FetchBlob("gpu_0/pred_w"), new)
     workspace.ResetWorkspace()
+
+
+def test_checkpoint_round_trip_through_the_device_engine(tmp_path):
+    """save after two solver steps, resume into a fresh engine: parameters, momentum and the next
+    step's loss are bit-identical; a 2-D (image model) weight file inflates into the 3-D kernels"""
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb import workspace, synth
+    from utils import checkpoints as ck
+
+    def fresh():
+        workspace.ResetWorkspace()
+        workspace.set_compute_dtype("fp32")
+        load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 8,
+                                              "TRAIN.CROP_SIZE", 64, "TRAIN.DROPOUT_RATE", 0.0])
+        cfg.CHECKPOINT.DIR = str(tmp_path)
+        cfg.TRAIN.PARAMS_FILE = ""
+        model = ModelBuilder(train=True, split="train", name="train")
+        model.build_model(suffix="_train")
+        workspace.register(model)
+        for k, v in synth.inputs(cfg, 1, seed=3, crop=64, frames=8).items():
+            workspace.FeedBlob("gpu_0/" + k, v)
+        return model, workspace.CreateNet(model.net)
+
+    model, eng = fresh()
+    model.UpdateWorkspaceLr(0)
+    for _ in range(2):
+        workspace.RunNet(model.net)
+    path = ck.create_and_get_checkpoint_directory() + "/c2_model_iter2.pkl"
+    ck.save_model_params(model, path, model_iter=1)
+    names = ["conv1_w", "res3_1_branch2b_w", "nonlocal_conv4_1_theta_b", "pred_w", "res_conv1_bn_s"]
+    want_p = {n: workspace.FetchBlob("gpu_0/" + n).copy() for n in names}
+    want_m = {n: workspace.FetchBlob("gpu_0/%s_momentum" % n).copy() for n in names[:4]}
+    workspace.RunNet(model.net)
+    want_loss = float(workspace.FetchBlob("gpu_0/loss"))
+
+    model2, eng2 = fresh()
+    assert ck.load_model_from_params_file(model2) == 2
+    for n in names:
+        assert np.array_equal(workspace.FetchBlob("gpu_0/" + n), want_p[n]), n
+    for n in names[:4]:
+        assert np.array_equal(workspace.FetchBlob("gpu_0/%s_momentum" % n), want_m[n]), n
+    assert abs(float(workspace.FetchBlob("gpu_0/lr")) - float(model.current_lr)) < 1e-9
+    workspace.RunNet(model2.net)
+    assert float(workspace.FetchBlob("gpu_0/loss")) == want_loss
+
+    # image-model file: 2-D conv weights -> inflated over kT, classifier of another size skipped
+    blobs = ck.read_blobs(path)
+    w3 = blobs["res2_0_branch2a_w"]                       # (64, 64, 3, 1, 1) in the I3D graph
+    blobs["res2_0_branch2a_w"] = w3.sum(axis=2)
+    blobs["pred_w"] = np.zeros((400, 2048), np.float32)
+    img = str(tmp_path / "image_model.pkl")
+    ck.write_blobs(img, blobs)
+    model3, eng3 = fresh()
+    pred0 = workspace.FetchBlob("gpu_0/pred_w").copy()
+    ck.initialize_params_from_file(model3, img, load_momentum=False)
+    got = workspace.FetchBlob("gpu_0/res2_0_branch2a_w")
+    np.testing.assert_allclose(got, np.repeat(w3.sum(axis=2, keepdims=True), 3, axis=2) / 3.0, rtol=1e-6)
+    assert np.array_equal(workspace.FetchBlob("gpu_0/pred_w"), pred0)
+    workspace.ResetWorkspace()

@@ -1333,6 +1333,14 @@ class Engine(object):
         off, cnt, shape = self.train_layout[name]
         return self._from_kernel_layout(name, self.flat_mom[off:off + cnt].view(shape))
 
+    def feed_momentum(self, momenta):
+        """{name: array in the reference layout}: the `<param>_momentum` blobs of a checkpoint"""
+        for name, arr in momenta.items():
+            if name not in self.train_layout:
+                raise KeyError("parameter %r has no momentum buffer (not trainable)" % name)
+            off, cnt, shape = self.train_layout[name]
+            self.flat_mom[off:off + cnt].view(shape).copy_(self._to_kernel_layout(name, arr).to(self.device))
+
     def _build_wprep_tables(self):
         """device tables for vlfb_weight_prep_batched: all convs / only those with trainable weights"""
         import ctypes as C_

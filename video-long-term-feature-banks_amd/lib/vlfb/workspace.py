@@ -94,6 +94,9 @@ def FeedBlob(name, arr):
         if base in eng.param_views:
             eng.feed_params({base: arr})
             return True
+        if base.endswith("_momentum") and eng.train and base[:-9] in eng.train_layout:
+            eng.feed_momentum({base[:-9]: arr})
+            return True
         if base == "lr":
             eng.set_lr(float(arr))
             return True
@@ -114,6 +117,11 @@ def FetchBlob(name):
         return np.float32(eng.lr)
     out = eng.fetch(base)
     return out.reshape(()) if base == "loss" else out
+
+
+def GetEngine(net):
+    """the Engine behind a created net (no Caffe2 equivalent; used by utils.checkpoints)"""
+    return _engines[id(net)]
 
 
 def HasBlob(name):
