@@ -91,15 +91,16 @@ def test_checkpoint_round_trip_through_the_device_engine(tmp_path):
 
     # image-model file: 2-D conv weights -> inflated over kT, classifier of another size skipped
     blobs = ck.read_blobs(path)
-    w3 = blobs["res2_0_branch2a_w"]                       # (64, 64, 3, 1, 1) in the I3D graph
-    blobs["res2_0_branch2a_w"] = w3.sum(axis=2)
+    tname = next(n for n in model.params if n.endswith("branch2a_w") and blobs[n].shape[2] == 3)
+    w3 = blobs[tname]                                     # (Ci, Cin, 3, 1, 1) in the I3D graph
+    blobs[tname] = w3.sum(axis=2)
     blobs["pred_w"] = np.zeros((400, 2048), np.float32)
     img = str(tmp_path / "image_model.pkl")
     ck.write_blobs(img, blobs)
     model3, eng3 = fresh()
     pred0 = workspace.FetchBlob("gpu_0/pred_w").copy()
     ck.initialize_params_from_file(model3, img, load_momentum=False)
-    got = workspace.FetchBlob("gpu_0/res2_0_branch2a_w")
+    got = workspace.FetchBlob("gpu_0/" + tname)
     np.testing.assert_allclose(got, np.repeat(w3.sum(axis=2, keepdims=True), 3, axis=2) / 3.0, rtol=1e-6)
     assert np.array_equal(workspace.FetchBlob("gpu_0/pred_w"), pred0)
     workspace.ResetWorkspace()
