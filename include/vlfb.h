@@ -300,6 +300,43 @@ int vlfb_sgd_update(float* p, float* g, float* m, int64_t n, float lr, float wd,
                     int nesterov, vlfb_stream_t stream);
 int vlfb_scale_inplace(float* x, int64_t n, float s, vlfb_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Long-term feature bank resident on the device.
+ * Replaces the host dict-of-lists bank of tools/lfb_loader.py:49-112 (construct_ava_lfb,
+ * construct_frame_level_lfb) and the per-clip NumPy sampling of lib/datasets/ava.py:300-323 and
+ * lib/datasets/charades.py:251-276.
+ *   bank  [n_videos][n_steps][capacity][dim]  elements of `dtype`, caller-owned
+ *   count [n_videos][n_steps] int32, caller-owned, zero = empty
+ * AVA: step = second (minus a base), capacity = most boxes kept per second.
+ * Charades: step = LFB frame slot, capacity = 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlfb_lfb_desc {
+  int32_t n_videos, n_steps, capacity, dim;
+  int32_t dtype;
+} vlfb_lfb_desc;
+int64_t vlfb_lfb_bank_bytes(const vlfb_lfb_desc* d);
+/* Append `rows` features (feats [rows][dim] of feat_dtype) under keys [rows][2] = {video, step}.
+ * Rows of the same key keep their batch order behind what the bank already holds (list.append of
+ * lfb_loader.py:100-104); rows with video < 0 are padding and skipped; rows that do not fit
+ * (bad key / cell full) are counted in *dropped (optional device int32). */
+int vlfb_lfb_append(const vlfb_lfb_desc* d, void* bank, int32_t* count, const void* feats,
+                    int feat_dtype, const int32_t* keys, int64_t rows, int32_t* dropped,
+                    vlfb_stream_t stream);
+/* AVA window sampling (ava.py:300-323): query [rows][3] = {video, centre step, sample id};
+ * out [rows][window*max_per_step][dim]; time slot j holds min(n, max_per_step) distinct features
+ * of step centre - window/2 + j in random order, zeros elsewhere.  The draw is a pure function of
+ * (seed, sample id, video, step): rows sharing a sample id get the same features (the reference
+ * repeats the clip's sample for each of its RoIs, ava_data_input.py:191-192). */
+int vlfb_lfb_sample_window(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
+                           const int32_t* query, int64_t rows, int window, int max_per_step,
+                           uint64_t seed, void* out, int out_dtype, vlfb_stream_t stream);
+/* Frame-level sampling (charades.py:251-276): query [rows][3] = {video, first step, last step};
+ * out [rows][window][dim] = the first `window` occupied steps of [first, last] packed to the
+ * front, zeros behind. */
+int vlfb_lfb_sample_compact(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
+                            const int32_t* query, int64_t rows, int window, void* out,
+                            int out_dtype, vlfb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""oracle/lfb.py against a literal transcription of the reference's samplers' *structure* (CPU)."""
+import numpy as np
+
+from oracle import lfb as ol
+
+
+def _bank(rng, n_videos=3, secs=range(900, 960), dim=8, max_n=9):
+    lfb = {}
+    for v in range(n_videos):
+        lfb[v] = {}
+        for s in secs:
+            n = int(rng.integers(0, max_n))
+            if n:
+                lfb[v][s] = [rng.standard_normal(dim) for _ in range(n)]
+    return lfb
+
+
+def test_construct_ava_lfb_keeps_append_order_and_rounds_keys():
+    rng = np.random.default_rng(0)
+    feats = [[rng.standard_normal((4, 6, 1, 1, 1))], [rng.standard_normal((3, 6, 1, 1, 1))]]
+    meta = [[np.array([[7.0, 902.0, 0, 0], [7.0, 902.0, 0, 0], [8.0, 903.0, 0, 0], [7.0000001, 901.9999, 0, 0]])],
+            [np.array([[8.0, 903.0, 0, 0], [7.0, 950.0, 0, 0], [7.0, 902.0, 0, 0]])]]
+    lfb = ol.construct_ava_lfb(feats, meta)
+    assert sorted(lfb) == [7, 8] and sorted(lfb[7]) == [902, 950]
+    got = np.stack(lfb[7][902])
+    want = np.stack([feats[0][0][0], feats[0][0][1], feats[0][0][3], feats[1][0][2]]).reshape(4, 6)
+    assert np.array_equal(got, want)
+    assert len(lfb[8][903]) == 2
+
+
+def test_sample_lfb_ava_structure_matches_reference_semantics():
+    rng = np.random.default_rng(1)
+    lfb = _bank(rng)
+    W, K, D = 20, 5, 8
+    for video in lfb:
+        for sec in (905, 930, 959, 1200):
+            out = ol.sample_lfb_ava(lfb[video], sec, W, K, D, seed=11, sample_id=3, video=video)
+            assert out.shape == (W * K, D)
+            lower = sec - W // 2
+            for j in range(W):
+                si = lower + j
+                rows = out[j * K:(j + 1) * K]
+                n = len(lfb[video].get(si, []))
+                m = min(n, K)
+                assert np.all(rows[m:] == 0)
+                pool = [tuple(f) for f in lfb[video].get(si, [])]
+                picked = [tuple(r) for r in rows[:m]]
+                assert len(set(picked)) == m and all(p in pool for p in picked)     # distinct, from this second
+    # same draw id -> same sample; another id -> (almost surely) another
+    a = ol.sample_lfb_ava(lfb[0], 930, W, K, D, 11, 3, 0)
+    assert np.array_equal(a, ol.sample_lfb_ava(lfb[0], 930, W, K, D, 11, 3, 0))
+    assert not np.array_equal(a, ol.sample_lfb_ava(lfb[0], 930, W, K, D, 11, 4, 0))
+
+
+def test_choice_is_close_to_uniform():
+    n, k, trials = 7, 3, 4000
+    first = np.zeros(n)
+    member = np.zeros(n)
+    for t in range(trials):
+        c = ol.choice_without_replacement(n, k, seed=5, sample_id=t, video=1, step=40)
+        assert len(set(c)) == k
+        first[c[0]] += 1
+        member[c] += 1
+    assert np.all(np.abs(first / trials - 1.0 / n) < 0.03)
+    assert np.all(np.abs(member / trials - float(k) / n) < 0.04)
+
+
+def test_charades_window_and_compaction():
+    rng = np.random.default_rng(2)
+    frames = ol.charades_lfb_frames([100, 30, 400], clips_per_second=2)
+    assert frames[0] == (0, 11) and all((f + 1) % 12 == 0 for _, f in frames) and (1, 23) in frames
+    feats = rng.standard_normal((len(frames) + 3, 4, 1, 1, 1))          # 3 padding rows of the last batch
+    lfb = ol.construct_frame_level_lfb([[feats[:10]], [feats[10:]]], frames)
+    assert sorted(lfb) == [0, 1, 2] and len(lfb[2]) == 33
+    assert ol.charades_window(200, 20, 2) == (80, 320)
+    out = ol.sample_lfb_charades(lfb[2], 200, 20, 2, 4)
+    want = [lfb[2][f] for f in sorted(lfb[2]) if 80 <= f <= 320][:20]
+    assert len(want) == 20 and np.array_equal(out, np.array(want))
+    # clip near the start: fewer than `window` frames, zero tail
+    out = ol.sample_lfb_charades(lfb[1], 10, 20, 2, 4)
+    have = [f for f in sorted(lfb[1]) if -110 <= f <= 130]
+    assert np.array_equal(out[:len(have)], np.array([lfb[1][f] for f in have])) and np.all(out[len(have):] == 0)

@@ -1406,6 +1406,21 @@ class Engine(object):
             hip.call("vlfb_cast", hip.ptr(src), hip.F32, root.ptr(), self.code, src.numel())
             torch.cuda.current_stream().synchronize()
 
+    def blob_tensor(self, name):
+        """(device tensor, dtype code) behind a blob, for device-side producers / consumers that skip
+        the host (the feature bank appends `box_pooled` from it and samples into `lfb`).  Row-major
+        blobs only: (rows, C[,1,1,1]) activations and (R, K, D) banks are stored exactly as shaped."""
+        b = self.env[name].root
+        if getattr(b, "dead", False):
+            raise KeyError("blob %r was fused away" % name)
+        if getattr(b, "pad_c", None):
+            raise KeyError("blob %r is stored padded; use feed()/fetch()" % name)
+        spatial = b.shape[2:] if b.caxis == 1 else ()
+        if any(int(d) != 1 for d in spatial):
+            raise KeyError("blob %r is stored channels-last; use feed()/fetch()" % name)
+        t = b.tensor[:b.numel]
+        return t, hip.dtype_code(t.dtype)
+
     def fetch(self, name):
         """blob (or its gradient with suffix '_grad') as a float32 numpy array in the reference layout"""
         grad = False

@@ -63,6 +63,10 @@ class PoolDesc(C.Structure):
         "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw")]
 
 
+class LfbDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_videos", "n_steps", "capacity", "dim", "dtype")]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _SIGS = {
@@ -110,6 +114,11 @@ _SIGS = {
                                     C.c_float, _P]),
     "vlfb_sgd_update": (C.c_int, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
     "vlfb_scale_inplace": (C.c_int, [_P, _I64, C.c_float, _P]),
+    "vlfb_lfb_bank_bytes": (_I64, [C.POINTER(LfbDesc)]),
+    "vlfb_lfb_append": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, C.c_int, _P, _I64, _P, _P]),
+    "vlfb_lfb_sample_window": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, C.c_int, C.c_uint64,
+                                         _P, C.c_int, _P]),
+    "vlfb_lfb_sample_compact": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

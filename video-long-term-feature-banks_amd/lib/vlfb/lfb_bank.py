@@ -1,0 +1,195 @@
+"""The long-term feature bank as a device tensor.
+
+Reference: tools/lfb_loader.py builds `{video: {sec: [feat, ...]}}` (AVA, :79-112) or
+`{video: {frame: feat}}` (Charades/EPIC, :49-76) on the host from `box_pooled` / `pool5` fetched
+after every inference iteration, pickles it, and the dataset classes sample a window per clip in
+NumPy (lib/datasets/ava.py:300-323, charades.py:251-276) -- 2.46 MB per RoI through the blob queue
+every training iteration.
+
+Here the bank lives in HBM for the whole job (AVA train: 235 videos x 900 s x 16 slots x 2048 bf16
+= 13.9 GB of the 288 GB), `box_pooled` is appended to it by a kernel without leaving the device,
+and the sampled (R, K, 2048) block is written by a kernel straight into the model's `lfb` input.
+`from_reference` / `to_reference` convert to and from the reference's pickled dictionaries.
+
+All compute goes through libvlfb_hip.so (vlfb_lfb_*); there is no host fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from vlfb import hip
+
+FPS = 24   # cfg.CHARADES.FPS (lib/datasets/charades.py:43)
+
+
+class DeviceBank(object):
+    """bank[video][step][slot][dim] + count[video][step] on one GPU.
+
+    `step_base` is subtracted from the reference's time keys (AVA seconds start at 902);
+    `video_ids` optionally maps the reference's video keys to dense rows."""
+
+    def __init__(self, n_videos, n_steps, capacity, dim=2048, dtype="bf16", device="cuda:0", step_base=0,
+                 video_ids=None):
+        hip.lib()
+        self.device = torch.device(device)
+        self.code = hip.BF16 if dtype in ("bf16", torch.bfloat16) else hip.F32
+        self.desc = hip.LfbDesc(int(n_videos), int(n_steps), int(capacity), int(dim), self.code)
+        nbytes = hip.lib().vlfb_lfb_bank_bytes(C.byref(self.desc))
+        if nbytes <= 0:
+            raise hip.VlfbError("lfb bank: bad geometry %r" % ((n_videos, n_steps, capacity, dim),))
+        self.bank = torch.zeros(int(n_videos) * int(n_steps) * int(capacity) * int(dim), device=self.device,
+                                dtype=hip.TORCH_DTYPE[self.code])
+        self.count = torch.zeros(int(n_videos) * int(n_steps), device=self.device, dtype=torch.int32)
+        self.dropped = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self.step_base = int(step_base)
+        self.video_row = None if video_ids is None else {v: i for i, v in enumerate(video_ids)}
+        self.video_ids = None if video_ids is None else list(video_ids)
+
+    # ---- geometry --------------------------------------------------------------------------------
+    n_videos = property(lambda self: self.desc.n_videos)
+    n_steps = property(lambda self: self.desc.n_steps)
+    capacity = property(lambda self: self.desc.capacity)
+    dim = property(lambda self: self.desc.dim)
+
+    def _rows_of(self, videos):
+        v = np.asarray(videos).astype(np.int64).reshape(-1)
+        if self.video_row is None:
+            return v
+        return np.array([self.video_row.get(int(x), -1) if x >= 0 else -1 for x in v], dtype=np.int64)
+
+    def _dev_i32(self, arr):
+        return torch.as_tensor(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device)
+
+    # ---- construction ----------------------------------------------------------------------------
+    def append(self, feats, videos, steps):
+        """feats: (R, dim[,1,1,1]) device tensor (fp32 / bf16) or host array; videos/steps: (R,) reference
+        keys (a negative video marks a padding row)."""
+        if not torch.is_tensor(feats):
+            feats = torch.as_tensor(np.asarray(feats, dtype=np.float32))
+        feats = feats.to(self.device).reshape(feats.shape[0], -1).contiguous()
+        assert feats.shape[1] == self.dim, "append: feature width %d, bank dim %d" % (feats.shape[1], self.dim)
+        rows = feats.shape[0]
+        keys = np.stack([self._rows_of(videos), np.asarray(steps).astype(np.int64).reshape(-1) - self.step_base], axis=1)
+        assert keys.shape == (rows, 2)
+        kd = self._dev_i32(keys)
+        hip.call("vlfb_lfb_append", C.byref(self.desc), hip.ptr(self.bank), hip.ptr(self.count), hip.ptr(feats),
+                 hip.dtype_code(feats.dtype), hip.ptr(kd), rows, hip.ptr(self.dropped))
+        torch.cuda.current_stream().synchronize()     # kd / feats may be temporaries
+
+    def append_ava(self, box_pooled, metadata):
+        """one inference iteration of construct_ava_lfb (lfb_loader.py:79-112): metadata rows are
+        [video_id, sec, ...] as floats"""
+        md = np.asarray(metadata, dtype=np.float64)
+        self.append(box_pooled, np.round(md[:, 0]).astype(np.int64), np.round(md[:, 1]).astype(np.int64))
+
+    def append_frames(self, pool5, frame_keys, sample_freq):
+        """one inference iteration of construct_frame_level_lfb (lfb_loader.py:49-76): frame_keys are
+        (video, frame) pairs with (frame + 1) % sample_freq == 0 (charades.py:233-248); rows of
+        `pool5` beyond len(frame_keys) are padding"""
+        fk = np.asarray(frame_keys, dtype=np.int64).reshape(-1, 2)
+        rows = pool5.shape[0]
+        vids = np.full(rows, -1, dtype=np.int64)
+        steps = np.zeros(rows, dtype=np.int64)
+        n = min(rows, fk.shape[0])
+        assert np.all((fk[:n, 1] + 1) % sample_freq == 0), "frame keys must be LFB frames"
+        vids[:n] = fk[:n, 0]
+        steps[:n] = (fk[:n, 1] + 1) // sample_freq - 1
+        self.append(pool5, vids, steps + self.step_base)
+
+    def check_no_drops(self):
+        n = int(self.dropped.item())
+        if n:
+            raise hip.VlfbError("lfb bank: %d features did not fit (capacity %d per step, or key out of range)"
+                                % (n, self.capacity))
+
+    def counts(self):
+        return self.count.view(self.n_videos, self.n_steps).cpu().numpy()
+
+    # ---- sampling --------------------------------------------------------------------------------
+    def _out(self, out, shape, dtype):
+        if out is None:
+            return torch.empty(shape, device=self.device, dtype=dtype or hip.TORCH_DTYPE[self.code])
+        assert out.is_contiguous() and out.numel() == int(np.prod(shape)), "sample: output tensor has the wrong size"
+        return out
+
+    def sample_window(self, videos, secs, sample_ids, window, max_per_step, seed, out=None, out_dtype=None):
+        """AVA (ava.py:300-323): -> (R, window*max_per_step, dim).  `sample_ids` name the random draw
+        (e.g. iteration * batch + clip); RoIs of one clip pass the same id and get the same sample."""
+        rows = len(videos)
+        q = np.stack([self._rows_of(videos), np.asarray(secs).astype(np.int64).reshape(-1) - self.step_base,
+                      np.asarray(sample_ids).astype(np.int64).reshape(-1) & 0x7FFFFFFF], axis=1)
+        qd = self._dev_i32(q)
+        out = self._out(out, (rows, window * max_per_step, self.dim), out_dtype)
+        hip.call("vlfb_lfb_sample_window", C.byref(self.desc), hip.ptr(self.bank), hip.ptr(self.count), hip.ptr(qd),
+                 rows, int(window), int(max_per_step), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), hip.ptr(out),
+                 hip.dtype_code(out.dtype))
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def sample_frames(self, videos, center_frames, window, clips_per_second, out=None, out_dtype=None):
+        """Charades (charades.py:251-276): -> (N, window, dim), the first `window` bank frames inside
+        [begin, end] around each clip centre, packed to the front"""
+        rows = len(videos)
+        sample_freq = FPS // int(clips_per_second)
+        secs = int(window) // int(clips_per_second)
+        c = np.asarray(center_frames, dtype=np.float64).reshape(-1)
+        begin = np.round(c - (float(secs) / 2.0 * FPS)).astype(np.int64)
+        end = begin + secs * FPS
+        # bank step t holds frame sample_freq*(t+1)-1: frames in [begin, end]  <=>  t in [lo, hi]
+        lo = -((-(begin + 1)) // sample_freq) - 1
+        hi = (end + 1) // sample_freq - 1
+        q = np.stack([self._rows_of(videos), lo, hi], axis=1)
+        qd = self._dev_i32(q)
+        out = self._out(out, (rows, int(window), self.dim), out_dtype)
+        hip.call("vlfb_lfb_sample_compact", C.byref(self.desc), hip.ptr(self.bank), hip.ptr(self.count), hip.ptr(qd),
+                 rows, int(window), hip.ptr(out), hip.dtype_code(out.dtype))
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    # ---- interchange with the reference's pickles -----------------------------------------------
+    @classmethod
+    def from_reference(cls, lfb, capacity=None, dtype="bf16", device="cuda:0", frame_level=False, sample_freq=None):
+        """`lfb` as tools/lfb_loader.py writes it: {video: {sec: [feat, ...]}} or, frame_level,
+        {video: {frame: feat}}"""
+        vids = sorted(lfb)
+        if frame_level:
+            assert sample_freq, "frame-level banks need sample_freq (FPS // LFB_CLIPS_PER_SECOND)"
+            n_steps = max([(max(f) + 1) // sample_freq for f in lfb.values() if len(f)] + [1])
+            first = next(iter(next(v for v in lfb.values() if len(v)).values()))
+            bank = cls(len(vids), n_steps, 1, int(np.size(first)), dtype, device, 0, vids)
+            for v in vids:
+                frames = sorted(lfb[v])
+                if frames:
+                    bank.append_frames(torch.as_tensor(np.stack([np.ravel(lfb[v][f]) for f in frames]).astype(np.float32)),
+                                       [(v, f) for f in frames], sample_freq)
+            return bank
+        secs = [s for v in lfb.values() for s in v]
+        base, n_steps = (min(secs), max(secs) - min(secs) + 1) if secs else (0, 1)
+        cap = capacity or max([len(l) for v in lfb.values() for l in v.values()] + [1])
+        first = next(l[0] for v in lfb.values() for l in v.values() if len(l))
+        bank = cls(len(vids), n_steps, cap, int(np.size(first)), dtype, device, base, vids)
+        for v in vids:
+            feats, ks = [], []
+            for s in sorted(lfb[v]):
+                for f in lfb[v][s]:
+                    feats.append(np.ravel(f))
+                    ks.append(s)
+            if feats:
+                bank.append(torch.as_tensor(np.stack(feats).astype(np.float32)), [v] * len(ks), ks)
+        bank.check_no_drops()
+        return bank
+
+    def to_reference(self, frame_level=False, sample_freq=None):
+        cnt = self.counts()
+        data = self.bank.view(self.n_videos, self.n_steps, self.capacity, self.dim).float().cpu().numpy()
+        out = {}
+        for vi in range(self.n_videos):
+            key = self.video_ids[vi] if self.video_ids is not None else vi
+            out[key] = {}
+            for s in np.nonzero(cnt[vi])[0]:
+                if frame_level:
+                    out[key][int(sample_freq * (s + 1) - 1)] = data[vi, s, 0].copy()
+                else:
+                    out[key][int(s + self.step_base)] = [data[vi, s, k].copy() for k in range(cnt[vi, s])]
+        return out
