@@ -313,6 +313,8 @@ int vlfb_scale_inplace(float* x, int64_t n, float s, vlfb_stream_t stream);
 typedef struct vlfb_lfb_desc {
   int32_t n_videos, n_steps, capacity, dim;
   int32_t dtype;
+  int32_t step_base;   /* reference time key of step 0 (AVA seconds start at 902); only the sampling
+                          draw depends on it, so that it is a function of the reference's own keys */
 } vlfb_lfb_desc;
 int64_t vlfb_lfb_bank_bytes(const vlfb_lfb_desc* d);
 /* Append `rows` features (feats [rows][dim] of feat_dtype) under keys [rows][2] = {video, step}.

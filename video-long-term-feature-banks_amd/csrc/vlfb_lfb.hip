@@ -58,7 +58,7 @@ __device__ void row_copy(void* dst, int ddt, long long doff, const void* src, in
 }
 
 struct BankP {
-  int n_videos, n_steps, capacity, dim, dtype;
+  int n_videos, n_steps, capacity, dim, dtype, step_base;
 };
 
 __device__ __forceinline__ bool key_ok(const BankP& b, int video, int step) {
@@ -123,10 +123,11 @@ __global__ void lfb_sample_window_kernel(BankP b, const char* __restrict__ bank,
   const int m = n < K ? n : K;
   __shared__ int sel[64];
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint32_t hi = lfb_key(seed, sid, (uint32_t)video, (uint32_t)step, (uint32_t)i);
+    const uint32_t tkey = (uint32_t)(step + b.step_base);      // the reference's time key (e.g. the AVA second)
+    const uint32_t hi = lfb_key(seed, sid, (uint32_t)video, tkey, (uint32_t)i);
     int rank = 0;
     for (int q = 0; q < n; ++q) {
-      const uint32_t hq = lfb_key(seed, sid, (uint32_t)video, (uint32_t)step, (uint32_t)q);
+      const uint32_t hq = lfb_key(seed, sid, (uint32_t)video, tkey, (uint32_t)q);
       rank += (hq < hi) || (hq == hi && q < i);
     }
     if (rank < m) sel[rank] = i;
@@ -171,6 +172,7 @@ int check_desc(const vlfb_lfb_desc* d, BankP* b) {
   VLFB_REQUIRE(d->n_videos > 0 && d->n_steps > 0 && d->capacity > 0 && d->dim > 0, "lfb: empty bank geometry");
   VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "lfb: bank dtype must be f32 or bf16");
   b->n_videos = d->n_videos; b->n_steps = d->n_steps; b->capacity = d->capacity; b->dim = d->dim; b->dtype = d->dtype;
+  b->step_base = d->step_base;
   return VLFB_OK;
 }
 

@@ -64,7 +64,7 @@ class PoolDesc(C.Structure):
 
 
 class LfbDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n_videos", "n_steps", "capacity", "dim", "dtype")]
+    _fields_ = [(n, C.c_int32) for n in ("n_videos", "n_steps", "capacity", "dim", "dtype", "step_base")]
 
 
 _P = C.c_void_p

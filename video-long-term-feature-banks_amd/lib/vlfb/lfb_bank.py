@@ -34,7 +34,7 @@ class DeviceBank(object):
         hip.lib()
         self.device = torch.device(device)
         self.code = hip.BF16 if dtype in ("bf16", torch.bfloat16) else hip.F32
-        self.desc = hip.LfbDesc(int(n_videos), int(n_steps), int(capacity), int(dim), self.code)
+        self.desc = hip.LfbDesc(int(n_videos), int(n_steps), int(capacity), int(dim), self.code, int(step_base))
         nbytes = hip.lib().vlfb_lfb_bank_bytes(C.byref(self.desc))
         if nbytes <= 0:
             raise hip.VlfbError("lfb bank: bad geometry %r" % ((n_videos, n_steps, capacity, dim),))
