@@ -32,6 +32,9 @@ def test_train_net_style_loop_through_the_facade():
         workspace.RunNet(model.net)
         losses.append(float(workspace.FetchBlob("gpu_0/loss")))
     assert all(np.isfinite(losses))
+    # NaN guard: every step's loss from the device ring with one sync, then nothing until the next step
+    import utils.misc as misc
+    assert np.allclose(misc.check_nan_losses(), losses, rtol=0, atol=0) and misc.check_nan_losses(model) == []
     assert not np.allclose(workspace.FetchBlob("gpu_0/pred_w"), w0)                      # head is trained
     assert np.array_equal(workspace.FetchBlob("gpu_0/res4_2_branch2a_w"), frozen0)        # FREEZE_BACKBONE
     assert workspace.FetchBlob("gpu_0/pred_w_momentum").shape == (157, 2560)
@@ -41,6 +44,10 @@ def test_train_net_style_loop_through_the_facade():
     new = np.random.default_rng(0).standard_normal((157, 2560)).astype(np.float32)
     workspace.FeedBlob("gpu_0/pred_w", new)
     assert np.array_equal(workspace.FetchBlob("gpu_0/pred_w"), new)
+    workspace.FeedBlob("gpu_0/pred_b", np.full(157, np.nan, np.float32))
+    workspace.RunNet(model.net)
+    with pytest.raises(FloatingPointError):
+        misc.check_nan_losses(model)
     workspace.ResetWorkspace()
 
 

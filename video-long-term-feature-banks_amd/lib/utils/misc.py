@@ -21,3 +21,27 @@ def get_crop_size(split):
 def unscope_name(blob_name):
     blob_name = str(blob_name)
     return blob_name[blob_name.rfind(_SCOPE_SEP) + 1:]
+
+
+def check_nan_losses(model=None):
+    """NaN guard of the training loop (reference misc.py:50-58, called every iteration from
+    tools/train_net.py:160 -- one FetchBlob, i.e. one host sync, per GPU per step).
+
+    Here the loss step keeps its last 64 values in a device ring, so the loop may call this every
+    N <= 64 iterations and still see every step's loss with a single sync.  The reference logs and
+    `os._exit(0)`s; a library raises instead.  Returns the losses it inspected."""
+    import math
+    if model is not None:
+        engines = [model.engine]
+    else:
+        from vlfb import workspace
+        engines = list(workspace._engines.values())
+    seen = []
+    for eng in engines:
+        if eng is None:
+            continue
+        losses = eng.recent_losses()
+        seen.extend(losses)
+        if any(math.isnan(v) for v in losses):
+            raise FloatingPointError("NaN losses on %s" % (getattr(eng.model, "scope", "") or "gpu_0/"))
+    return seen

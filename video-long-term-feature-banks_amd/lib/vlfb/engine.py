@@ -633,6 +633,9 @@ class FCStep(Step):
                 supports_add=False, supports_mask=False)
 
 
+LOSS_RING = 64
+
+
 class LossStep(Step):
     """Sigmoid + SigmoidCrossEntropyLoss (resnet_video.py:333-338); test mode: Sigmoid only"""
 
@@ -648,14 +651,32 @@ class LossStep(Step):
     def setup(self):
         self.rows, self.cols = self.logits.shape[0], self.logits.shape[1]
         self.dlogits = None
+        self.ring = None
+        self.ring_pos = 0
         if self.loss is not None:
             self.dlogits = torch.empty(self.rows * self.cols, device=self.eng.device, dtype=torch.float32)
+            # the last LOSS_RING losses stay on the device: the NaN guard (utils.misc.check_nan_losses)
+            # reads them in one go every few iterations instead of syncing on `loss` every step
+            self.ring = torch.zeros(LOSS_RING, device=self.eng.device, dtype=torch.float32)
 
     def fwd(self):
         hip.call("vlfb_sigmoid_ce", self.logits.ptr(), self.labels.ptr() if self.labels is not None else None,
                  self.prob.ptr() if self.prob is not None else None,
                  self.loss.ptr() if self.loss is not None else None, hip.ptr(self.dlogits), self.rows, self.cols,
                  self.scale)
+        if self.ring is not None:
+            self.ring.narrow(0, self.ring_pos % LOSS_RING, 1).copy_(self.loss.root.tensor.narrow(0, 0, 1), non_blocking=True)
+            self.ring_pos += 1
+
+    def recent_losses(self):
+        """losses of the (at most LOSS_RING) forward passes since the previous call, oldest first; one sync"""
+        n = min(self.ring_pos, LOSS_RING)
+        if self.ring is None or n == 0:
+            return []
+        host = self.ring.cpu().numpy()
+        start = self.ring_pos - n
+        self.ring_pos = 0
+        return [float(host[(start + i) % LOSS_RING]) for i in range(n)]
 
     def bwd(self):
         self.logits.root.slot.contribute_alias(self.dlogits)
@@ -1478,6 +1499,14 @@ class Engine(object):
             off, cnt, _ = self.train_layout[n]
             segments.append((off, cnt, index[id(self.param_step[n])]))
         self.comm = GradComm(self.flat_grad, segments, int(bucket_mb) << 20)
+
+    def recent_losses(self):
+        """losses since the last call (device ring of the loss step; a single host sync)"""
+        out = []
+        for st in self.steps:
+            if isinstance(st, LossStep):
+                out.extend(st.recent_losses())
+        return out
 
     def scale_momentum(self, factor):
         hip.call("vlfb_scale_inplace", hip.ptr(self.flat_mom), self.flat_mom.numel(), float(factor))
