@@ -196,3 +196,35 @@ def test_test_mode_forward_and_lfb_inference():
         key = "box_pooled" if infer_only else "prob"
         got = eng.fetch(key)
         assert rel(got, blobs[key].numpy().reshape(got.shape)) < 1e-3
+
+
+def test_test_crop_256_shapes_nonlocal_4096x1024():
+    """TEST.CROP_SIZE 256: spatial x8/7, so the grouped res3 non-local block
+    attends 4096 x 1024 positions and the head pool is 16x16; forward parity in test mode"""
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb.engine import Engine
+    from oracle import model as om
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TEST.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 8,
+                                          "TEST.VIDEO_LENGTH", 8, "TEST.CROP_SIZE", 256])
+    inputs = om.synth_inputs(cfg, 1, "test", seed=4, crop=256, frames=8)
+    params = om.synth_params(cfg, seed=4)
+    model = ModelBuilder(train=False, split="test", name="test")
+    model.build_model(suffix="_test")
+    eng = Engine(model, "fp32")
+    names = list(model.input_blob_names)
+    eng.plan(collections.OrderedDict((n, inputs[n[:-5]].shape) for n in names))
+    att = [s for s in eng.steps if type(s).__name__ == "AttentionStep"]
+    # 8 frames -> 4 at res3 -> one group of 4 frames: 4*32*32 queries x 4*16*16 keys
+    assert (att[0].theta.shape[2], att[0].phi.shape[2]) == (4096, 1024)
+    eng.feed_params({k: v for k, v in params.items() if k in eng.param_views})
+    for n in names:
+        eng.feed(n, inputs[n[:-5]])
+    eng.forward()
+    torch.cuda.synchronize()
+    blobs, _ = om.run(cfg, {k: v for k, v in params.items() if k in eng.param_views}, inputs, "test",
+                      torch.float64, False, None)
+    for key in ("prob", "pool5"):
+        got = eng.fetch(key)
+        assert rel(got, blobs[key].numpy().reshape(got.shape)) < 1e-3, key
