@@ -311,8 +311,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // =============================================================================================
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
 // =============================================================================================
-template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW>
+template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW,
+          int ST = 2>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
+  // ST = LDS stages of the k-loop ring (tiles in flight = ST - 1, counted vmcnt on the oldest).
+  // Shipped instances use ST = 2.  Measured on MI355X: ST = 5 with 64-byte tile rows (four 16 KiB
+  // tiles in flight on the same 80 KiB) is 15-20 % SLOWER on the long-K res5 layers (561 vs 688
+  // TFLOP/s) -- the loop is bound by LDS-read + DMA-issue + MFMA phases that do not overlap inside a
+  // barrier-synchronised workgroup, not by DMA latency, and halving BK doubles the barriers.
   // NW = 4: waves 2 (m) x 2 (n), 64 x (BN/2) each.  NW = 8: waves 2 x 4, 64 x (BN/4) each -- twice the
   // wavefronts per CU on the same LDS footprint (more latency hiding, 1.5x the LDS fragment reads).
   constexpr int NTHR = 64 * NW;
@@ -407,6 +413,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
     if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed
     __syncthreads();
   };
+  // wait until at most `newer` tiles issued after the wanted one are still in flight (loads retire
+  // in order, so the wanted tile and everything older -- incl. the PRE rows -- have landed)
+  constexpr int LPT = A_IT + B_IT;          // DMA instructions per lane per tile
+  auto ring_wait = [&](int newer) {
+    if (newer >= 3 && ST >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+    else if (newer == 2 && ST >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (newer == 1 && ST >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
 
   f32x4_v acc[FN][FM];
 #pragma unroll
@@ -438,14 +453,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
     }
   }
 
-  load_tile(0, 0);
+  static_assert(ST >= 2 && ST <= 5 && 3 * LPT < 64, "ring depth / vmcnt immediate");
+#pragma unroll
+  for (int s0 = 0; s0 < ST - 1; ++s0)
+    if (s0 < ktiles) load_tile(s0, s0);
   store_tile(0);
-  tile_ready();
 
+  int cur = 0, nxt = ST - 1;              // ring slots of tile kt and of tile kt + ST - 1
   for (int kt = 0; kt < ktiles; ++kt) {
-    const bool more = kt + 1 < ktiles;
-    if (more) load_tile(kt + 1, (kt + 1) & 1);
-    const char* xa = smem + (kt & 1) * BUF;
+    const int ahead = ktiles - 1 - kt;    // tiles after kt
+    if (GLDS) ring_wait(ahead < ST - 2 ? ahead : ST - 2);
+    // Bare barrier: __syncthreads() carries a workgroup fence that the compiler lowers to
+    // vmcnt(0), which would drain the ring.  Every wave has waited for ITS part of tile kt above and
+    // has consumed (lgkmcnt) its LDS reads of tile kt-1 before its last MFMAs, so after the barrier
+    // tile kt is complete and the slot of tile kt-1 may be refilled.
+    if (GLDS) asm volatile("s_barrier" ::: "memory");
+    else __syncthreads();
+    const bool more = kt + ST - 1 < ktiles;
+    if (more) load_tile(kt + ST - 1, nxt);
+    const char* xa = smem + cur * BUF;
     const char* wb = xa + BM * RB;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -459,9 +485,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) acc[j][i] = Mma<T>::mma(wf[j], xf[i], acc[j][i]);
     }
-    if (more) store_tile((kt + 1) & 1);
-    tile_ready();
+    if (!GLDS) {
+      if (more) store_tile(nxt);
+    }
+    cur = cur + 1 == ST ? 0 : cur + 1;
+    nxt = nxt + 1 == ST ? 0 : nxt + 1;
   }
+  __syncthreads();                        // all waves are done with the last tile: LDS is reused below
 
   // ---- epilogue ------------------------------------------------------------------------------
   if (p.vec_epi) {
