@@ -893,22 +893,26 @@ __device__ __forceinline__ bf16x8_v tr_frag(const char* tile, int c0, int ks, in
   return u.v;
 }
 
-template <typename OutT, int BP, int BQ, bool IDENT, bool PACKW>
-__global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
+template <typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
+  // NW = 4: waves 2 (p) x 2 (q).  NW = 8: waves 2 x 4 on the same tile -- twice the wavefronts per CU.
   typedef bf16_t T;
+  constexpr int NTHR = 64 * NW;
+  constexpr int NWQ = NW / 2;
   constexpr int BK = 64;                         // positions per k-tile
   constexpr int RSP = BP * 2, RSQ = BQ * 2;      // LDS row bytes (one position)
   constexpr int CP = BP / 8, CQ = BQ / 8;        // 16-byte chunks per row
-  constexpr int PI = BK * CP / kThreads, QI = BK * CQ / kThreads;   // DMA pieces per thread
-  constexpr int RPP_P = kThreads / CP, RPP_Q = kThreads / CQ;       // rows per pass
-  constexpr int WP = BP / 2, WQ = BQ / 2;
+  constexpr int PI = BK * CP / NTHR, QI = BK * CQ / NTHR;   // DMA pieces per thread
+  constexpr int RPP_P = NTHR / CP, RPP_Q = NTHR / CQ;       // rows per pass
+  constexpr int WP = BP / 2, WQ = BQ / NWQ;
+  static_assert(PI >= 1 && QI >= 1 && WQ >= 16, "tile too small for this many waves");
   constexpr int FP = WP / 16, FQ = WQ / 16;
   constexpr int BUF = BK * (RSP + RSQ);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wp = wave >> 1, wq = wave & 1;
+  const int wp = wave / NWQ, wq = wave % NWQ;
   const int l15 = lane & 15, g = lane >> 4;
 
   const int nwg = p.tiles_m * p.tiles_n;
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
       const int k = kb + prow + RPP_P * i;
-      glds16(src_or_zero(Pb, ((long long)k * p.ldp + pch) * 2, pok && k < kend), pt + i * 4096);
+      glds16(src_or_zero(Pb, ((long long)k * p.ldp + pch) * 2, pok && k < kend), pt + i * (NTHR * 16));
     }
 #pragma unroll
     for (int i = 0; i < QI; ++i) {
@@ -980,7 +984,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
         }
         qrow_jump(p, qcur[i], jump, qtap);
       }
-      glds16(src, qt + i * 4096);
+      glds16(src, qt + i * (NTHR * 16));
     }
   };
 
@@ -991,9 +995,10 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
     for (int b = 0; b < FP; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 
   if (ktiles > 0) load_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   for (int kt = 0; kt < ktiles; ++kt) {
+    // own DMA of tile kt landed, then a bare barrier (see gemm_nt_kernel): tile kt is complete and
+    // the other buffer, last read for tile kt-1, may be refilled
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (kt + 1 < ktiles) load_tile(kt + 1, (kt + 1) & 1);
     const char* pt = smem + (kt & 1) * BUF;
     const char* qt = pt + BK * RSP;
@@ -1010,8 +1015,6 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_tr_kernel(const GP p) {
         for (int i = 0; i < FP; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[j][i], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds qq = qb + 0..3 for output row pp (same as gemm_tn_kernel) ----------
@@ -1241,6 +1244,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   }
   pl->pre = 0;
   pl->threads = kThreads;
+  if (d->mode == VLFB_CONV_WGRAD && pl->tn_tr && pl->bm == 128 && pl->bn == 128) {
+    static const int env_tw = [] { const char* e = getenv("VLFB_TN_WAVES"); return e ? atoi(e) : 8; }();
+    if (env_tw == 8) pl->threads = 512;
+  }
   if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16 && pl->bn == 128 && pl->rb == 128) {
     static const int env_nw = [] { const char* e = getenv("VLFB_NT_WAVES"); return e ? atoi(e) : 8; }();
     if (env_nw == 8) pl->threads = 512;
@@ -1305,7 +1312,8 @@ void launch_tn(const Plan& pl, hipStream_t s) {
 
 template <typename OutT, bool IDENT, bool PACKW>
 void launch_tn_tr(const Plan& pl, hipStream_t s) {
-  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW>, pl, s);
+  if (pl.bm == 128 && pl.bn == 128 && pl.threads == 512) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW, 8>, pl, s);
+  else if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW>, pl, s);
   else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 64, 128, IDENT, PACKW>, pl, s);
   else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<OutT, 128, 64, IDENT, PACKW>, pl, s);
   else launch_k(gemm_tn_tr_kernel<OutT, 64, 64, IDENT, PACKW>, pl, s);
