@@ -1051,15 +1051,17 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   }
 }
 
-// split-K slab reduction: one wave covers 64 float4 columns, the G waves of a workgroup stride over
-// the splits (4 loads in flight each) and fold through LDS; wave 0 applies the epilogue
-template <typename OutT, int G>
-__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale,
+// split-K slab reduction: a workgroup owns CL float4 columns (CL*16 contiguous bytes of every slab
+// row); its G lane groups stride over the splits (4 loads in flight each) and fold through LDS; group
+// 0 applies the epilogue.  Many splits (skinny weights: few columns, hundreds of slabs) use narrow
+// 16-column workgroups so the grid still covers the chip.
+template <typename OutT, int G, int CL>
+__global__ __launch_bounds__(CL * G) void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale,
                                                               long long n, int ldo, int splits, float alpha,
                                                               int accumulate) {
-  __shared__ float4 part[G > 1 ? (G - 1) * 64 : 1];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long long i = ((long long)blockIdx.x * 64 + lane) * 4;
+  __shared__ float4 part[G > 1 ? (G - 1) * CL : 1];
+  const int lane = threadIdx.x % CL, g = threadIdx.x / CL;
+  const long long i = ((long long)blockIdx.x * CL + lane) * 4;
   float4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < n) {
     const float* src = ws + i;
@@ -1078,12 +1080,12 @@ __global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* ws, c
     }
   }
   if (G > 1) {
-    if (g > 0) part[(g - 1) * 64 + lane] = s;
+    if (g > 0) part[(g - 1) * CL + lane] = s;
     __syncthreads();
     if (g == 0) {
 #pragma unroll
       for (int j = 0; j < G - 1; ++j) {
-        float4 t = part[j * 64 + lane];
+        float4 t = part[j * CL + lane];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
     }
@@ -1202,12 +1204,14 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     const int bk = 128 / es;
     int splits = d->splits;
     if (splits <= 0) {
-      // Two 64 KiB-LDS workgroups fit a CU, so one "wave" of the grid is 512 workgroups.  Pick the
-      // split count that fills whole waves best (every extra split costs one more fp32 slab
-      // pass), keeping at least 8 k-tiles of work per split.
+      // Pick the split count that fills whole rounds of `slots` workgroups best (every extra split
+      // costs one more fp32 slab pass), keeping at least 8 k-tiles of work per split.  Two 64 KiB-LDS
+      // workgroups fit a CU (512 slots), but these launches share the chip with the dgrad chain of
+      // the main stream: rounds of 256 (one workgroup per CU, half the slab traffic) measured best
+      // end to end (336 vs 331 clips/s at 512, 323 at 128).
       const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
-      static const int env_slots = [] { const char* e = getenv("VLFB_WGRAD_SLOTS"); return e ? atoi(e) : 512; }();
-      const long long slots = env_slots > 0 ? env_slots : 512;
+      static const int env_slots = [] { const char* e = getenv("VLFB_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
+      const long long slots = env_slots > 0 ? env_slots : 256;
       long long maxs = (M + 8 * bk - 1) / (8 * bk);
       const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
       if (maxs > slab_cap) maxs = slab_cap;
@@ -1392,15 +1396,14 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   if (pl.splits > 1) {
     const long long n = (long long)d->Cn * g.K;
     VLFB_REQUIRE(n % 4 == 0, "conv: split WGRAD output size must be a multiple of 4");
-    const unsigned grid = (unsigned)((n / 4 + 63) / 64);
     const int G = pl.splits >= 32 ? 16 : pl.splits >= 8 ? 4 : 1;
-#define VLFB_REDUCE(OT, GG)                                                                         \
-  hipLaunchKernelGGL((wgrad_reduce_kernel<OT, GG>), dim3(grid), dim3(64 * GG), 0, s, g.ws, g.O,    \
-                     rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate)
+#define VLFB_REDUCE(OT, GG, CC)                                                                       \
+  hipLaunchKernelGGL((wgrad_reduce_kernel<OT, GG, CC>), dim3((unsigned)((n / 4 + CC - 1) / CC)),     \
+                     dim3(CC * GG), 0, s, g.ws, g.O, rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate)
     if (d->out_dtype == VLFB_F32) {
-      if (G == 16) VLFB_REDUCE(float, 16); else if (G == 4) VLFB_REDUCE(float, 4); else VLFB_REDUCE(float, 1);
+      if (G == 16) VLFB_REDUCE(float, 16, 16); else if (G == 4) VLFB_REDUCE(float, 4, 64); else VLFB_REDUCE(float, 1, 64);
     } else {
-      if (G == 16) VLFB_REDUCE(bf16_t, 16); else if (G == 4) VLFB_REDUCE(bf16_t, 4); else VLFB_REDUCE(bf16_t, 1);
+      if (G == 16) VLFB_REDUCE(bf16_t, 16, 16); else if (G == 4) VLFB_REDUCE(bf16_t, 4, 64); else VLFB_REDUCE(bf16_t, 1, 64);
     }
 #undef VLFB_REDUCE
     return check_launch("wgrad reduce");
