@@ -71,6 +71,10 @@ def test_ava_lfb_graph_and_gradient_routing():
     x = eng.env["res2_0_branch2c_bn"]             # block output: read by next 2a conv + identity shortcut
     assert x.root.slot.expected == 2 and x.root.relu
     assert eng.env["data_train"].detached and not eng.env["lfb_train"].needs_grad
+    # solver: one weight-decay range over the whole flat bucket (no trainable '_bn' parameter: the
+    # affine pairs are frozen), i.e. a single fused launch
+    assert len(eng.wd_ranges) == 1 and eng.wd_ranges[0][0] == 0 and eng.wd_ranges[0][1] == eng.flat_param.numel()
+    assert eng.wd_ranges[0][2] == cfg.SOLVER.WEIGHT_DECAY
 
 
 def test_frozen_backbone_runs_backward_only_through_the_head():

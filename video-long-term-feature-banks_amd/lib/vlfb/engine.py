@@ -1225,6 +1225,18 @@ class Engine(object):
             self.param_views[n] = self.flat_param[off:off + cnt].view(shape)
         for n, (off, cnt, shape) in self.frozen_layout.items():
             self.param_views[n] = self.flat_frozen[off:off + cnt].view(shape)
+        # weight decay per parameter (model_builder_video.py:365-372): WEIGHT_DECAY_BN when the name
+        # contains '_bn', else WEIGHT_DECAY; neighbours with the same value share one solver launch
+        self.wd_ranges = []
+        names = list(self.train_layout)
+        for i, n in enumerate(names):
+            off = self.train_layout[n][0]
+            end = self.train_layout[names[i + 1]][0] if i + 1 < len(names) else ntrain
+            wd = float(cfg.SOLVER.WEIGHT_DECAY_BN if "_bn" in n else cfg.SOLVER.WEIGHT_DECAY)
+            if self.wd_ranges and self.wd_ranges[-1][2] == wd:
+                self.wd_ranges[-1][1] = end
+            else:
+                self.wd_ranges.append([off, end, wd])
         if self.train:
             self.flat_grad = torch.zeros_like(self.flat_param)
             self.flat_mom = torch.zeros_like(self.flat_param)
@@ -1518,9 +1530,10 @@ class Engine(object):
         if self.comm is not None:
             self.comm.wait()
         sol = cfg.SOLVER
-        # '_bn' parameters would use WEIGHT_DECAY_BN, but affine params are frozen (no gradient)
-        hip.call("vlfb_sgd_update", hip.ptr(self.flat_param), hip.ptr(self.flat_grad), hip.ptr(self.flat_mom),
-                 self.flat_param.numel(), self.lr, float(sol.WEIGHT_DECAY), float(sol.MOMENTUM), int(bool(sol.NESTEROV)))
+        for off, end, wd in self.wd_ranges:       # one launch unless a trainable '_bn' parameter exists
+            hip.call("vlfb_sgd_update", hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off,
+                     hip.ptr(self.flat_mom) + 4 * off, end - off, self.lr, wd, float(sol.MOMENTUM),
+                     int(bool(sol.NESTEROV)))
         self.refresh_operands()
         self.iteration += 1
 
