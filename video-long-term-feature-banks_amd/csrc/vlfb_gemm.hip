@@ -312,8 +312,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
 // =============================================================================================
 template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW,
-          int ST = 2>
+          int ST = 2, bool UT = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
+  // UT ("uniform tap", gathered convs whose taps span whole k-tiles: Cs * sizeof(T) % RB == 0, and for
+  // DGRAD unit stride): the filter tap of a k-tile is the same for the whole workgroup, so it is a
+  // scalar cursor advanced once per tile, the source pixel is  row base + scalar tap delta, and only
+  // the three padding compares stay per lane.  The generic path decodes the tap per lane and rebuilds
+  // the address from (n, t, h, w) every tile: measured 5 VALU instructions per MFMA on the 3x3 layers
+  // (SQ_INSTS_VALU 43.1 M vs SQ_INSTS_MFMA 7.2 M), more issue time than the MFMAs themselves.
+  static_assert(!UT || (!IDENT && !PACKW), "UT is for gathered, unpacked operands");
   // ST = LDS stages of the k-loop ring (tiles in flight = ST - 1, counted vmcnt on the oldest).
   // Shipped instances use ST = 2.  Measured on MI355X: ST = 5 with 64-byte tile rows (four 16 KiB
   // tiles in flight on the same 80 KiB) is 15-20 % SLOWER on the long-K res5 layers (561 vs 688
@@ -359,12 +366,30 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
 
   RowC arow[A_IT];
   bool aok[A_IT];
+  int upix[UT ? A_IT : 1];                 // UT: pixel index of the row at tap (0,0,0) (may be "negative")
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     int m = m0 + r0 + RPPS * i;
     aok[i] = m < p.M;
     if (!IDENT) arow[i] = decode_row(p, aok[i] ? m : 0);
+    if (UT) {
+      RowC& r = arow[i];                   // (t, h, w) become the tap-(0,0,0) source coordinates
+      if (!DGRAD) { r.t = r.t * p.st - p.pt; r.h = r.h * p.sh - p.ph; r.w = r.w * p.sw - p.pw; }
+      else { r.t += p.pt; r.h += p.ph; r.w += p.pw; }
+      upix[i] = ((r.n * p.Ts + r.t) * p.Hs + r.h) * p.Ws + r.w;
+    }
   }
+  // weight rows of this lane: byte offset of (row, chunk ccg) at k-tile 0 (weights are < 4 GiB)
+  unsigned boff[B_IT];
+  bool bok[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = n0 + r0 + RPPS * i;
+    bok[i] = n < p.Ncols;
+    boff[i] = (unsigned)(((long long)(bok[i] ? n : 0) * p.ldb + (long long)ccg * EPC) * (long long)sizeof(T));
+  }
+  // UT: scalar tap cursor of the NEXT tile to be fetched (tiles are fetched in order 0, 1, 2, ...)
+  int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
 
   uint4 ra[A_IT], rb[B_IT];
   const int ktiles = (p.K * (int)sizeof(T) + RB - 1) / RB;
@@ -372,23 +397,40 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   auto load_tile = [&](int kt, int buf) {
     const int kc = kt * CPRW + ccg;
     TapC tap;
-    if (IDENT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
+    if (IDENT || UT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
     else tap = decode_tap<T, PACKW>(p, kc);
     const bool kok = kc * EPC < p.K;
     if (GLDS) {
       char* xa = smem + buf * BUF + wave_u * 1024;
       char* wb = smem + buf * BUF + BM * RB + wave_u * 1024;
+      if (UT) {
+        const int sgn = DGRAD ? -1 : 1;
+        const int da = sgn * u_a * p.dt, db = sgn * u_b * p.dh, dc = sgn * u_c * p.dw;   // scalar
+        const int dpix = (da * p.Hs + db) * p.Ws + dc;
+        const int cbyte = (u_ci + ccg * EPC) * (int)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i)
-        glds16(PACKW ? packw_chunk_ptr<T>(p, Ab, aok[i], arow[i], tap)
-                     : act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc),
-               xa + i * (RPPS * RB));
+        for (int i = 0; i < A_IT; ++i) {
+          const bool ok = aok[i] && (unsigned)(arow[i].t + da) < (unsigned)p.Ts &&
+                          (unsigned)(arow[i].h + db) < (unsigned)p.Hs && (unsigned)(arow[i].w + dc) < (unsigned)p.Ws;
+          glds16(src_or_zero(Ab, (long long)(upix[i] + dpix) * (p.lda * (int)sizeof(T)) + cbyte, ok),
+                 xa + i * (RPPS * RB));
+        }
+        u_ci += RB / (int)sizeof(T);
+        if (u_ci >= p.Cs) {
+          u_ci = 0;
+          if (++u_c == p.kw) { u_c = 0; if (++u_b == p.kh) { u_b = 0; ++u_a; } }
+        }
+      } else {
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + r0 + RPPS * i;
-        glds16(src_or_zero(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols),
-               wb + i * (RPPS * RB));
+        for (int i = 0; i < A_IT; ++i)
+          glds16(PACKW ? packw_chunk_ptr<T>(p, Ab, aok[i], arow[i], tap)
+                       : act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc),
+                 xa + i * (RPPS * RB));
       }
+      const unsigned kbyte = (unsigned)kt * RB;
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i)
+        glds16(src_or_zero(Bb, (long long)(boff[i] + kbyte), kok && bok[i]), wb + i * (RPPS * RB));
     } else {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
@@ -1117,6 +1159,7 @@ struct Plan {
   int tn_tr;      // WGRAD: DMA + LDS transpose-read kernel (bf16)
   int pre;        // NT: prefetch residual / mask rows before the k-loop (thin-K, epilogue-bound launches)
   int threads;    // workgroup size (NT: 256 or 512)
+  int ut;         // NT: taps span whole k-tiles (and DGRAD has unit stride): scalar tap cursor
   dim3 grid;
   size_t lds;
   long long ws_elems;
@@ -1256,7 +1299,11 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     static const int env_nw = [] { const char* e = getenv("VLFB_NT_WAVES"); return e ? atoi(e) : 8; }();
     if (env_nw == 8) pl->threads = 512;
   }
+  pl->ut = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
+    static const int env_ut = [] { const char* e = getenv("VLFB_NT_UT"); return e ? atoi(e) : 1; }();
+    pl->ut = env_ut && !pl->ident && !d->pack_w && ((long long)d->Cs * es) % pl->rb == 0 &&
+             (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1));
     const long long ktiles = (K * es + pl->rb - 1) / pl->rb;
     const size_t buf = (size_t)(pl->bm + pl->bn) * pl->rb;
     pl->lds = (ktiles <= 1 ? 1 : 2) * buf;           // a single k-tile needs no second buffer
@@ -1282,6 +1329,18 @@ void launch_k(K kernel, const Plan& pl, hipStream_t s) {
   }
   hipLaunchKernelGGL(kernel, pl.grid, dim3(pl.threads), pl.lds, s, pl.gp);
 }
+// one tile shape, with or without the uniform-tap gather (UT only exists for gathered, unpacked operands)
+template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW>
+void launch_nt_shape(const Plan& pl, hipStream_t s) {
+  if constexpr (!IDENT && !PACKW) {
+    if (pl.ut) {
+      launch_k(gemm_nt_kernel<T, OutT, BM, BN, IDENT, DGRAD, PACKW, RB, PRE, NW, 2, true>, pl, s);
+      return;
+    }
+  }
+  launch_k(gemm_nt_kernel<T, OutT, BM, BN, IDENT, DGRAD, PACKW, RB, PRE, NW, 2, false>, pl, s);
+}
+
 template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
@@ -1293,17 +1352,17 @@ void launch_nt(const Plan& pl, hipStream_t s) {
     return;
   }
   if (BF && pl.threads == 512) {   // 8 waves per workgroup (bf16, 128-wide tiles)
-    if (CAN_PRE && pl.pre) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>, pl, s);
-    else launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>, pl, s);
+    if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>(pl, s);
+    else launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>(pl, s);
     return;
   }
   if (CAN_PRE && pl.pre) {
-    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>, pl, s);
-    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>, pl, s);
+    if (pl.bn == 128) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>(pl, s);
+    else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>(pl, s);
     return;
   }
-  if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, 4>, pl, s);
-  else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, 4>, pl, s);
+  if (pl.bn == 128) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, 4>(pl, s);
+  else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, 4>(pl, s);
 }
 template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn(const Plan& pl, hipStream_t s) {
