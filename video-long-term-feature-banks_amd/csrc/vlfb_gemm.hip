@@ -52,6 +52,7 @@ struct GP {
   int relu, bias_mode, accumulate;
   int tiles_m, tiles_n;
   int splits, kper;
+  unsigned a_bytes, b_bytes;   // NT: extent of one batch element of A / B (buffer descriptors)
   int vec_epi;        // NT: LDS-staged, fully coalesced epilogue is legal for this problem
   int epi;            // NT: the fp32 tile is staged through LDS in this many passes (1 or 2)
 };
@@ -144,6 +145,19 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)src,
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// The same copy through a buffer descriptor (buffer_load_dwordx4 ... offen lds): 32-bit byte offset
+// per lane, hardware range check -- a lane whose offset is >= num_records writes ZEROS to its LDS
+// slot (probed on MI355X, scratch/buf_probe.hip), so padding needs no zero page and no 64-bit address
+// arithmetic.  kOOB is the "this chunk is padding" offset; operands are required to be < 2 GiB.
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bufglds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           (int)voff, (int)soff, 0, 0);
 }
 
 // Branch-free predicated loads: the load always executes (from offset 0 of the operand when the
@@ -379,15 +393,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
       upix[i] = ((r.n * p.Ts + r.t) * p.Hs + r.h) * p.Ws + r.w;
     }
   }
-  // weight rows of this lane: byte offset of (row, chunk ccg) at k-tile 0 (weights are < 4 GiB)
-  unsigned boff[B_IT];
-  bool bok[B_IT];
+  // byte offset of (row, chunk ccg) at k-tile 0 for the weight rows (and, IDENT / UT, the
+  // activation rows) of this lane; kOOB when the row does not exist
+  unsigned boff[B_IT], aoff[(IDENT || UT) ? A_IT : 1];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const int n = n0 + r0 + RPPS * i;
-    bok[i] = n < p.Ncols;
-    boff[i] = (unsigned)(((long long)(bok[i] ? n : 0) * p.ldb + (long long)ccg * EPC) * (long long)sizeof(T));
+    boff[i] = n < p.Ncols ? (unsigned)(n * p.ldb + ccg * EPC) * (unsigned)sizeof(T) : kOOB;
   }
+  if (IDENT || UT) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int m = m0 + r0 + RPPS * i;
+      if (IDENT) aoff[i] = aok[i] ? (unsigned)(m * p.lda + ccg * EPC) * (unsigned)sizeof(T) : kOOB;
+      else aoff[i] = (unsigned)(upix[i] * p.lda + ccg * EPC) * (unsigned)sizeof(T);   // wraps for padding rows
+    }
+  }
+  const auto rsA = make_rsrc(Ab, p.a_bytes);
+  const auto rsB = make_rsrc(Bb, p.b_bytes);
   // UT: scalar tap cursor of the NEXT tile to be fetched (tiles are fetched in order 0, 1, 2, ...)
   int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
 
@@ -403,34 +426,47 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
     if (GLDS) {
       char* xa = smem + buf * BUF + wave_u * 1024;
       char* wb = smem + buf * BUF + BM * RB + wave_u * 1024;
+      // the last k-tile may end inside the row (K * sizeof(T) % RB != 0): chunks past K are padding
+      const unsigned kbyte = (unsigned)kt * RB;
       if (UT) {
         const int sgn = DGRAD ? -1 : 1;
         const int da = sgn * u_a * p.dt, db = sgn * u_b * p.dh, dc = sgn * u_c * p.dw;   // scalar
-        const int dpix = (da * p.Hs + db) * p.Ws + dc;
-        const int cbyte = (u_ci + ccg * EPC) * (int)sizeof(T);
+        const unsigned dbyte = (unsigned)(((da * p.Hs + db) * p.Ws + dc) * p.lda + u_ci) * (unsigned)sizeof(T);
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
           const bool ok = aok[i] && (unsigned)(arow[i].t + da) < (unsigned)p.Ts &&
                           (unsigned)(arow[i].h + db) < (unsigned)p.Hs && (unsigned)(arow[i].w + dc) < (unsigned)p.Ws;
-          glds16(src_or_zero(Ab, (long long)(upix[i] + dpix) * (p.lda * (int)sizeof(T)) + cbyte, ok),
-                 xa + i * (RPPS * RB));
+          bufglds16(rsA, ok ? aoff[i] + dbyte : kOOB, 0, xa + i * (RPPS * RB));
         }
         u_ci += RB / (int)sizeof(T);
         if (u_ci >= p.Cs) {
           u_ci = 0;
           if (++u_c == p.kw) { u_c = 0; if (++u_b == p.kh) { u_b = 0; ++u_a; } }
         }
+      } else if (IDENT) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) bufglds16(rsA, kok ? aoff[i] : kOOB, kbyte, xa + i * (RPPS * RB));
       } else {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-          glds16(PACKW ? packw_chunk_ptr<T>(p, Ab, aok[i], arow[i], tap)
-                       : act_chunk_ptr<T, IDENT, DGRAD>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc),
-                 xa + i * (RPPS * RB));
+        for (int i = 0; i < A_IT; ++i) {
+          unsigned off;
+          if (PACKW) {
+            const int ts = arow[i].t * p.st - p.pt + tap.a * p.dt;
+            const int hs = arow[i].h * p.sh - p.ph + tap.b * p.dh;
+            const bool ok = aok[i] && tap.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+            const int w0 = arow[i].w * p.sw - p.pw + tap.c;            // pw already includes the left padding
+            const int pix = ((arow[i].n * p.Ts + ts) * p.Hs + hs) * p.Ws + w0;
+            off = ok ? (unsigned)pix * 4u * (unsigned)sizeof(T) : kOOB;
+          } else {
+            bool ok;
+            const long long e = src_offset<DGRAD>(p, arow[i], tap, ok);
+            off = (ok && aok[i] && tap.ok) ? (unsigned)e * (unsigned)sizeof(T) : kOOB;
+          }
+          bufglds16(rsA, off, 0, xa + i * (RPPS * RB));
+        }
       }
-      const unsigned kbyte = (unsigned)kt * RB;
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i)
-        glds16(src_or_zero(Bb, (long long)(boff[i] + kbyte), kok && bok[i]), wb + i * (RPPS * RB));
+      for (int i = 0; i < B_IT; ++i) bufglds16(rsB, kok ? boff[i] : kOOB, kbyte, wb + i * (RPPS * RB));
     } else {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
@@ -1301,6 +1337,15 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   }
   pl->ut = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
+    // extents behind the buffer descriptors of the NT kernel (one batch element)
+    const long long a_rows = pl->ident ? M : (long long)d->N * d->Ts * d->Hs * d->Ws;
+    const long long a_bytes = a_rows * (pl->packw ? 4 : g.lda) * es;
+    const long long b_bytes = (long long)d->Cn * g.ldb * es;
+    VLFB_REQUIRE(a_bytes < (1ll << 31) && b_bytes < (1ll << 31),
+                 "conv: an operand of %lld / %lld bytes exceeds the 2 GiB a buffer descriptor addresses; split the batch",
+                 a_bytes, b_bytes);
+    g.a_bytes = (unsigned)a_bytes;
+    g.b_bytes = (unsigned)b_bytes;
     static const int env_ut = [] { const char* e = getenv("VLFB_NT_UT"); return e ? atoi(e) : 1; }();
     pl->ut = env_ut && !pl->ident && !d->pack_w && ((long long)d->Cs * es) % pl->rb == 0 &&
              (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1));
