@@ -1036,33 +1036,48 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
     }
   }
 
+  // DMA through buffer descriptors whose extent ends at position `kend`: rows past the end of this
+  // split's slab (only the last k-tile can have them) are zero-filled by the range check, the k-tile
+  // advance is the scalar offset, and the per-lane part is a loop-invariant 32-bit byte offset.
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(Pb, (unsigned)kend * (unsigned)p.ldp * 2u);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(Ab, IDENT ? (unsigned)kend * (unsigned)p.lda * 2u : p.a_bytes);
+  unsigned poff[PI], qoff[IDENT ? QI : 1];
+#pragma unroll
+  for (int i = 0; i < PI; ++i)
+    poff[i] = pok ? (unsigned)((kbeg + prow + RPP_P * i) * p.ldp + pch) * 2u : kOOB;
+  if (IDENT) {
+#pragma unroll
+    for (int i = 0; i < QI; ++i)
+      qoff[i] = qtap.ok ? (unsigned)((kbeg + qrow0 + RPP_Q * i) * p.lda + kc * 8) * 2u : kOOB;
+  }
+
   auto load_tile = [&](int kt, int buf) {
     char* pt = smem + buf * BUF + wave_u * 1024;
     char* qt = smem + buf * BUF + BK * RSP + wave_u * 1024;
     const int kb = kbeg + kt * BK;
+    const unsigned pstep = (unsigned)(kt * BK) * (unsigned)p.ldp * 2u;
 #pragma unroll
-    for (int i = 0; i < PI; ++i) {
-      const int k = kb + prow + RPP_P * i;
-      glds16(src_or_zero(Pb, ((long long)k * p.ldp + pch) * 2, pok && k < kend), pt + i * (NTHR * 16));
-    }
+    for (int i = 0; i < PI; ++i) bufglds16(rsP, poff[i], pstep, pt + i * (NTHR * 16));
+    if (IDENT) {
+      const unsigned qstep = (unsigned)(kt * BK) * (unsigned)p.lda * 2u;
 #pragma unroll
-    for (int i = 0; i < QI; ++i) {
-      const int k = kb + qrow0 + RPP_Q * i;
-      const char* src;
-      if (IDENT) {
-        src = src_or_zero(Ab, ((long long)k * p.lda + (long long)kc * 8) * 2, qtap.ok && k < kend);
-      } else {
+      for (int i = 0; i < QI; ++i) bufglds16(rsQ, qoff[i], qstep, qt + i * (NTHR * 16));
+    } else {
+#pragma unroll
+      for (int i = 0; i < QI; ++i) {
+        const int k = kb + qrow0 + RPP_Q * i;
+        unsigned off;
         if (PACKW) {   // W-padded stem input: the two pixels of the chunk are always inside the row
           const int w0 = qcur[i].w * p.sw - p.pw + qtap.c;
-          src = src_or_zero(Ab, (qcur[i].base + w0) * 8, qtap.ok && qcur[i].hv && k < kend);
+          off = (qtap.ok && qcur[i].hv && k < kend) ? (unsigned)(qcur[i].base + w0) * 8u : kOOB;
         } else {
           const int ws = qcur[i].w * p.sw - p.pw + qtap.c * p.dw;
           const bool ok = qtap.ok && qcur[i].hv && k < kend && (unsigned)ws < (unsigned)p.Ws;
-          src = src_or_zero(Ab, ((qcur[i].base + ws) * p.lda + qtap.ci) * 2, ok);
+          off = ok ? (unsigned)((qcur[i].base + ws) * p.lda + qtap.ci) * 2u : kOOB;
         }
         qrow_jump(p, qcur[i], jump, qtap);
+        bufglds16(rsQ, off, 0, qt + i * (NTHR * 16));
       }
-      glds16(src, qt + i * (NTHR * 16));
     }
   };
 
@@ -1335,17 +1350,19 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     static const int env_nw = [] { const char* e = getenv("VLFB_NT_WAVES"); return e ? atoi(e) : 8; }();
     if (env_nw == 8) pl->threads = 512;
   }
-  pl->ut = 0;
-  if (d->mode != VLFB_CONV_WGRAD) {
-    // extents behind the buffer descriptors of the NT kernel (one batch element)
+  {
+    // extents behind the buffer descriptors of the DMA kernels (one batch element)
     const long long a_rows = pl->ident ? M : (long long)d->N * d->Ts * d->Hs * d->Ws;
     const long long a_bytes = a_rows * (pl->packw ? 4 : g.lda) * es;
-    const long long b_bytes = (long long)d->Cn * g.ldb * es;
+    const long long b_bytes = d->mode == VLFB_CONV_WGRAD ? M * g.ldp * es : (long long)d->Cn * g.ldb * es;
     VLFB_REQUIRE(a_bytes < (1ll << 31) && b_bytes < (1ll << 31),
                  "conv: an operand of %lld / %lld bytes exceeds the 2 GiB a buffer descriptor addresses; split the batch",
                  a_bytes, b_bytes);
     g.a_bytes = (unsigned)a_bytes;
     g.b_bytes = (unsigned)b_bytes;
+  }
+  pl->ut = 0;
+  if (d->mode != VLFB_CONV_WGRAD) {
     static const int env_ut = [] { const char* e = getenv("VLFB_NT_UT"); return e ? atoi(e) : 1; }();
     pl->ut = env_ut && !pl->ident && !d->pack_w && ((long long)d->Cs * es) % pl->rb == 0 &&
              (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1));
