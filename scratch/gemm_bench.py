@@ -61,3 +61,34 @@ run('res4_2a_t3', 8, 1024, 256, 16, 14, 14, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1,
 run('res3_2b', 8, 128, 128, 16, 28, 28, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1))
 run('res2_2b', 8, 64, 64, 32, 56, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1))
 run('res2_2c', 8, 64, 256, 32, 56, 56, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1))
+
+
+def run_stem(splits_list=(0, 16, 24, 32, 40, 48, 64)):
+    """conv1 wgrad (packed stem: Cin 3->4, kw 7->8, W-padded input) with forced split counts"""
+    N, T, H, W, Cout = 8, 32, 224, 224, 64
+    To, Ho, Wo = 32, 112, 112
+    x = torch.randn(N, T, H, W + 8, 4, device=dev).to(bf)
+    g = torch.randn(N, To, Ho, Wo, Cout, device=dev).to(bf)
+    dw = torch.empty(Cout, 5, 7, 8, 4, device=dev, dtype=torch.float32)
+    G = dict(kt=5, kh=7, kw=7, st=1, sh=2, sw=2, pt=2, ph=3, pw=3 - 4, dt=1, dh=1, dw=1)
+    fl = 2.0 * N * To * Ho * Wo * Cout * 5 * 7 * 7 * 3
+    for sp in splits_list:
+        d = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W + 8,
+                          Cs=4, Cn=Cout, pack_w=8, splits=sp, **G)
+        ws = torch.empty(max(hip.conv_workspace_bytes(d), 16) // 4, device=dev, dtype=torch.float32)
+        fn = lambda: hip.conv_run(d, x, None, g, dw, workspace=ws)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        print('stem wgrad splits=%-3d %9.1f us %8.1f TFLOP/s (algorithmic)' % (sp, us, fl / us / 1e6))
+
+
+if which == 'stem':
+    run_stem()

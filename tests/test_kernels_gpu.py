@@ -160,10 +160,14 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
     assert rel_err(DW, base.double() + w_to_kernel(gw)) < (2e-5 if dtype == torch.float32 else 2e-3), "wgrad acc"
 
 
+@pytest.mark.parametrize("hw", [(20, 20), (12, 80), (10, 224)])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv_stem_packed(dtype):
-    """conv1: 5x7x7, stride (1,2,2), pad (2,3,3), Cin=3 packed as [kw_pad=8][4] runs (resnet_video.py:169-179)"""
-    N, T, H, W, Cout = 2, 6, 20, 20, 64
+def test_conv_stem_packed(dtype, hw):
+    """conv1: 5x7x7, stride (1,2,2), pad (2,3,3), Cin=3 packed as [kw_pad=8][4] runs (resnet_video.py:169-179).
+    Output rows of 10 positions use the generic kernels, rows of 40 / 112 the whole-row bf16 stem
+    wgrad kernel (partial last k-step: positions 32..39 / 96..111 live, the rest masked)."""
+    N, T, Cout = 2, 6, 64
+    H, W = hw
     k, s, p, d = (5, 7, 7), (1, 2, 2), (2, 3, 3), (1, 1, 1)
     gen = torch.Generator().manual_seed(3)
     x = q(torch.randn(N, 3, T, H, W, generator=gen), dtype)

@@ -81,7 +81,7 @@ def test_forward_backward_matches_oracle(preset, dtype):
         ref = blobs[name].detach().numpy().reshape(got.shape)
         report.append((name, rel(got, ref)))
     loss = float(eng.fetch("loss").reshape(-1)[0])
-    report.append(("loss", abs(loss - float(blobs["loss"])) / abs(float(blobs["loss"]))))
+    report.append(("loss", abs(loss - float(blobs["loss"].detach())) / abs(float(blobs["loss"].detach()))))
     worst_act = max(r for _, r in report)
     print("\n[%s %s] activations:" % (preset, dtype), ", ".join("%s=%.2e" % x for x in report))
     assert set(grads) == set(eng.trainable), "trainable set differs from the oracle's"

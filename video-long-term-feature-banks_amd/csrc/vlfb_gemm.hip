@@ -1144,6 +1144,150 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   }
 }
 
+// =============================================================================================
+// Stem WGRAD (conv1, bf16): dW[co][a][b][kw][c] = sum_pos G[pos][co] * X[t+a][2h+b][2w+kw][c].
+// With Cin = 3 (packed to 4) the K = (kt*kh) x (8 kw x 4 c) gathered columns of a position come from
+// only kt*kh short input rows, so the generic TN kernel spends its time issuing 16-byte gather DMAs
+// (9 column tiles x 6 pieces per lane per 64 positions) and re-reads the 411 MB gradient once per
+// column tile.  Here one workgroup takes whole OUTPUT ROWS (n, t, h): it stages the kt*kh raw input
+// rows that row touches (Ws*8 bytes each, contiguous DMA) plus the Wr x 64 gradient tile, and every
+// wave builds its MFMA fragments straight from the raw rows with ds_read_b64_tr_b16 -- the 16 columns
+// (4 kw x 4 c) of a position are 32 contiguous bytes, consecutive positions are sw pixels apart.
+// 8 waves x 9 column tiles of 16 x all 64 output channels = the whole 64 x K gradient stays in
+// registers (144 accumulator VGPRs) across the workgroup's rows; slabs + wgrad_reduce as usual.
+// 6x fewer DMA pieces, the gradient is read once.
+// =============================================================================================
+constexpr int kStemCT = 9;    // column tiles (16 of the K columns each) per wave
+__global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int taps = p.K >> 5;                       // (a, b) pairs
+  const int rbytes = p.Ws * 8;                     // one staged input row (Cs = 4 bf16 per pixel)
+  const int ppr = rbytes >> 4;                     // 16-byte pieces per row
+  const int npieces = taps * ppr;
+  const int poff_lds = npieces * 16;               // gradient tile behind the rows
+  const int stage = poff_lds + p.Wr * 128;         // Cn = 64 bf16 per position
+  const int split = blockIdx.x;
+  const int tiles_total = p.tiles_m, tpw = p.kper;
+  const int tile_beg = split * tpw;
+  const int tile_end = min(tiles_total, tile_beg + tpw);
+
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(p.P, p.b_bytes);
+
+  // ---- per-lane DMA assignment (tile-invariant part) -------------------------------------------
+  constexpr int RI = 8;                            // row pieces per lane (RI * 512 >= npieces, host-checked)
+  int ra[RI], rb[RI], rj[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int id = tid + 512 * i;
+    const int tap = id / ppr;
+    ra[i] = tap / p.kh;
+    rb[i] = tap - ra[i] * p.kh;
+    rj[i] = (id - tap * ppr) * 16;
+  }
+  // gradient tile: piece id -> (position row, 16-byte slot); the source chunk is XOR-swizzled so
+  // that tr_frag<128> reads conflict-free (same layout as gemm_tn_tr_kernel with BP = 64)
+  unsigned gvoff[2];
+  bool gok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 512 * i;
+    const int row = id >> 3, slot = id & 7;
+    const int pc = (((slot >> 1) ^ tr_key<128>(row)) << 1) | (slot & 1);
+    gok[i] = row < p.Wr;
+    gvoff[i] = (unsigned)(row * p.ldp + pc * 8) * 2u;
+  }
+
+  auto load_tile = [&](int tile, int buf) {
+    const int h = tile % p.Hr;
+    const int nt = tile / p.Hr;
+    const int t = nt % p.Tr, n = nt / p.Tr;
+    char* base = smem + buf * stage;
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      if (tid + 512 * i < npieces) {
+        const int tin = t * p.st - p.pt + ra[i], hin = h * p.sh - p.ph + rb[i];
+        const bool ok = (unsigned)tin < (unsigned)p.Ts && (unsigned)hin < (unsigned)p.Hs;
+        const unsigned off = ok ? (unsigned)(((n * p.Ts + tin) * p.Hs + hin) * rbytes + rj[i]) : kOOB;
+        bufglds16(rsX, off, 0, base + (i * 512 + wave_u * 64) * 16);
+      }
+    }
+    const unsigned gstep = (unsigned)(tile * p.Wr) * (unsigned)p.ldp * 2u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (gok[i]) bufglds16(rsG, gvoff[i], gstep, base + poff_lds + (i * 512 + wave_u * 64) * 16);
+  };
+
+  f32x4_v acc[kStemCT][4];
+#pragma unroll
+  for (int j = 0; j < kStemCT; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's column tiles: ct = wave * 9 + j  ->  tap = ct >> 1, kw half = ct & 1
+  const int ct0 = wave_u * kStemCT;
+  const int ncts = 2 * taps;
+  const int pl = lane & 15;
+  const int ksteps = (p.Wr + 31) >> 5;
+
+  if (tile_beg < tile_end) load_tile(tile_beg, 0);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_beg) & 1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tile + 1 < tile_end) load_tile(tile + 1, buf ^ 1);
+    const char* rows = smem + buf * stage;
+    const char* gt = rows + poff_lds;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int r0 = ks * 32 + 8 * g + (pl >> 2);            // position read by this lane (first half)
+      const bool live = ks * 32 + 8 * g < p.Wr;              // Wr % 8 == 0: the 8 positions of a group live or die together
+      bf16x8_v pf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pf[i] = tr_frag<128>(gt, i * 16, ks, lane);
+        if (!live) pf[i] = bf16x8_v{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      // dead positions read position Wr-1 instead (finite data x the zeroed gradient fragment)
+      const int q0 = min(r0, p.Wr - 1), q1 = min(r0 + 4, p.Wr - 1);
+      const int a0 = (q0 * p.sw - p.pw) * 8 + (pl & 3) * 8;
+      const int a1 = (q1 * p.sw - p.pw) * 8 + (pl & 3) * 8;
+      // all 9 fragments first, then the 36 MFMAs (no control flow in between: the column tiles past
+      // the end of K, on the last wave only, recompute the last real tile and are dropped at the store)
+      bf16x8_v qf[kStemCT];
+#pragma unroll
+      for (int j = 0; j < kStemCT; ++j) {
+        const int ct = min(ct0 + j, ncts - 1);
+        const char* rowp = rows + (ct >> 1) * rbytes + (ct & 1) * 32;
+        union { struct { s16x4_v a, b; } s; bf16x8_v v; } u;
+        u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(rowp + a0));
+        u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(rowp + a1));
+        qf[j] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < kStemCT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // ---- slab of this workgroup: ws[split][co][K], lane holds 4 consecutive columns of row co -------
+  float* slab = p.ws + (long long)split * ((long long)p.Ncols * p.ldo);
+#pragma unroll
+  for (int j = 0; j < kStemCT; ++j) {
+    const int ct = ct0 + j;
+    if (ct >= ncts) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = i * 16 + l15;
+      *reinterpret_cast<float4*>(slab + (long long)co * p.ldo + ct * 16 + g * 4) =
+          make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+    }
+  }
+}
+
 // split-K slab reduction: a workgroup owns CL float4 columns (CL*16 contiguous bytes of every slab
 // row); its G lane groups stride over the splits (4 loads in flight each) and fold through LDS; group
 // 0 applies the epilogue.  Many splits (skinny weights: few columns, hundreds of slabs) use narrow
@@ -1211,6 +1355,8 @@ struct Plan {
   int pre;        // NT: prefetch residual / mask rows before the k-loop (thin-K, epilogue-bound launches)
   int threads;    // workgroup size (NT: 256 or 512)
   int ut;         // NT: taps span whole k-tiles (and DGRAD has unit stride): scalar tap cursor
+  int stem;       // WGRAD: packed-stem kernel (whole output rows per workgroup, raw input rows in LDS)
+  size_t stem_lds;
   dim3 grid;
   size_t lds;
   long long ws_elems;
@@ -1276,6 +1422,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->splits = 1;
   pl->ws_elems = 0;
   pl->tn_tr = 0;
+  pl->stem = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
     pl->bm = 128;
     pl->bn = d->Cn > 64 ? 128 : 64;
@@ -1293,47 +1440,73 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     static const int env_tr = [] { const char* e = getenv("VLFB_TN_TR"); return e ? atoi(e) : 1; }();
     pl->tn_tr = env_tr && d->dtype == VLFB_BF16 && d->Cn % 8 == 0;
     if (!pl->tn_tr && pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
-    g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
-    g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
-    const int bk = 128 / es;
-    int splits = d->splits;
-    if (splits <= 0) {
-      // Pick the split count that fills whole rounds of `slots` workgroups best (every extra split
-      // costs one more fp32 slab pass), keeping at least 8 k-tiles of work per split.  Two 64 KiB-LDS
-      // workgroups fit a CU (512 slots), but these launches share the chip with the dgrad chain of
-      // the main stream: rounds of 256 (one workgroup per CU, half the slab traffic) measured best
-      // end to end (336 vs 331 clips/s at 512, 323 at 128).
-      const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
-      static const int env_slots = [] { const char* e = getenv("VLFB_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
-      const long long slots = env_slots > 0 ? env_slots : 256;
-      long long maxs = (M + 8 * bk - 1) / (8 * bk);
-      const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
-      if (maxs > slab_cap) maxs = slab_cap;
-      if (maxs > 1024) maxs = 1024;
-      if (batch > 1 || maxs < 1) maxs = 1;
-      double best = -1.0;
-      splits = 1;
-      for (long long sp = 1; sp <= maxs; sp = (sp < 8 ? sp + 1 : sp + 8)) {   // 1..8, then multiples of 8
-        const long long total = tiles * sp;
-        const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
-        if (eff > best + 0.03) { best = eff; splits = (int)sp; }
+    static const int env_stem = [] { const char* e = getenv("VLFB_STEM_WGRAD"); return e ? atoi(e) : 1; }();
+    if (env_stem && pl->tn_tr && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
+        d->dt == 1 && d->dh == 1 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && (d->Ws * 8) % 16 == 0) {
+      const int taps_ab = d->kt * d->kh;
+      const long long npieces = (long long)taps_ab * (d->Ws * 8 / 16);
+      const long long stage = npieces * 16 + (long long)d->Wr * 128;
+      const long long tiles_total = (long long)d->N * d->Tr * d->Hr;
+      if (npieces <= 4096 && taps_ab * 2 <= 8 * kStemCT && 2 * stage <= 160 * 1024 && tiles_total >= 2) {
+        static const int env_wgs = [] { const char* e = getenv("VLFB_STEM_WGS"); return e ? atoi(e) : 256; }();
+        const long long wgs = tiles_total < env_wgs ? tiles_total : env_wgs;
+        const long long tpw = (tiles_total + wgs - 1) / wgs;
+        const int splits = (int)((tiles_total + tpw - 1) / tpw);
+        g.tiles_m = (int)tiles_total;
+        g.tiles_n = 1;
+        g.kper = (int)tpw;
+        g.splits = splits;
+        pl->splits = splits;
+        pl->ws_elems = (long long)splits * d->Cn * K;
+        pl->stem = 1;
+        pl->stem_lds = (size_t)(2 * stage);
       }
     }
-    VLFB_REQUIRE(splits == 1 || batch == 1, "conv: split WGRAD cannot be batched");
-    long long kper = (M + splits - 1) / splits;
-    kper = (kper + bk - 1) / bk * bk;
-    splits = (int)((M + kper - 1) / kper);
-    g.kper = (int)kper;
-    g.splits = splits;
-    pl->splits = splits;
-    if (splits > 1) {
-      VLFB_REQUIRE(g.ldo == (int)K, "conv: split WGRAD needs a dense output (ldo == K)");
-      pl->ws_elems = (long long)splits * d->Cn * K;
+    if (!pl->stem) {
+      g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
+      g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
+      const int bk = 128 / es;
+      int splits = d->splits;
+      if (splits <= 0) {
+        // Pick the split count that fills whole rounds of `slots` workgroups best (every extra split
+        // costs one more fp32 slab pass), keeping at least 8 k-tiles of work per split.  Two 64 KiB-LDS
+        // workgroups fit a CU (512 slots), but these launches share the chip with the dgrad chain of
+        // the main stream: rounds of 256 (one workgroup per CU, half the slab traffic) measured best
+        // end to end (336 vs 331 clips/s at 512, 323 at 128).
+        const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
+        static const int env_slots = [] { const char* e = getenv("VLFB_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
+        const long long slots = env_slots > 0 ? env_slots : 256;
+        long long maxs = (M + 8 * bk - 1) / (8 * bk);
+        const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
+        if (maxs > slab_cap) maxs = slab_cap;
+        if (maxs > 1024) maxs = 1024;
+        if (batch > 1 || maxs < 1) maxs = 1;
+        double best = -1.0;
+        splits = 1;
+        for (long long sp = 1; sp <= maxs; sp = (sp < 8 ? sp + 1 : sp + 8)) {   // 1..8, then multiples of 8
+          const long long total = tiles * sp;
+          const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+          if (eff > best + 0.03) { best = eff; splits = (int)sp; }
+        }
+      }
+      VLFB_REQUIRE(splits == 1 || batch == 1, "conv: split WGRAD cannot be batched");
+      long long kper = (M + splits - 1) / splits;
+      kper = (kper + bk - 1) / bk * bk;
+      splits = (int)((M + kper - 1) / kper);
+      g.kper = (int)kper;
+      g.splits = splits;
+      pl->splits = splits;
+      if (splits > 1) {
+        VLFB_REQUIRE(g.ldo == (int)K, "conv: split WGRAD needs a dense output (ldo == K)");
+        pl->ws_elems = (long long)splits * d->Cn * K;
+      }
+      if (splits > 1 && splits % 8 == 0)
+        pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n * splits), 1, 1);
+      else
+        pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
+    } else {
+      pl->grid = dim3((unsigned)pl->splits, 1, 1);
     }
-    if (splits > 1 && splits % 8 == 0)
-      pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n * splits), 1, 1);
-    else
-      pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
   }
   pl->rb = 128;
   if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16) {
@@ -1376,6 +1549,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->pre = env_pre && g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
   } else {
     pl->lds = (size_t)2 * (pl->bm + pl->bn) * 128;
+    if (pl->stem) { pl->lds = pl->stem_lds; pl->threads = 512; }
   }
   return VLFB_OK;
 }
@@ -1446,6 +1620,16 @@ void launch_tn_tr(const Plan& pl, hipStream_t s) {
 
 template <typename T, typename OutT>
 int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
+  if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.stem) {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      configured = true;
+    }
+    hipLaunchKernelGGL(stem_wgrad_kernel, pl.grid, dim3(512), pl.lds, s, pl.gp);
+    return check_launch("conv wgrad (stem) kernel");
+  }
   if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn_tr) {
     if (pl.ident) launch_tn_tr<OutT, true, false>(pl, s);
     else if (pl.packw) launch_tn_tr<OutT, false, true>(pl, s);
