@@ -185,7 +185,9 @@ def main():
     clips_total = clips * world * args.steps
     value = clips_total / elapsed
     out = collections.OrderedDict([
-        ("metric", "clips/sec fwd+bwd R50-I3D-NL+LFB-NL, 32x224^2 synthetic"),
+        ("metric", "clips/sec fwd+bwd R50-I3D-NL+LFB-NL, 32x224^2 synthetic"
+         if (args.workload, args.frames, args.crop) == ("ava_r50_lfb_nl", 32, 224)
+         else "clips/sec fwd+bwd %s, %dx%d^2 synthetic" % (args.workload, args.frames, args.crop)),
         ("value", round(value, 3)), ("unit", "clips/s"), ("n_gpus", world), ("steps", args.steps),
         ("warmup", args.warmup), ("ms_per_step", round(elapsed / args.steps * 1e3, 3)),
         ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None), ("dtype", args.dtype),
