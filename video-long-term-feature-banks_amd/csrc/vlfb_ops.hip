@@ -431,6 +431,56 @@ __global__ void softmax_fwd_kernel(const float* __restrict__ s, T* __restrict__ 
     for (int c = lane; c < cols; c += 64) Elem<T>::st(pr + c, __expf(sr[c] * scale - m) * inv);
   }
 }
+// Rows of at most 64*4*NV columns (cols % 4 == 0): the row is read ONCE with 16-byte loads and stays in
+// registers (same arithmetic as above: max, exp, sum, scale), the result leaves as 4 packed elements
+// per lane.  The non-local blocks have 784 (train) / 1024 (test crop) / 1568 (64 frames) columns.
+template <typename T, int NV>
+__global__ void softmax_fwd_rowreg_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows,
+                                          int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const int nvec = cols >> 2;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const float4* sr = reinterpret_cast<const float4*>(s + r * cols);
+    float4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        float4 t = sr[c];
+        t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+        v[i] = t;
+        m = fmaxf(m, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+      }
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < nvec) {
+        v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m);
+        v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* pr = p + r * cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        if (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(pr + 4 * c) = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+        } else {
+          *reinterpret_cast<uint2*>(pr + 4 * c) = make_uint2(pack_bf2(v[i].x * inv, v[i].y * inv), pack_bf2(v[i].z * inv, v[i].w * inv));
+        }
+      }
+    }
+  }
+}
 template <typename T>
 __global__ void softmax_bwd_kernel(const float* __restrict__ dp, const T* __restrict__ p,
                                    T* __restrict__ ds, long long rows, int cols, float scale) {
@@ -757,6 +807,18 @@ extern "C" int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows
                                 float scale, vlfb_stream_t stream) {
   VLFB_REQUIRE(s && p && rows > 0 && cols > 0 && cols < (1ll << 31), "softmax_fwd: bad args");
   int grid = grid_for(rows * 64, 256);
+  if (cols % 4 == 0 && cols <= 64 * 4 * 8 && (dtype == VLFB_F32 || dtype == VLFB_BF16)) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = cols <= 64 * 4 * 4;
+    if (dtype == VLFB_F32) {
+      if (small) hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<float, 4>), dim3(grid), dim3(256), 0, st, s, (float*)p, (long long)rows, (int)cols, scale);
+      else hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<float, 8>), dim3(grid), dim3(256), 0, st, s, (float*)p, (long long)rows, (int)cols, scale);
+    } else {
+      if (small) hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, s, (bf16_t*)p, (long long)rows, (int)cols, scale);
+      else hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, s, (bf16_t*)p, (long long)rows, (int)cols, scale);
+    }
+    return check_launch("softmax_fwd");
+  }
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (float*)p, (long long)rows, (int)cols, scale);
   else if (dtype == VLFB_BF16)
