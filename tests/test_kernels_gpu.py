@@ -444,10 +444,12 @@ def test_fc_and_sigmoid_ce(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_fbo_attention_core(dtype):
+@pytest.mark.parametrize("D", [512, 40])
+def test_fbo_attention_core(dtype, D):
+    """D = 512: chip-wide kernels (dot / mix / row fix-up); D = 40: per-row kernels"""
     gen = torch.Generator().manual_seed(31)
     code = hip.dtype_code(dtype)
-    R, K, D = 5, 300, 512
+    R, K = 5, 300
     theta = q(torch.randn(R, D, generator=gen), dtype)
     phi = q(torch.randn(R, K, D, generator=gen), dtype)
     g = q(torch.randn(R, K, D, generator=gen), dtype)

@@ -320,6 +320,99 @@ __global__ void fbo_attn_bwd_kv_kernel(const T* __restrict__ dt, const T* __rest
   }
 }
 
+// ---- chip-wide variants (D a multiple of 8 lanes x 16 bytes): the per-row kernels above run R (= #RoIs,
+// a few dozen) workgroups and are latency-bound (204 us for 24 RoIs x 300 bank features x 512) -------
+// out[r][k] = scale * <q[r], kv[r][k]> : one wave per (r, k), 16 bytes per lane per pass
+template <typename T>
+__global__ void fbo_dot_kernel(const T* __restrict__ q, const T* __restrict__ kv, float* __restrict__ out,
+                               long long RK, int K, int D, long long ld, float scale) {
+  constexpr int V = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= RK) return;
+  const long long r = wave / K;
+  const T* qr = q + r * D;
+  const T* kr = kv + wave * ld;
+  float a = 0.f;
+  for (int d = lane * V; d < D; d += 64 * V) {
+    float x[V], y[V];
+    Vec16<T>::load(qr + d, x);
+    Vec16<T>::load(kr + d, y);
+#pragma unroll
+    for (int e = 0; e < V; ++e) a += x[e] * y[e];
+  }
+  a = wave_sum(a);
+  if (lane == 0) out[wave] = a * scale;
+}
+// weights of one row into LDS.  BWD = false: w = softmax(s).  BWD = true: s holds dp = <dt, g[k]>,
+// w = scale * p * (dp - <p, dp>).
+template <bool BWD>
+__device__ __forceinline__ void fbo_row_weights(const float* __restrict__ sr, const float* __restrict__ pr,
+                                                float* w, float* red, int K, float scale) {
+  if (!BWD) {
+    float m = -INFINITY;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, sr[k]);
+    m = block_max(m, red);
+    float sum = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) sum += expf(sr[k] - m);
+    sum = block_sum(sum, red);
+    const float inv = 1.0f / sum;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) w[k] = expf(sr[k] - m) * inv;
+  } else {
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) dot += sr[k] * pr[k];
+    dot = block_sum(dot, red);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) w[k] = scale * pr[k] * (sr[k] - dot);
+  }
+  __syncthreads();
+}
+// out[r][d] = sum_k w[k] * kv[r][k][d] for this workgroup's 8 x V channels, w recomputed from s by
+// every workgroup of the row (s is only READ here: the D/(8V) workgroups of a row run concurrently).
+// grid = (R, D / (8 V)); 256 threads = 8 channel lanes x 32 key groups, folded through LDS.
+template <typename T, bool BWD>
+__global__ void fbo_mix_kernel(const float* __restrict__ s, const float* __restrict__ pin,
+                               const T* __restrict__ kv, T* __restrict__ out,
+                               int K, int D, long long ld, float scale) {
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ float sm[];          // [K] weights, [4] reduction slots, [32][8 V] partials
+  float* w = sm;
+  float* red = sm + K;
+  float* part = red + 4;
+  const int r = blockIdx.x, dblk = blockIdx.y;
+  fbo_row_weights<BWD>(s + (long long)r * K, BWD ? pin + (long long)r * K : nullptr, w, red, K, scale);
+  const int dl = threadIdx.x & 7, kg = threadIdx.x >> 3;
+  const int d0 = (dblk * 8 + dl) * V;
+  const T* base = kv + (long long)r * K * ld + d0;
+  float a[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) a[e] = 0.f;
+  for (int k = kg; k < K; k += 32) {
+    float x[V];
+    Vec16<T>::load(base + (long long)k * ld, x);
+    const float wk = w[k];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] += wk * x[e];
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) part[(kg * 8 + dl) * V + e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 8 * V) {            // one thread per output channel of the block
+    float t = 0.f;
+    for (int j = 0; j < 32; ++j) t += part[j * 8 * V + threadIdx.x];
+    Elem<T>::st(out + (long long)r * D + dblk * 8 * V + threadIdx.x, t);
+  }
+}
+
+// afterwards, one workgroup per row turns s into the weights in place (p = softmax(logits) / ds from dp)
+template <bool BWD>
+__global__ void fbo_rowfix_kernel(float* __restrict__ s, const float* __restrict__ pin, int K, float scale) {
+  extern __shared__ float sm[];          // [K] weights, [4] reduction slots
+  const int r = blockIdx.x;
+  float* sr = s + (long long)r * K;
+  fbo_row_weights<BWD>(sr, BWD ? pin + (long long)r * K : nullptr, sm, sm + K, K, scale);
+  for (int k = threadIdx.x; k < K; k += blockDim.x) sr[k] = sm[k];
+}
+
 // ---- solver -------------------------------------------------------------------------------------
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                            long long n, float lr, float wd, float mu, int nesterov) {
@@ -453,6 +546,25 @@ extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void*
   VLFB_REQUIRE(k <= 8192, "fbo_attn_fwd: bank too long for the LDS row buffer");
   size_t lds = (size_t)(k + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int v = dtype == VLFB_F32 ? 4 : 8;
+    if ((dtype == VLFB_F32 || dtype == VLFB_BF16) && d % (8 * v) == 0 && ld % v == 0) {
+      // chip-wide path: logits into p (fp32 [R][K]), then softmax in place + weighted sum of g
+      const long long rk = (long long)r * k;
+      const unsigned g1 = (unsigned)((rk * 64 + 255) / 256);
+      const dim3 g2((unsigned)r, (unsigned)(d / (8 * v)));
+      const size_t lds2 = (size_t)(k + 4 + 32 * 8 * v) * sizeof(float);
+      if (dtype == VLFB_F32) {
+        hipLaunchKernelGGL(fbo_dot_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)theta, (const float*)phi, p, rk, (int)k, (int)d, (long long)ld, scale);
+        hipLaunchKernelGGL((fbo_mix_kernel<float, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const float*)g, (float*)t, (int)k, (int)d, (long long)ld, scale);
+      } else {
+        hipLaunchKernelGGL(fbo_dot_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, (const bf16_t*)theta, (const bf16_t*)phi, p, rk, (int)k, (int)d, (long long)ld, scale);
+        hipLaunchKernelGGL((fbo_mix_kernel<bf16_t, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const bf16_t*)g, (bf16_t*)t, (int)k, (int)d, (long long)ld, scale);
+      }
+      hipLaunchKernelGGL((fbo_rowfix_kernel<false>), dim3((unsigned)r), dim3(256), lds, s, p, (const float*)nullptr, (int)k, scale);
+      return check_launch("fbo_attn_fwd");
+    }
+  }
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(fbo_attn_fwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)t, (int)k, (int)d, (long long)ld, scale);
   else if (dtype == VLFB_BF16)
@@ -472,6 +584,25 @@ extern "C" int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* 
   size_t lds = (size_t)(k + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   int grid2 = grid_for(r * k * (d / v), 256);
+  if ((dtype == VLFB_F32 || dtype == VLFB_BF16) && d % (8 * v) == 0) {
+    // chip-wide path: dp = <dt, g[k]> into ds_ws, then ds (in place) + dtheta = sum_k ds[k] phi[k]
+    const long long rk = (long long)r * k;
+    const unsigned g1 = (unsigned)((rk * 64 + 255) / 256);
+    const dim3 g2((unsigned)r, (unsigned)(d / (8 * v)));
+    const size_t lds2 = (size_t)(k + 4 + 32 * 8 * v) * sizeof(float);
+    if (dtype == VLFB_F32) {
+      hipLaunchKernelGGL(fbo_dot_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)dt, (const float*)g, ds_ws, rk, (int)k, (int)d, (long long)ld, 1.0f);
+      hipLaunchKernelGGL((fbo_mix_kernel<float, true>), g2, dim3(256), lds2, s, (const float*)ds_ws, p, (const float*)phi, (float*)dtheta, (int)k, (int)d, (long long)ld, scale);
+      hipLaunchKernelGGL((fbo_rowfix_kernel<true>), dim3((unsigned)r), dim3(256), lds, s, ds_ws, p, (int)k, scale);
+      hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<float>, dim3(grid2), dim3(256), 0, s, (const float*)dt, (const float*)theta, p, (const float*)ds_ws, (float*)dphi, (float*)dg, (long long)r, (int)k, (int)d, (long long)ld);
+    } else {
+      hipLaunchKernelGGL(fbo_dot_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, (const bf16_t*)dt, (const bf16_t*)g, ds_ws, rk, (int)k, (int)d, (long long)ld, 1.0f);
+      hipLaunchKernelGGL((fbo_mix_kernel<bf16_t, true>), g2, dim3(256), lds2, s, (const float*)ds_ws, p, (const bf16_t*)phi, (bf16_t*)dtheta, (int)k, (int)d, (long long)ld, scale);
+      hipLaunchKernelGGL((fbo_rowfix_kernel<true>), dim3((unsigned)r), dim3(256), lds, s, ds_ws, p, (int)k, scale);
+      hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<bf16_t>, dim3(grid2), dim3(256), 0, s, (const bf16_t*)dt, (const bf16_t*)theta, p, (const float*)ds_ws, (bf16_t*)dphi, (bf16_t*)dg, (long long)r, (int)k, (int)d, (long long)ld);
+    }
+    return check_launch("fbo_attn_bwd");
+  }
   if (dtype == VLFB_F32) {
     hipLaunchKernelGGL(fbo_attn_bwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)dt, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)dtheta, ds_ws, (int)k, (int)d, (long long)ld, scale);
     hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<float>, dim3(grid2), dim3(256), 0, s, (const float*)dt, (const float*)theta, p, (const float*)ds_ws, (float*)dphi, (float*)dg, (long long)r, (int)k, (int)d, (long long)ld);

@@ -412,6 +412,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// 4 consecutive elements of T (16 / 8 bytes, naturally aligned) as floats
+template <typename T>
+__device__ __forceinline__ void load_elems4(const T* p, float (&v)[4]) {
+  if (sizeof(T) == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+
 template <typename T>
 __global__ void softmax_fwd_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows,
                                    int cols, float scale) {
@@ -496,6 +509,45 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ dp, const T* __rest
     T* o = ds + r * cols;
     for (int c = lane; c < cols; c += 64)
       Elem<T>::st(o + c, scale * Elem<T>::ld(pr + c) * (dr[c] - dot));
+  }
+}
+
+// backward with the row resident in registers (same conditions as softmax_fwd_rowreg_kernel)
+template <typename T, int NV>
+__global__ void softmax_bwd_rowreg_kernel(const float* __restrict__ dp, const T* __restrict__ p,
+                                          T* __restrict__ ds, long long rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const int nvec = cols >> 2;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const float4* dr = reinterpret_cast<const float4*>(dp + r * cols);
+    const T* pr = p + r * cols;
+    float4 d[NV], q[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        d[i] = dr[c];
+        float t[4];
+        load_elems4<T>(pr + 4 * c, t);
+        q[i] = make_float4(t[0], t[1], t[2], t[3]);
+        dot += (d[i].x * q[i].x + d[i].y * q[i].y) + (d[i].z * q[i].z + d[i].w * q[i].w);
+      }
+    }
+    dot = wave_sum(dot);
+    T* o = ds + r * cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const float a = scale * q[i].x * (d[i].x - dot), b = scale * q[i].y * (d[i].y - dot);
+        const float e = scale * q[i].z * (d[i].z - dot), f = scale * q[i].w * (d[i].w - dot);
+        if (sizeof(T) == 4) *reinterpret_cast<float4*>(o + 4 * c) = make_float4(a, b, e, f);
+        else *reinterpret_cast<uint2*>(o + 4 * c) = make_uint2(pack_bf2(a, b), pack_bf2(e, f));
+      }
+    }
   }
 }
 
@@ -830,6 +882,18 @@ extern "C" int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dt
                                 int64_t cols, float scale, vlfb_stream_t stream) {
   VLFB_REQUIRE(dp && p && ds && rows > 0 && cols > 0 && cols < (1ll << 31), "softmax_bwd: bad args");
   int grid = grid_for(rows * 64, 256);
+  if (cols % 4 == 0 && cols <= 64 * 4 * 8 && (dtype == VLFB_F32 || dtype == VLFB_BF16)) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = cols <= 64 * 4 * 4;
+    if (dtype == VLFB_F32) {
+      if (small) hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<float, 4>), dim3(grid), dim3(256), 0, st, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
+      else hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<float, 8>), dim3(grid), dim3(256), 0, st, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
+    } else {
+      if (small) hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, dp, (const bf16_t*)p, (bf16_t*)ds, (long long)rows, (int)cols, scale);
+      else hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, dp, (const bf16_t*)p, (bf16_t*)ds, (long long)rows, (int)cols, scale);
+    }
+    return check_launch("softmax_bwd");
+  }
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
   else if (dtype == VLFB_BF16)
