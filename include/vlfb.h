@@ -339,6 +339,28 @@ int vlfb_lfb_sample_compact(const vlfb_lfb_desc* d, const void* bank, const int3
                             const int32_t* query, int64_t rows, int window, void* out,
                             int out_dtype, vlfb_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Clip preprocessing on the device.  Replaces the per-frame cv2 / NumPy chain of
+ * lib/datasets/data_input_helper.py:70-139 (images_and_boxes_preprocessing) with one kernel:
+ * uint8 BGR frames [frames][src_h][src_w][3] -> bilinear resize to resized_h x resized_w (OpenCV's
+ * 8-bit INTER_LINEAR fixed-point algorithm; xofs/xcoef/yofs/ycoef are cv::resize's per-column / per-row
+ * source index and 11-bit weight tables, may be NULL when no resize happens) -> crop: output pixel
+ * (y, x) takes resized pixel (y0 + y, x0 + x), or (y0 + y, x0 - x) when flip is set (x0 is then the
+ * RIGHT edge of the window: train flips after the crop, test before it) -> x / 255 -> (x - mean[c]) / std[c] (mean / std in
+ * the source channel order) -> optional BGR -> RGB, written to dst rows of w_total pixels x c_pad
+ * channels starting at pixel w_left (the W-padded, channel-padded layout of the model's data input;
+ * padding is not touched).  dst points at frame 0 of the destination clip.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlfb_clip_desc {
+  int32_t frames, src_h, src_w, resized_h, resized_w;
+  int32_t crop_h, crop_w, y0, x0, flip;
+  int32_t to_rgb, w_left, w_total, c_pad;
+  float mean[3], std[3];
+} vlfb_clip_desc;
+int vlfb_clip_preprocess(const vlfb_clip_desc* d, const uint8_t* frames, const int32_t* xofs,
+                         const int16_t* xcoef, const int32_t* yofs, const int16_t* ycoef, void* dst,
+                         int dst_dtype, vlfb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

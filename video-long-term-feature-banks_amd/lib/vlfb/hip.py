@@ -63,6 +63,12 @@ class PoolDesc(C.Structure):
         "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw")]
 
 
+class ClipDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("frames", "src_h", "src_w", "resized_h", "resized_w", "crop_h", "crop_w",
+                                         "y0", "x0", "flip", "to_rgb", "w_left", "w_total", "c_pad")] + \
+               [("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
 class LfbDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_videos", "n_steps", "capacity", "dim", "dtype", "step_base")]
 
@@ -114,6 +120,7 @@ _SIGS = {
                                     C.c_float, _P]),
     "vlfb_sgd_update": (C.c_int, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
     "vlfb_scale_inplace": (C.c_int, [_P, _I64, C.c_float, _P]),
+    "vlfb_clip_preprocess": (C.c_int, [C.POINTER(ClipDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vlfb_lfb_bank_bytes": (_I64, [C.POINTER(LfbDesc)]),
     "vlfb_lfb_append": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, C.c_int, _P, _I64, _P, _P]),
     "vlfb_lfb_sample_window": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, C.c_int, C.c_uint64,
