@@ -1454,6 +1454,18 @@ class Engine(object):
         t = b.tensor[:b.numel]
         return t, hip.dtype_code(t.dtype)
 
+    def blob_padded(self, name):
+        """the W-/channel-padded clip input (`data`) as a device tensor [N][T][H][W + 2*pad_w][pad_c] and
+        its (pad_w, pad_c): the destination of datasets.data_input_helper.images_and_boxes_preprocessing.
+        Padding pixels / the padding channel are zero and must stay zero."""
+        b = self.env[name].root
+        if not getattr(b, "pad_c", None):
+            raise KeyError("blob %r is not stored padded" % name)
+        wpad = getattr(b, "pad_w", 0)
+        N, T, H, W = b.shape[0], b.shape[2], b.shape[3], b.shape[4]
+        n = N * T * H * (W + 2 * wpad) * b.pad_c
+        return b.tensor[:n].view(N, T, H, W + 2 * wpad, b.pad_c), (wpad, b.pad_c)
+
     def fetch(self, name):
         """blob (or its gradient with suffix '_grad') as a float32 numpy array in the reference layout"""
         grad = False
