@@ -133,21 +133,14 @@ __device__ __forceinline__ uint4 ld16(const char* base, long long byte_off) {
 __device__ __forceinline__ uint2 ld8(const char* base, long long byte_off) {
   return *reinterpret_cast<const uint2*>(base + byte_off);
 }
-// 16 bytes of zeros in HBM: the source of every padding / out-of-range chunk, so that gathers
-// need no select on the data (only on the address) and direct-to-LDS loads can write zeros.
+// 16 bytes of zeros in HBM: the source of padding / out-of-range chunks of the register-staged
+// (fp32 TN) gathers, so that they need no select on the data, only on the address.
 __device__ uint4 g_zero16;
 __device__ __forceinline__ const char* src_or_zero(const char* base, long long byte_off, bool ok) {
   return ok ? base + byte_off : reinterpret_cast<const char*>(&g_zero16);
 }
-// async 16-byte global -> LDS copy (global_load_lds_dwordx4): per-lane source, destination =
-// wave-uniform `lds_wave_base` + lane * 16
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void*)src,
-      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// The same copy through a buffer descriptor (buffer_load_dwordx4 ... offen lds): 32-bit byte offset
+// Async 16-byte global -> LDS copies (the DMA kernels) go through a buffer descriptor
+// (buffer_load_dwordx4 ... offen lds; destination = wave-uniform LDS base + lane * 16): 32-bit byte offset
 // per lane, hardware range check -- a lane whose offset is >= num_records writes ZEROS to its LDS
 // slot (probed on MI355X, scratch/buf_probe.hip), so padding needs no zero page and no 64-bit address
 // arithmetic.  kOOB is the "this chunk is padding" offset; operands are required to be < 2 GiB.
@@ -170,32 +163,6 @@ __device__ __forceinline__ uint2 ld8_if(const char* base, long long byte_off, bo
   return *reinterpret_cast<const uint2*>(src_or_zero(base, byte_off, ok));
 }
 
-// Source address of one gathered 16-byte chunk (zero page when it is padding); non-PACKW only.
-template <typename T, bool IDENT, bool DGRAD>
-__device__ __forceinline__ const char* act_chunk_ptr(const GP& p, const char* base, int m, bool m_ok,
-                                                     const RowC& r, const TapC& t, int kc) {
-  constexpr int EPC = Elem<T>::EPC;
-  if (IDENT)
-    return src_or_zero(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T), m_ok && t.ok);
-  bool ok;
-  const long long off = src_offset<DGRAD>(p, r, t, ok);
-  return src_or_zero(base, off * (long long)sizeof(T), ok && m_ok && t.ok);
-}
-
-// Packed stem (conv1): the input is [N][T][H][W + 2*4][4] (RGB0 pixels, 4 zero pixels on both sides
-// of every row, written by vlfb_ncthw_to_nthwc_wpad), so a 16-byte chunk = 2 bf16 / 1 fp32 pixel(s)
-// of the (kw, c) run is always inside the row: only t / h padding needs the zero page.
-template <typename T>
-__device__ __forceinline__ const char* packw_chunk_ptr(const GP& p, const char* base, bool m_ok,
-                                                       const RowC& r, const TapC& t) {
-  const int ts = r.t * p.st - p.pt + t.a * p.dt;
-  const int hs = r.h * p.sh - p.ph + t.b * p.dh;
-  const bool ok = m_ok && t.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
-  const int w0 = r.w * p.sw - p.pw + t.c;            // pw already includes the left padding
-  const long long pix = ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws) + w0;
-  return src_or_zero(base, pix * 4 * (long long)sizeof(T), ok);
-}
-
 // One gathered 16-byte chunk of the activation operand (branch-free).
 template <typename T, bool IDENT, bool DGRAD, bool PACKW>
 __device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, int m, bool m_ok,
@@ -203,9 +170,8 @@ __device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, i
   constexpr int EPC = Elem<T>::EPC;
   if (IDENT) {
     return ld16_if(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T), m_ok && t.ok);
-  } else if (PACKW) {
-    return *reinterpret_cast<const uint4*>(packw_chunk_ptr<T>(p, base, m_ok, r, t));
   } else {
+    static_assert(!PACKW, "the packed stem is gathered through buffer offsets in the kernels themselves");
     bool ok;
     const long long off = src_offset<DGRAD>(p, r, t, ok);
     return ld16_if(base, off * (long long)sizeof(T), ok && m_ok && t.ok);
@@ -368,14 +334,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   const char* Ab = p.A + (long long)z * p.a_bs * (long long)sizeof(T);
   const char* Bb = p.B + (long long)z * p.b_bs * (long long)sizeof(T);
 
-  // Staging: thread t owns LDS slot (row = t/8 + 32*i, 16-byte slot t%8) of both operand tiles.
-  // GLDS (everything but the packed stem): the global->LDS copy is asynchronous DMA
-  // (global_load_lds_dwordx4, no VGPR round trip); a wave's 64 slots are 1 KiB contiguous, and
-  // because the LDS image is XOR-swizzled the lane fetches global chunk (slot ^ (row & 7)).
-  constexpr bool GLDS = true;
+  // Staging: thread t owns LDS slot (row = t / CPRW + RPPS * i, 16-byte slot t % CPRW) of both operand
+  // tiles.  The global->LDS copy is asynchronous DMA (buffer_load_dwordx4 ... lds, no VGPR round
+  // trip); a wave's 64 slots are 1 KiB contiguous, and because the LDS image is XOR-swizzled the lane
+  // fetches global chunk (slot ^ key(row)).
   const int cc = tid % CPRW;
   const int r0 = tid / CPRW;
-  const int ccg = GLDS ? (cc ^ swz_key<RB>(r0)) : cc;   // global 16-byte chunk column fetched by this lane
+  const int ccg = cc ^ swz_key<RB>(r0);   // global 16-byte chunk column fetched by this lane
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   RowC arow[A_IT];
@@ -414,7 +379,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   // UT: scalar tap cursor of the NEXT tile to be fetched (tiles are fetched in order 0, 1, 2, ...)
   int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
 
-  uint4 ra[A_IT], rb[B_IT];
   const int ktiles = (p.K * (int)sizeof(T) + RB - 1) / RB;
 
   auto load_tile = [&](int kt, int buf) {
@@ -423,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
     if (IDENT || UT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
     else tap = decode_tap<T, PACKW>(p, kc);
     const bool kok = kc * EPC < p.K;
-    if (GLDS) {
+    {
       char* xa = smem + buf * BUF + wave_u * 1024;
       char* wb = smem + buf * BUF + BM * RB + wave_u * 1024;
       // the last k-tile may end inside the row (K * sizeof(T) % RB != 0): chunks past K are padding
@@ -467,29 +431,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) bufglds16(rsB, kok ? boff[i] : kOOB, kbyte, wb + i * (RPPS * RB));
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i)
-        ra[i] = load_act_chunk<T, IDENT, DGRAD, PACKW>(p, Ab, m0 + r0 + RPPS * i, aok[i], arow[i], tap, kc);
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + r0 + RPPS * i;
-        rb[i] = ld16_if(Bb, ((long long)n * p.ldb + (long long)kc * EPC) * (long long)sizeof(T), kok && n < p.Ncols);
-      }
     }
-  };
-  auto store_tile = [&](int buf) {
-    if (GLDS) return;
-    char* xa = smem + buf * BUF;
-    char* wb = xa + BM * RB;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(xa + lds_off<RB>(r0 + RPPS * i, cc)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(wb + lds_off<RB>(r0 + RPPS * i, cc)) = rb[i];
-  };
-  auto tile_ready = [&]() {
-    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed
-    __syncthreads();
   };
   // wait until at most `newer` tiles issued after the wanted one are still in flight (loads retire
   // in order, so the wanted tile and everything older -- incl. the PRE rows -- have landed)
@@ -535,18 +477,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
 #pragma unroll
   for (int s0 = 0; s0 < ST - 1; ++s0)
     if (s0 < ktiles) load_tile(s0, s0);
-  store_tile(0);
 
   int cur = 0, nxt = ST - 1;              // ring slots of tile kt and of tile kt + ST - 1
   for (int kt = 0; kt < ktiles; ++kt) {
     const int ahead = ktiles - 1 - kt;    // tiles after kt
-    if (GLDS) ring_wait(ahead < ST - 2 ? ahead : ST - 2);
+    ring_wait(ahead < ST - 2 ? ahead : ST - 2);
     // Bare barrier: __syncthreads() carries a workgroup fence that the compiler lowers to
     // vmcnt(0), which would drain the ring.  Every wave has waited for ITS part of tile kt above and
     // has consumed (lgkmcnt) its LDS reads of tile kt-1 before its last MFMAs, so after the barrier
     // tile kt is complete and the slot of tile kt-1 may be refilled.
-    if (GLDS) asm volatile("s_barrier" ::: "memory");
-    else __syncthreads();
+    asm volatile("s_barrier" ::: "memory");
     const bool more = kt + ST - 1 < ktiles;
     if (more) load_tile(kt + ST - 1, nxt);
     const char* xa = smem + cur * BUF;
@@ -562,9 +502,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
       for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int i = 0; i < FM; ++i) acc[j][i] = Mma<T>::mma(wf[j], xf[i], acc[j][i]);
-    }
-    if (!GLDS) {
-      if (more) store_tile(nxt);
     }
     cur = cur + 1 == ST ? 0 : cur + 1;
     nxt = nxt + 1 == ST ? 0 : nxt + 1;
@@ -1508,11 +1445,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       pl->grid = dim3((unsigned)pl->splits, 1, 1);
     }
   }
-  pl->rb = 128;
-  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16) {
-    static const int env_rb = [] { const char* e = getenv("VLFB_NT_RB"); return e ? atoi(e) : 128; }();
-    pl->rb = env_rb == 128 ? 128 : 64;
-  }
+  pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
   pl->pre = 0;
   pl->threads = kThreads;
   if (d->mode == VLFB_CONV_WGRAD && pl->tn_tr && pl->bm == 128 && pl->bn == 128) {
@@ -1581,12 +1514,6 @@ template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr bool CAN_PRE = BF && sizeof(OutT) == 2 && !PACKW;
-  if (BF && pl.rb == 64) {
-    // 64-byte tile rows: half the LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU
-    if (pl.bn == 128) launch_k(gemm_nt_kernel<T, OutT, 128, 128, IDENT, DGRAD, PACKW, BF ? 64 : 128, false, 4>, pl, s);
-    else launch_k(gemm_nt_kernel<T, OutT, 128, 64, IDENT, DGRAD, PACKW, BF ? 64 : 128, false, 4>, pl, s);
-    return;
-  }
   if (BF && pl.threads == 512) {   // 8 waves per workgroup (bf16, 128-wide tiles)
     if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>(pl, s);
     else launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>(pl, s);
