@@ -43,7 +43,7 @@ def build(preset, dtype, overrides=SMALL, train=True):
     split = "train" if train else "test"
     model = ModelBuilder(train=train, split=split, name=split)
     model.build_model(suffix="_" + split)
-    inputs = om.synth_inputs(cfg, n_clips, "train", seed=cfg.RNG_SEED, rois_per_clip=[2, 3] if cfg.DATASET == "ava" else None,
+    inputs = om.synth_inputs(cfg, n_clips, "train", seed=cfg.RNG_SEED, rois_per_clip=[2, 3][:n_clips] if cfg.DATASET == "ava" else None,
                              crop=cfg.TRAIN.CROP_SIZE, frames=cfg.TRAIN.VIDEO_LENGTH)
     params = om.synth_params(cfg, seed=cfg.RNG_SEED)
     eng = Engine(model, dtype, base_seed=cfg.RNG_SEED)
@@ -109,11 +109,28 @@ def test_forward_backward_matches_oracle(preset, dtype):
         assert p90 < 0.15 and worst[0][1] < 0.35, (p90, worst)
 
 
-@pytest.mark.parametrize("preset", ["charades_r50_lfb_avg", "ava_r50_lfb_max", "ava_r101_lfb_nl_3l"])
-def test_other_heads_and_depths_match_oracle_fp32(preset):
-    """FBO-avg / FBO-max heads (lfb_helper.py:106-127) and the R101 / 3-layer FBO-NL variant"""
+VARIANTS = {
+    "charades_r50_lfb_avg": ("charades_r50_lfb_avg", SMALL),
+    "ava_r50_lfb_max": ("ava_r50_lfb_max", SMALL),
+    "ava_r101_lfb_nl_3l": ("ava_r101_lfb_nl_3l", SMALL),
+    # the LFB model with the backbone trained too (the YAML freezes it)
+    "charades_r50_lfb_nl_unfrozen": ("charades_r50_lfb_nl", SMALL + ["MODEL.FREEZE_BACKBONE", False]),
+    # 64-frame clips (pool stride 32, 8 groups of 4 frames in the res3 non-local blocks)
+    "ava_r101_lfb_nl_3l_64f": ("ava_r101_lfb_nl_3l", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 64,
+                                                      "TRAIN.CROP_SIZE", 64]),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_other_heads_and_depths_match_oracle_fp32(variant):
+    """FBO-avg / FBO-max heads (lfb_helper.py:106-127), the R101 / 3-layer FBO-NL variant, the unfrozen
+    LFB model and 64-frame clips"""
     from oracle import model as om
-    cfg, model, eng, inputs, params, seed_fn = build(preset, "fp32")
+    preset, overrides = VARIANTS[variant]
+    cfg, model, eng, inputs, params, seed_fn = build(preset, "fp32", overrides)
+    if variant.endswith("64f"):
+        groups = [s for s in eng.steps if type(s).__name__ == "AttentionStep"][0]
+        assert groups.theta.shape[0] == 8          # (T/2)/4 groups per clip
     eng.forward()
     eng.backward()
     torch.cuda.synchronize()
@@ -121,7 +138,8 @@ def test_other_heads_and_depths_match_oracle_fp32(preset):
     for name in ("pool5", "prob"):
         got = eng.fetch(name)
         assert rel(got, blobs[name].detach().numpy().reshape(got.shape)) < 1e-3, name
-    assert abs(float(eng.fetch("loss").reshape(-1)[0]) - float(blobs["loss"])) < 1e-3 * abs(float(blobs["loss"]))
+    ref_loss = float(blobs["loss"].detach())
+    assert abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) < 1e-3 * abs(ref_loss)
     assert set(grads) == set(eng.trainable)
     gmax = max(float(g.norm()) for g in grads.values())
     errs = [rel(eng.fetch_grad(n), grads[n].numpy()) for n in eng.trainable if float(grads[n].norm()) > 1e-9 * gmax]
