@@ -61,7 +61,7 @@ __device__ __forceinline__ Bilin bilinear(float y, float x, int height, int widt
   return b;
 }
 
-// one block per RoI; each thread owns one 16-byte channel chunk (loops if C is larger)
+// one block per RoI; threads = 16-byte channel chunks x groups of pooled rows
 template <typename T>
 __global__ void roi_align_max_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ rois,
                                          T* __restrict__ out, uint8_t* __restrict__ argbin,
@@ -85,12 +85,23 @@ __global__ void roi_align_max_fwd_kernel(const T* __restrict__ feat, const float
       }
   }
 
-  for (int c0 = threadIdx.x * V; c0 < C; c0 += blockDim.x * V) {
+  // threads = channel chunks x GR row groups: group q scans pooled rows [q*rows_per, ...) and the groups
+  // are folded through LDS in bin order with a strict >, so the first maximal bin wins as in a serial scan
+  extern __shared__ char roi_sm[];
+  const int nch = C / V;                               // 16-byte channel chunks (host: C % V == 0)
+  const int GR = blockDim.x / nch > 0 ? blockDim.x / nch : 1;
+  const int chunk = threadIdx.x % nch, q = threadIdx.x / nch;
+  const int rows_per = (pooled + GR - 1) / GR;
+  float* sbest = reinterpret_cast<float*>(roi_sm);     // [GR][C]
+  uint8_t* sarg = reinterpret_cast<uint8_t*>(sbest + (long long)GR * C);
+  if (q < GR && chunk < nch) {
+    const int c0 = chunk * V;
     float best[V];
     int arg[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { best[k] = -INFINITY; arg[k] = 0; }
-    for (int ph = 0; ph < pooled; ++ph)
+    const int ph_end = min(pooled, (q + 1) * rows_per);
+    for (int ph = q * rows_per; ph < ph_end; ++ph)
       for (int pw = 0; pw < pooled; ++pw) {
         float acc[V];
 #pragma unroll
@@ -117,9 +128,28 @@ __global__ void roi_align_max_fwd_kernel(const T* __restrict__ feat, const float
           if (v > best[k]) { best[k] = v; arg[k] = bin; }
         }
       }
-    Vec16<T>::store(out + (long long)r * C + c0, best);
 #pragma unroll
-    for (int k = 0; k < V; ++k) argbin[(long long)r * C + c0 + k] = (uint8_t)arg[k];
+    for (int k = 0; k < V; ++k) {
+      sbest[(long long)q * C + c0 + k] = best[k];
+      sarg[(long long)q * C + c0 + k] = (uint8_t)arg[k];
+    }
+  }
+  __syncthreads();
+  if (q == 0 && chunk < nch) {
+    const int c0 = chunk * V;
+    float best[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float bv = sbest[c0 + k];
+      int ba = sarg[c0 + k];
+      for (int j = 1; j < GR; ++j) {
+        const float v = sbest[(long long)j * C + c0 + k];
+        if (v > bv) { bv = v; ba = sarg[(long long)j * C + c0 + k]; }
+      }
+      best[k] = bv;
+      argbin[(long long)r * C + c0 + k] = (uint8_t)ba;
+    }
+    Vec16<T>::store(out + (long long)r * C + c0, best);
   }
 }
 
@@ -168,13 +198,18 @@ extern "C" int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* 
   VLFB_REQUIRE(pooled > 0 && pooled * pooled <= 255, "roi_align_fwd: pooled resolution out of range");
   const int v = dtype == VLFB_F32 ? 4 : 8;
   VLFB_REQUIRE(c % v == 0, "roi_align_fwd: C must be a multiple of %d", v);
-  int threads = (int)((c / v + 63) / 64 * 64);
-  if (threads > 256) threads = 256;
+  const int nch = (int)(c / v);
+  VLFB_REQUIRE(nch <= 1024, "roi_align_fwd: at most %d channels", 1024 * v);
+  int gr = 1024 / nch;                      // row groups per RoI (few RoIs: parallelism has to come from the bins)
+  if (gr > pooled) gr = pooled;
+  if (gr < 1) gr = 1;
+  const int threads = nch * gr;
+  const size_t lds = (size_t)gr * c * 5;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
-    hipLaunchKernelGGL(roi_align_max_fwd_kernel<float>, dim3((unsigned)r), dim3(threads), 0, s, (const float*)feat, rois, (float*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
+    hipLaunchKernelGGL(roi_align_max_fwd_kernel<float>, dim3((unsigned)r), dim3(threads), lds, s, (const float*)feat, rois, (float*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
   else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(roi_align_max_fwd_kernel<bf16_t>, dim3((unsigned)r), dim3(threads), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
+    hipLaunchKernelGGL(roi_align_max_fwd_kernel<bf16_t>, dim3((unsigned)r), dim3(threads), lds, s, (const bf16_t*)feat, rois, (bf16_t*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
   else return set_error(VLFB_ERR_ARG, "roi_align_fwd: bad dtype");
   return check_launch("roi_align_max_fwd");
 }
