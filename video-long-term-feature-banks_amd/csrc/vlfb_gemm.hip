@@ -1452,9 +1452,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     static const int env_tw = [] { const char* e = getenv("VLFB_TN_WAVES"); return e ? atoi(e) : 8; }();
     if (env_tw == 8) pl->threads = 512;
   }
-  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16 && pl->bn == 128 && pl->rb == 128) {
+  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16 && pl->rb == 128) {
     static const int env_nw = [] { const char* e = getenv("VLFB_NT_WAVES"); return e ? atoi(e) : 8; }();
-    if (env_nw == 8) pl->threads = 512;
+    static const int env_nw64 = [] { const char* e = getenv("VLFB_NT_WAVES64"); return e ? atoi(e) : 8; }();
+    if ((pl->bn == 128 ? env_nw : env_nw64) == 8) pl->threads = 512;
   }
   {
     // extents behind the buffer descriptors of the DMA kernels (one batch element)
@@ -1514,7 +1515,12 @@ template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr bool CAN_PRE = BF && sizeof(OutT) == 2 && !PACKW;
-  if (BF && pl.threads == 512) {   // 8 waves per workgroup (bf16, 128-wide tiles)
+  if (BF && pl.threads == 512) {   // 8 waves per workgroup (bf16)
+    if (pl.bn == 64) {
+      if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>(pl, s);
+      else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>(pl, s);
+      return;
+    }
     if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>(pl, s);
     else launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>(pl, s);
     return;
