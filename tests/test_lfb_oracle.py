@@ -80,3 +80,19 @@ def test_charades_window_and_compaction():
     out = ol.sample_lfb_charades(lfb[1], 10, 20, 2, 4)
     have = [f for f in sorted(lfb[1]) if -110 <= f <= 130]
     assert np.array_equal(out[:len(have)], np.array([lfb[1][f] for f in have])) and np.all(out[len(have):] == 0)
+
+
+def test_device_bank_step_window_equals_the_reference_frame_window():
+    """host index math of DeviceBank.sample_frames (no GPU): bank steps [lo, hi] are exactly the LFB
+    frames the reference would find in [begin, end]"""
+    from vlfb.lfb_bank import frame_window_steps
+    for cps in (1, 2, 3, 4):
+        freq = ol.FPS // cps
+        for window in (4, 10, 20):
+            centers = np.arange(-50, 900, 7)
+            lo, hi = frame_window_steps(centers, window, cps)
+            for c, l, h in zip(centers, lo, hi):
+                begin, end = ol.charades_window(int(c), window, cps)
+                want = [f for f in range(begin, end + 1) if f >= 0 and (f + 1) % freq == 0]
+                got = [freq * (t + 1) - 1 for t in range(max(int(l), 0), int(h) + 1)]
+                assert got == want, (cps, window, c)

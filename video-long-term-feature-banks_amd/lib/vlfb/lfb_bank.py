@@ -23,6 +23,20 @@ from vlfb import hip
 FPS = 24   # cfg.CHARADES.FPS (lib/datasets/charades.py:43)
 
 
+def frame_window_steps(center_frames, window, clips_per_second):
+    """first / last bank step (inclusive) of the frame window the reference searches around each clip
+    centre (charades.py:259-261: begin = round(centre - secs/2 * FPS), end = begin + secs * FPS).
+    Bank step t holds frame sample_freq * (t + 1) - 1, so frames in [begin, end] <=> t in [lo, hi]."""
+    sample_freq = FPS // int(clips_per_second)
+    secs = int(window) // int(clips_per_second)
+    c = np.asarray(center_frames, dtype=np.float64).reshape(-1)
+    begin = np.round(c - (float(secs) / 2.0 * FPS)).astype(np.int64)
+    end = begin + secs * FPS
+    lo = -((-(begin + 1)) // sample_freq) - 1
+    hi = (end + 1) // sample_freq - 1
+    return lo, hi
+
+
 class DeviceBank(object):
     """bank[video][step][slot][dim] + count[video][step] on one GPU.
 
@@ -131,14 +145,7 @@ class DeviceBank(object):
         """Charades (charades.py:251-276): -> (N, window, dim), the first `window` bank frames inside
         [begin, end] around each clip centre, packed to the front"""
         rows = len(videos)
-        sample_freq = FPS // int(clips_per_second)
-        secs = int(window) // int(clips_per_second)
-        c = np.asarray(center_frames, dtype=np.float64).reshape(-1)
-        begin = np.round(c - (float(secs) / 2.0 * FPS)).astype(np.int64)
-        end = begin + secs * FPS
-        # bank step t holds frame sample_freq*(t+1)-1: frames in [begin, end]  <=>  t in [lo, hi]
-        lo = -((-(begin + 1)) // sample_freq) - 1
-        hi = (end + 1) // sample_freq - 1
+        lo, hi = frame_window_steps(center_frames, window, clips_per_second)
         q = np.stack([self._rows_of(videos), lo, hi], axis=1)
         qd = self._dev_i32(q)
         out = self._out(out, (rows, int(window), self.dim), out_dtype)
