@@ -16,277 +16,10 @@
 // same lane<->k mapping: lane l owns 8 consecutive k of row (l & 15) at k-offset (l >> 4) * 8.
 // MFMA operands are swapped (weights as A, activations as B) so that each lane ends up holding
 // 4 consecutive output channels of one output row -> 8/16-byte epilogue stores.
-#include "vlfb_common.h"
-#include <string.h>
-#include <stdlib.h>
+#include "vlfb_gemm_common.h"
 
 namespace vlfb {
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
-typedef __attribute__((ext_vector_type(4))) float f32x4_v;
-
-constexpr int kThreads = 256;
-constexpr int kRowBytes = 128;  // one LDS tile row = 128 bytes of K
-
-struct GP {
-  const char* A;
-  const char* B;
-  const char* P;
-  char* O;
-  const float* bias;
-  const float* rowscale;
-  const char* R;
-  const char* Mask;
-  float* ws;
-  int M, Ncols, K;
-  int Tr, Hr, Wr, Ts, Hs, Ws, Cs;
-  int kh, kw;
-  float inv_khw, inv_kw, inv_kh;
-  int st, sh, sw, pt, ph, pw, dt, dh, dw;
-  int lst, lsh, lsw;  // log2 strides (DGRAD)
-  int cpt_shift;      // log2(16-byte chunks per tap)
-  int lda, ldb, ldo, ldr, ldp;
-  long long a_bs, b_bs, o_bs, r_bs, p_bs;
-  float alpha;
-  int relu, bias_mode, accumulate;
-  int tiles_m, tiles_n;
-  int splits, kper;
-  unsigned a_bytes, b_bytes;   // NT: extent of one batch element of A / B (buffer descriptors)
-  int vec_epi;        // NT: LDS-staged, fully coalesced epilogue is legal for this problem
-  int epi;            // NT: the fp32 tile is staged through LDS in this many passes (1 or 2)
-};
-
-struct RowC { int n, t, h, w; };
-
-__device__ __forceinline__ RowC decode_row(const GP& p, int m) {
-  RowC r;
-  int hw = p.Hr * p.Wr;
-  int thw = p.Tr * hw;
-  r.n = m / thw;
-  int rem = m - r.n * thw;
-  r.t = rem / hw;
-  rem -= r.t * hw;
-  r.h = rem / p.Wr;
-  r.w = rem - r.h * p.Wr;
-  return r;
-}
-__device__ __forceinline__ void advance_row(const GP& p, RowC& r) {
-  if (++r.w == p.Wr) {
-    r.w = 0;
-    if (++r.h == p.Hr) {
-      r.h = 0;
-      if (++r.t == p.Tr) { r.t = 0; ++r.n; }
-    }
-  }
-}
-
-struct TapC { int a, b, c, ci; bool ok; };
-
-// kc = global 16-byte chunk index along K
-template <typename T, bool PACKW>
-__device__ __forceinline__ TapC decode_tap(const GP& p, int kc) {
-  constexpr int EPC = Elem<T>::EPC;
-  TapC t;
-  t.ok = kc * EPC < p.K;
-  int tap = kc >> p.cpt_shift;
-  int within = kc & ((1 << p.cpt_shift) - 1);
-  if (PACKW) {
-    // taps enumerate (a, b); the packed (kw, channel) run is the per-tap K extent
-    t.a = (int)(((float)tap + 0.5f) * p.inv_kh);
-    t.b = tap - t.a * p.kh;
-    t.c = within * (EPC / 4);  // first pixel of this chunk (Cs == 4)
-    t.ci = 0;
-  } else {
-    t.a = (int)(((float)tap + 0.5f) * p.inv_khw);
-    int rem = tap - t.a * p.kh * p.kw;
-    t.b = (int)(((float)rem + 0.5f) * p.inv_kw);
-    t.c = rem - t.b * p.kw;
-    t.ci = within * EPC;
-  }
-  return t;
-}
-
-// element offset of the source chunk and whether it exists (false = padding). (non-PACKW)
-template <bool DGRAD>
-__device__ __forceinline__ long long src_offset(const GP& p, const RowC& r, const TapC& t, bool& ok) {
-  int ts, hs, ws;
-  if (!DGRAD) {
-    ts = r.t * p.st - p.pt + t.a * p.dt;
-    hs = r.h * p.sh - p.ph + t.b * p.dh;
-    ws = r.w * p.sw - p.pw + t.c * p.dw;
-    ok = (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-  } else {
-    const int nt = r.t + p.pt - t.a * p.dt;
-    const int nh = r.h + p.ph - t.b * p.dh;
-    const int nw = r.w + p.pw - t.c * p.dw;
-    ok = (nt | nh | nw) >= 0 && ((nt & (p.st - 1)) | (nh & (p.sh - 1)) | (nw & (p.sw - 1))) == 0;
-    ts = nt >> p.lst; hs = nh >> p.lsh; ws = nw >> p.lsw;
-    ok = ok && ts < p.Ts && hs < p.Hs && ws < p.Ws;
-  }
-  return ((long long)((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * p.lda + t.ci;
-}
-
-__device__ __forceinline__ uint4 ld16(const char* base, long long byte_off) {
-  return *reinterpret_cast<const uint4*>(base + byte_off);
-}
-__device__ __forceinline__ uint2 ld8(const char* base, long long byte_off) {
-  return *reinterpret_cast<const uint2*>(base + byte_off);
-}
-// 16 bytes of zeros in HBM: the source of padding / out-of-range chunks of the register-staged
-// (fp32 TN) gathers, so that they need no select on the data, only on the address.
-__device__ uint4 g_zero16;
-__device__ __forceinline__ const char* src_or_zero(const char* base, long long byte_off, bool ok) {
-  return ok ? base + byte_off : reinterpret_cast<const char*>(&g_zero16);
-}
-// Async 16-byte global -> LDS copies (the DMA kernels) go through a buffer descriptor
-// (buffer_load_dwordx4 ... offen lds; destination = wave-uniform LDS base + lane * 16): 32-bit byte offset
-// per lane, hardware range check -- a lane whose offset is >= num_records writes ZEROS to its LDS
-// slot (probed on MI355X, scratch/buf_probe.hip), so padding needs no zero page and no 64-bit address
-// arithmetic.  kOOB is the "this chunk is padding" offset; operands are required to be < 2 GiB.
-constexpr unsigned kOOB = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void bufglds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
-                                           (int)voff, (int)soff, 0, 0);
-}
-
-// Branch-free predicated loads: the load always executes (from offset 0 of the operand when the
-// element is padding / out of range) and the result is selected afterwards, so the gather of a
-// k-tile is one straight-line run of global loads instead of one basic block per element.
-__device__ __forceinline__ uint4 ld16_if(const char* base, long long byte_off, bool ok) {
-  return *reinterpret_cast<const uint4*>(src_or_zero(base, byte_off, ok));
-}
-__device__ __forceinline__ uint2 ld8_if(const char* base, long long byte_off, bool ok) {
-  return *reinterpret_cast<const uint2*>(src_or_zero(base, byte_off, ok));
-}
-
-// One gathered 16-byte chunk of the activation operand (branch-free).
-template <typename T, bool IDENT, bool DGRAD, bool PACKW>
-__device__ __forceinline__ uint4 load_act_chunk(const GP& p, const char* base, int m, bool m_ok,
-                                                const RowC& r, const TapC& t, int kc) {
-  constexpr int EPC = Elem<T>::EPC;
-  if (IDENT) {
-    return ld16_if(base, ((long long)m * p.lda + (long long)kc * EPC) * (long long)sizeof(T), m_ok && t.ok);
-  } else {
-    static_assert(!PACKW, "the packed stem is gathered through buffer offsets in the kernels themselves");
-    bool ok;
-    const long long off = src_offset<DGRAD>(p, r, t, ok);
-    return ld16_if(base, off * (long long)sizeof(T), ok && m_ok && t.ok);
-  }
-}
-
-// LDS tile rows are RB bytes of K (128: 8 chunks, XOR key row & 7; 64: 4 chunks, key (row >> 2) & 3
-// -- four 64-byte rows share one 256-byte bank row, so the key must change every 4 rows).
-template <int RB>
-__device__ __forceinline__ int swz_key(int row) { return RB == 128 ? (row & 7) : ((row >> 2) & 3); }
-template <int RB = 128>
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * RB + ((chunk ^ swz_key<RB>(row)) << 4);
-}
-
-// ---- MFMA wrappers --------------------------------------------------------------------------
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static constexpr int KSTEPS = 2;   // per 128-byte row (a 64-byte row is one k-step)
-  struct Frag { bf16x8_v v; };
-  template <int RB = 128>
-  __device__ static __forceinline__ Frag load(const char* tile, int row, int ks, int g) {
-    Frag f;
-    f.v = *reinterpret_cast<const bf16x8_v*>(tile + lds_off<RB>(row, ks * 4 + g));
-    return f;
-  }
-  __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static constexpr int KSTEPS = 1;
-  struct Frag { float v[8]; };
-  template <int RB = 128>
-  __device__ static __forceinline__ Frag load(const char* tile, int row, int /*ks*/, int g) {
-    static_assert(RB == 128, "the fp32 path keeps 128-byte tile rows");
-    Frag f;
-    float4 lo = *reinterpret_cast<const float4*>(tile + lds_off(row, 2 * g));
-    float4 hi = *reinterpret_cast<const float4*>(tile + lds_off(row, 2 * g + 1));
-    f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w;
-    f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
-    return f;
-  }
-  __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
-    return c;
-  }
-};
-
-template <typename T> __device__ __forceinline__ float ld_elem(const char* base, long long idx) {
-  return Elem<T>::ld(reinterpret_cast<const T*>(base) + idx);
-}
-
-// store 4 consecutive fp32 results as OutT (vector when aligned)
-template <typename OutT>
-__device__ __forceinline__ void store4(char* base, long long idx, const float (&v)[4], int count, bool vec_ok) {
-  OutT* o = reinterpret_cast<OutT*>(base) + idx;
-  if (vec_ok && count == 4) {
-    if (sizeof(OutT) == 4) {
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-    }
-  } else {
-    for (int i = 0; i < count; ++i) Elem<OutT>::st(o + i, v[i]);
-  }
-}
-
-// N consecutive elements of T (N * sizeof(T) = 8 or 16 bytes, naturally aligned) as floats
-template <typename T, int N>
-__device__ __forceinline__ void load_elems(const T* p, float (&v)[N]) {
-  if (sizeof(T) == 4) {
-    static_assert(sizeof(T) != 4 || N == 4, "fp32 rows are read 4 at a time");
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2 % N] = t.z; v[3 % N] = t.w;
-  } else if (N == 8) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[(2 * i) % N] = __uint_as_float(w[i] << 16);
-      v[(2 * i + 1) % N] = __uint_as_float(w[i] & 0xffff0000u);
-    }
-  } else {  // 4 bf16 = 8 bytes
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2 % N] = __uint_as_float(t.y << 16); v[3 % N] = __uint_as_float(t.y & 0xffff0000u);
-  }
-}
-
-// the same from a 16-byte register image (prefetched epilogue operands; only N*sizeof(T) == 16)
-template <typename T, int N>
-__device__ __forceinline__ void unpack_elems(const uint4& t, float (&v)[N]) {
-  if (sizeof(T) == 4) {
-    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
-    v[2 % N] = __uint_as_float(t.z); v[3 % N] = __uint_as_float(t.w);
-  } else {
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[(2 * i) % N] = __uint_as_float(w[i] << 16);
-      v[(2 * i + 1) % N] = __uint_as_float(w[i] & 0xffff0000u);
-    }
-  }
-}
-
-// XCD-aware remap of a linear workgroup id: consecutive ids on one XCD share operand panels.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int nx = 8;
-  int q = nwg / nx, r = nwg % nx;
-  int xcd = bid % nx, idx = bid / nx;
-  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
 
 // =============================================================================================
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
@@ -887,27 +620,6 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
 // the row so that the 8 rows touched by a 32-lane half of a tr-read fall on 8 different 32-byte
 // bank segments (the DMA destination is lane-linear, so the XOR is applied on the SOURCE chunk).
 // =============================================================================================
-typedef __attribute__((ext_vector_type(4))) short s16x4_v;
-
-template <int RS> __device__ __forceinline__ int tr_key(int row) {
-  return RS == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
-}
-// fragment: channels c0..c0+15 (lane -> c0 + (l & 15)), positions ks*32 + 8*(l>>4) .. +7
-template <int RS>
-__device__ __forceinline__ bf16x8_v tr_frag(const char* tile, int c0, int ks, int lane) {
-  const int g = lane >> 4, pl = lane & 15;
-  const int seg = c0 >> 4;
-  const int r0 = ks * 32 + 8 * g + (pl >> 2);
-  const int r1 = r0 + 4;
-  const s16x4_v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4_v*)(tile + r0 * RS + ((seg ^ tr_key<RS>(r0)) << 5) + ((pl & 3) << 3)));
-  const s16x4_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4_v*)(tile + r1 * RS + ((seg ^ tr_key<RS>(r1)) << 5) + ((pl & 3) << 3)));
-  union { struct { s16x4_v a, b; } s; bf16x8_v v; } u;
-  u.s.a = lo; u.s.b = hi;
-  return u.v;
-}
-
 template <typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   // NW = 4: waves 2 (p) x 2 (q).  NW = 8: waves 2 x 4 on the same tile -- twice the wavefronts per CU.
@@ -1293,13 +1005,22 @@ struct Plan {
   int threads;    // workgroup size (NT: 256 or 512)
   int ut;         // NT: taps span whole k-tiles (and DGRAD has unit stride): scalar tap cursor
   int stem;       // WGRAD: packed-stem kernel (whole output rows per workgroup, raw input rows in LDS)
+  int tn8;        // WGRAD: 256 x 256 phase-pipelined kernel (plain rows)
+  int nt8;        // NT: 256-row phase-pipelined kernel with this tile width (256 / 128), 0 = 128x128 kernel
+  int nt8_bm;     //     rows per tile: 256 or 196
+  int nt8_mode;   //     0 plain rows, 1 gathered FPROP, 2 gathered unit-stride DGRAD
   size_t stem_lds;
   dim3 grid;
   size_t lds;
   long long ws_elems;
 };
 
-int make_plan(const vlfb_conv_desc* d, Plan* pl) {
+int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
+  // development override of the kernel family (probe / A-B runs only)
+  static const int env_algo = [] { const char* e = getenv("VLFB_FORCE_ALGO"); return e ? atoi(e) : 0; }();
+  vlfb_conv_desc d_copy = *d_in;
+  if (env_algo && d_copy.algo == 0) d_copy.algo = env_algo;
+  const vlfb_conv_desc* d = &d_copy;
   GP& g = pl->gp;
   ::memset(&g, 0, sizeof(g));
   VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "conv: bad dtype %d", d->dtype);
@@ -1338,7 +1059,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   }
   g.M = (int)M; g.Ncols = d->Cn; g.K = (int)K;
   g.Tr = d->Tr; g.Hr = d->Hr; g.Wr = d->Wr; g.Ts = d->Ts; g.Hs = d->Hs; g.Ws = d->Ws; g.Cs = d->Cs;
-  g.kh = d->kh; g.kw = d->kw;
+  g.kt = d->kt; g.kh = d->kh; g.kw = d->kw;
   g.inv_khw = 1.0f / (float)(d->kh * d->kw); g.inv_kw = 1.0f / (float)d->kw; g.inv_kh = 1.0f / (float)d->kh;
   g.st = d->st; g.sh = d->sh; g.sw = d->sw; g.pt = d->pt; g.ph = d->ph; g.pw = d->pw;
   g.dt = d->dt; g.dh = d->dh; g.dw = d->dw;
@@ -1358,6 +1079,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
 
   pl->splits = 1;
   pl->ws_elems = 0;
+  pl->tn8 = 0;
   pl->tn_tr = 0;
   pl->stem = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
@@ -1372,10 +1094,23 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   } else {
     pl->bm = d->Cn > 64 ? 128 : 64;             // P tile (output rows)
     pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
+    // 256 x 256 phase-pipelined kernel (vlfb_gemm8.hip): plain-row bf16 operands with at least 128 of each
+    {
+      const bool ok = d->dtype == VLFB_BF16 && pl->ident && d->Cn % 8 == 0 && K % 8 == 0 && d->Cn >= 128 && K >= 128 &&
+                      g.lda % 8 == 0 && g.ldp % 8 == 0;
+      if (d->algo == VLFB_ALGO_PIPE256)
+        VLFB_REQUIRE(ok, "conv: algo = PIPE256 WGRAD needs bf16 plain-row operands with Cn, K >= 128 (multiples of 8)");
+      // library choice: every workgroup writes a 256 KiB fp32 slab, so only the large weights win
+      // (Cn * K >= 1 M elements: res5 1x1x1 wgrads 1.3-1.66x; 0.5 M and below 0.6-0.97x, scratch/nt8_probe.cpp)
+      pl->tn8 = ok && d->algo != VLFB_ALGO_TILE128 &&
+                (d->algo == VLFB_ALGO_PIPE256 || (batch == 1 && (long long)d->Cn * K >= (1ll << 20) && d->Cn >= 512 && K >= 512));
+      if (pl->tn8) pl->bm = pl->bn = 256;
+    }
     // few output rows (res2 / stem, Cout = 64): widen the Q tile so a workgroup still has
     // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
     static const int env_tr = [] { const char* e = getenv("VLFB_TN_TR"); return e ? atoi(e) : 1; }();
     pl->tn_tr = env_tr && d->dtype == VLFB_BF16 && d->Cn % 8 == 0;
+    if (pl->tn8) pl->tn_tr = 1;
     if (!pl->tn_tr && pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
     static const int env_stem = [] { const char* e = getenv("VLFB_STEM_WGRAD"); return e ? atoi(e) : 1; }();
     if (env_stem && pl->tn_tr && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
@@ -1443,6 +1178,40 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits, (unsigned)batch);
     } else {
       pl->grid = dim3((unsigned)pl->splits, 1, 1);
+    }
+  }
+  pl->nt8 = 0;
+  pl->nt8_mode = 0;
+  if (d->mode != VLFB_CONV_WGRAD && d->algo != VLFB_ALGO_TILE128) {
+    // 256-row phase-pipelined kernel (vlfb_gemm8.hip): bf16, 16-byte epilogue legal, at least 128 output
+    // channels and 128 k; gathered operands need taps that span whole 64-element k-tiles (and unit stride
+    // for DGRAD) and at most 32 taps (one validity bit per tap and row)
+    const bool gather_ok = pl->ident || (!d->pack_w && ((long long)d->Cs * es) % 128 == 0 && taps <= 32 &&
+                                         (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
+    const bool ok = d->dtype == VLFB_BF16 && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024;
+    if (d->algo == VLFB_ALGO_PIPE256)
+      VLFB_REQUIRE(ok, "conv: algo = PIPE256 needs bf16, Cn >= 128, K >= 128, M >= 1024, 16-byte aligned rows and "
+                       "taps spanning whole k-tiles");
+    // Library choice (measured per layer on MI355X at the 8-clip shapes, scratch/nt8_probe.cpp, tables in
+    // profiles/): with ONE 128-160 KiB workgroup per CU the prologue and the epilogue of a tile are exposed,
+    // so the pipelined kernel only wins where the k-loop is long and the tile count fills whole rounds of
+    // CUs without a heavy epilogue: 512-column outputs with K >= 1024 (res5 3x3 / 3x1x1 / 1x1x1, the
+    // non-local theta conv: 1.07-1.20x) and the batched P.g products of the non-local blocks (1.15-1.20x).
+    // Elsewhere (Cn = 2048 with residual + mask epilogues, K <= 512, the res3 / res4 shapes whose tiles
+    // fill half the chip) the 128x128 kernel with 2-3 co-resident workgroups is 1.1-1.6x faster.
+    const bool want = d->algo == VLFB_ALGO_PIPE256 ||
+                      (ok && ((d->Cn == 512 && K >= 1024) ||
+                              (batch > 1 && K >= 768 && d->Cn >= 256 && d->Cn <= 512 && d->out_dtype == VLFB_BF16)));
+    if (ok && want) {
+      const int pad256 = (d->Cn + 255) / 256 * 256, pad128 = (d->Cn + 127) / 128 * 128;
+      pl->nt8 = pad256 <= pad128 ? 256 : 128;
+      pl->nt8_mode = pl->ident ? 0 : (d->mode == VLFB_CONV_FPROP ? 1 : 2);
+      g.tiles_n = (d->Cn + pl->nt8 - 1) / pl->nt8;
+      // rows per tile: 256, or 196 (7 of 8 fragment rows useful) when that fills whole rounds of 256 CUs better
+      const long long t256 = (M + 255) / 256 * g.tiles_n * batch, t196 = (M + 195) / 196 * g.tiles_n * batch;
+      const long long c256 = (t256 + 255) / 256 * 8, c196 = (t196 + 255) / 256 * 7;
+      pl->nt8_bm = c196 < c256 ? 196 : 256;
+      g.tiles_m = (int)((M + pl->nt8_bm - 1) / pl->nt8_bm);
     }
   }
   pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
@@ -1563,11 +1332,17 @@ int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
     hipLaunchKernelGGL(stem_wgrad_kernel, pl.grid, dim3(512), pl.lds, s, pl.gp);
     return check_launch("conv wgrad (stem) kernel");
   }
+  if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn8)
+    return launch_tn8(pl.gp, pl.grid, sizeof(OutT) == 4, s);
   if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn_tr) {
     if (pl.ident) launch_tn_tr<OutT, true, false>(pl, s);
     else if (pl.packw) launch_tn_tr<OutT, false, true>(pl, s);
     else launch_tn_tr<OutT, false, false>(pl, s);
     return check_launch("conv wgrad (tr) kernel");
+  }
+  if (d->mode != VLFB_CONV_WGRAD && pl.nt8) {
+    if constexpr (sizeof(T) == 2)
+      return launch_nt8(pl.gp, pl.nt8_bm, pl.nt8, pl.nt8_mode, sizeof(OutT) == 4, (unsigned)(d->batch > 0 ? d->batch : 1), s);
   }
   if (d->mode == VLFB_CONV_WGRAD) {
     if (pl.ident) launch_tn<T, OutT, true, false>(pl, s);

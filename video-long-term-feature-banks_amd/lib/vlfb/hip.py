@@ -13,6 +13,7 @@ import torch
 F32, BF16 = 0, 1
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256 = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlfb_hip.so")
@@ -48,7 +49,7 @@ class ConvDesc(C.Structure):
         ("a_bstride", C.c_int64), ("b_bstride", C.c_int64), ("o_bstride", C.c_int64),
         ("r_bstride", C.c_int64), ("p_bstride", C.c_int64),
         ("alpha", C.c_float), ("relu", C.c_int32), ("bias_mode", C.c_int32),
-        ("accumulate", C.c_int32), ("splits", C.c_int32),
+        ("accumulate", C.c_int32), ("splits", C.c_int32), ("algo", C.c_int32),
     ]
 
 
