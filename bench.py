@@ -9,9 +9,12 @@ R50-I3D-NL + LFB-NL on synthetic 32 x 224^2 clips (BASELINE.json `metric`), one 
 Rank 0 prints ONE JSON line.  `value` is the whole-job clips/s with the inputs already resident in
 HBM (weak scaling: 8 clips per GPU, i.e. global batch 64 at 8 GPUs as the north star asks).
 `roofline` is the live HIP-event measurement of the dominant kernel family (the implicit-GEMM
-NT kernel: conv fprop + dgrad + the batched attention GEMMs): algorithmic FLOPs / summed launch
-time against the dense bf16 MFMA peak.  `cpu_baseline` is the fp32 CPU oracle (a port: the
-reference has no runnable CPU path) timed on this box's host cores on ONE clip.
+NT kernels: conv fprop + dgrad + the batched attention GEMMs): algorithmic FLOPs / summed launch
+time against the dense bf16 MFMA peak.  The events bracket every launch of the LAST TIMED STEP on the
+stream it is launched on, in the normal two-stream schedule (wgrads overlap the dgrad chain), i.e.
+they are the durations a rocprofv3 kernel trace of the same command shows (profiles/).
+`cpu_baseline` is the fp32 CPU oracle (a port: the reference has no runnable CPU path) timed on this
+box's host cores on ONE clip; `fp32_path` is the same GPU step on the exact-fp32 parity path.
 """
 import argparse
 import collections
@@ -33,13 +36,16 @@ FWD_BWD_GFLOP_PER_CLIP = 1106.1                 # R50-I3D-NL backbone, 3x fwd - 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=150)    # ~3 s timed region at ~20 ms / step
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ava_r50_lfb_nl",
                     help="ava_r50_lfb_nl (metric config) | charades_r50_baseline | charades_r50_lfb_nl | ava_r101_lfb_nl_3l")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--clips-per-gpu", type=int, default=8)
-    ap.add_argument("--rois-per-clip", type=int, default=3)
+    ap.add_argument("--rois-per-clip", type=int, default=0,
+                    help="0 = SURVEY 8d C4 draw U{1..5} per clip (seeded per rank); N > 0 = exactly N per clip")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the extra fp32 parity-path measurement")
+    ap.add_argument("--fp32-steps", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--crop", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -65,14 +71,17 @@ def cpu_baseline(workload, frames, crop, rois_per_clip):
     params = om.synth_params(cfg, seed=2)
     times = []
     budget = time.time() + 30.0
+    t0 = time.time()
+    om.run(cfg, params, inputs, "train", torch.float32, True, lambda name: 1)      # warm-up
+    warm = time.time() - t0
     while len(times) < 3 and (not times or time.time() + times[-1] < budget):
         t0 = time.time()
         om.run(cfg, params, inputs, "train", torch.float32, True, lambda name: 1)
         times.append(time.time() - t0)
     best = sorted(times)[len(times) // 2]
     return {"value": 1.0 / best, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "fp32 torch-CPU oracle fwd+bwd, %d run(s) of one %dx%dx%d clip, median %.2f s, %d threads of %d"
-                      % (len(times), frames, crop, crop, best, cores, os.cpu_count() or 1)}
+            "sample": "fp32 torch-CPU oracle fwd+bwd of one %dx%dx%d clip: 1 warm-up (%.2f s) + %d timed run(s), median %.2f s, "
+                      "%d threads of %d" % (frames, crop, crop, warm, len(times), best, cores, os.cpu_count() or 1)}
 
 
 def main():
@@ -98,7 +107,9 @@ def main():
     model = ModelBuilder(train=True, split="train", name="bench")
     model.build_model(suffix="_train")
     eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED)
-    batch = synth.inputs(cfg, clips, args.rois_per_clip, seed=cfg.RNG_SEED + rank, crop=args.crop, frames=args.frames)
+    rois = args.rois_per_clip if args.rois_per_clip > 0 else synth.rois_per_clip_draw(clips, seed=cfg.RNG_SEED + rank)
+    batch = synth.inputs(cfg, clips, rois, seed=cfg.RNG_SEED + rank, crop=args.crop, frames=args.frames)
+    n_rois = int(batch["proposals_train"].shape[0]) if "proposals_train" in batch else 0
     eng.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in model.input_blob_names))
     eng.feed_params(synth.params(model, seed=cfg.RNG_SEED))
     for k, v in batch.items():
@@ -114,12 +125,11 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1:
-            # HIP-event brackets around every GEMM launch of the last timed step; that step runs
-            # single-stream so each bracket times its kernel alone (no overlap with the side stream)
+            # HIP-event brackets around every GEMM launch of the last timed step, each on the stream the
+            # launch goes to, in the normal two-stream schedule: the durations are the ones the step pays
+            # (and the ones a rocprofv3 kernel trace of this command reports)
             hip.PROFILE = []
-            side, eng.side = eng.side, None
         eng.train_step(lr)
-    eng.side = side if args.steps > 0 else eng.side
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -150,13 +160,18 @@ def main():
         # per-launch attainable time: whichever of the MFMA and the HBM roof binds THIS launch
         f[4] += max(flops / (PEAK_TFLOPS[args.dtype] * 1e12), nbytes / (HBM_PEAK_GBPS * 1e9))
         rows.append((sec, flops, tag))
-    # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_hbm_traffic.txt): rocprofv3
-    # cannot run inside this process, so the counters of the SAME command are read from the profile
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if args.workload == "ava_r50_lfb_nl" and args.dtype == "bf16" and clips == 8 and os.path.exists(tpath):
-        t = json.load(open(tpath))
-        traffic = {"nt": t["gemm_nt"]["bytes_per_launch"], "tn": t["gemm_tn"]["bytes_per_launch"]}
+    # HBM bytes per launch: PMC counters cannot be read from inside this process, so they come from the
+    # committed rocprofv3 --pmc passes of THIS command line (profiles/*_hbm_traffic.json, made by
+    # scratch/pmc_traffic.py); any other workload / dtype / batch reports null and says why
+    traffic, traffic_source = {}, "none: no committed PMC pass for this workload/dtype/batch"
+    for tname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if args.workload == "ava_r50_lfb_nl" and args.dtype == "bf16" and clips == 8 and os.path.exists(tpath):
+            t = json.load(open(tpath))
+            traffic = {"nt": t["gemm_nt"]["bytes_per_launch"], "tn": t["gemm_tn"]["bytes_per_launch"]}
+            traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, read side x2 " \
+                             "per MI355X_MICROARCH.md; not measured in this run)" % tname
+            break
     if args.detail and rank == 0:
         with open(args.detail, "w") as fh:
             agg = collections.OrderedDict()
@@ -172,7 +187,9 @@ def main():
         fl, sec, n, nb, att = fam[key]
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic.get(key),
+                "frac": round(ach / peak, 4), "traffic": traffic.get(key), "traffic_source": traffic_source,
+                "source": "HIP events on the launch stream around every launch of the last timed step "
+                          "(two-stream steady state); sum of algorithmic FLOP / sum of launch durations",
                 "algorithmic_bytes_per_launch": round(nb / max(n, 1)),
                 "algorithmic_GBps": round(nb / sec / 1e9, 1) if sec > 0 else 0.0, "launches_per_step": n,
                 "avg_launch_us": round(sec / max(n, 1) * 1e6, 2), "gflop_per_step": round(fl / 1e9, 1),
@@ -192,18 +209,45 @@ def main():
         ("warmup", args.warmup), ("ms_per_step", round(elapsed / args.steps * 1e3, 3)),
         ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None), ("dtype", args.dtype),
         ("data", "synthetic"),
-        ("config", {"workload": "%s fwd+bwd+allreduce+sgd, %d clips/GPU (global batch %d), %d RoIs/clip, %dx%dx%d clips"
-                                % (args.workload, clips, clips * world, args.rois_per_clip, args.frames, args.crop, args.crop),
+        ("config", {"workload": "%s fwd+bwd+allreduce+sgd, %d clips/GPU (global batch %d), %s, %dx%dx%d clips"
+                                % (args.workload, clips, clips * world,
+                                   ("%d RoIs/clip" % args.rois_per_clip) if args.rois_per_clip > 0 else
+                                   ("RoIs/clip ~ U{1..5} (%d on rank 0)" % n_rois), args.frames, args.crop, args.crop),
                     "parallelism": "dp%d" % world, "final_loss": loss}),
         ("roofline", roof("nt", "gemm_nt_kernel (implicit-GEMM conv fprop+dgrad, attention NT GEMMs)")),
         ("roofline_wgrad", roof("tn", "gemm_tn_kernel (implicit-GEMM conv wgrad, attention TN GEMMs)")),
         ("model_flops_utilisation", round(value * FWD_BWD_GFLOP_PER_CLIP / 1e3 / (world * peak), 4)),
         ("host_enqueue_ms_per_step", round(host_ms, 2)),
     ])
+    if world == 1 and args.dtype == "bf16" and not args.no_fp32_line:
+        # the parity-grade path (exact-fp32 MFMA, fp32 storage: outputs AND gradients within 1e-3 of the fp64
+        # oracle) on the same workload, so that the number next to the parity claim exists
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            eng32 = Engine(model, "fp32", device=device, base_seed=cfg.RNG_SEED)
+            eng32.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in model.input_blob_names))
+            eng32.feed_params(synth.params(model, seed=cfg.RNG_SEED))
+            for k, v in batch.items():
+                if k in model.input_blob_names:
+                    eng32.feed(k, v)
+            eng32.train_step(lr)
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(args.fp32_steps):
+                eng32.train_step(lr)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t32) / max(args.fp32_steps, 1)
+            out["fp32_path"] = {"value": round(clips / dt32, 3), "unit": "clips/s", "ms_per_step": round(dt32 * 1e3, 3),
+                                "steps": args.fp32_steps, "dtype": "fp32 storage + v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak)",
+                                "model_flops_utilisation": round(clips / dt32 * FWD_BWD_GFLOP_PER_CLIP / 1e3 / PEAK_TFLOPS["fp32"], 4)}
+            del eng32
+        except Exception as e:   # a report, never a gate
+            out["fp32_path"] = {"value": None, "error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, args.frames, args.crop, args.rois_per_clip)
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.frames, args.crop, max(args.rois_per_clip, 3))
             except Exception as e:  # the baseline is a report, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

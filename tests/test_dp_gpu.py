@@ -147,3 +147,118 @@ def test_rccl_bucketed_allreduce_one_rank():
     assert eng.comm is None
     for n, g in got.items():
         assert np.array_equal(g, eng.fetch_grad(n)), n
+
+
+# ---- AVA: a different number of RoIs on every rank ---------------------------------------------------------
+AVA_OV = ["TRAIN.VIDEO_LENGTH", 16, "TRAIN.CROP_SIZE", 64]
+ROIS = {0: [1], 1: [4]}
+CHECK = ("pred_w", "lfb_nl0_theta_w", "res5_2_branch2c_w", "nonlocal_conv4_1_out_w", "conv1_w")
+
+
+def _ava_rank_inputs(cfg, rank):
+    from oracle import model as om
+    return om.synth_inputs(cfg, 1, "train", seed=20 + rank, rois_per_clip=ROIS[rank], crop=64, frames=16)
+
+
+def _ava_worker(rank, world, port, q):
+    import collections
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), VLFB_FORCE_DEVICE="0", VLFB_DIST_BACKEND="gloo")
+    from vlfb import dist
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb.engine import Engine
+    from oracle import model as om
+    dist.init_from_env()
+    load_preset("ava_r50_lfb_nl", ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", world] + AVA_OV)
+    inputs = _ava_rank_inputs(cfg, rank)
+    params = om.synth_params(cfg, seed=2)
+    model = ModelBuilder(train=True, split="train", name="dp")
+    model.build_model(suffix="_train")
+    eng = Engine(model, "fp32", device="cuda:0", base_seed=2)
+    assert eng.replica == rank
+    eng.plan(collections.OrderedDict((k + "_train", v.shape) for k, v in inputs.items()))
+    eng.feed_params(params)
+    for k, v in inputs.items():
+        eng.feed(k + "_train", v)
+    eng.enable_data_parallel(bucket_mb=4)
+    eng.forward()
+    eng.backward()
+    eng.comm.wait()
+    torch.cuda.synchronize()
+    drop = [s for s in eng.steps if type(s).__name__ == "DropoutStep" and s.out.name == "pool5_dropout"][0]
+    out = {n: eng.fetch_grad(n) for n in CHECK}
+    out["_mask_row0"] = drop.mask.view(-1)[:drop.ch * drop.inner].cpu().numpy().copy()
+    out["_loss"] = float(eng.fetch("loss").reshape(-1)[0])
+    q.put((rank, out))
+    dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_with_different_roi_counts_sum_their_per_gpu_normalised_losses():
+    """Each GPU normalises its loss by ITS OWN number of valid targets and scales by 1/NUM_GPUS
+    (resnet_video.py:333-338), so with 1 RoI on rank 0 and 4 on rank 1 the all-reduced gradient is the SUM
+    of the two per-rank oracle gradients -- not the gradient of one 5-RoI batch.  Also: the replicas draw
+    different dropout masks (one RNG per GPU in the reference)."""
+    import torch.multiprocessing as mp
+    _setup_paths()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ava_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from vlfb import rng as vrng
+    from oracle import model as om
+    load_preset("ava_r50_lfb_nl", ["NUM_GPUS", 2, "TRAIN.BATCH_SIZE", 2] + AVA_OV)
+    params = om.synth_params(cfg, seed=2)
+    total, losses = None, []
+    for rank in range(2):
+        blobs, grads = om.run(cfg, params, _ava_rank_inputs(cfg, rank), "train", torch.float64, True,
+                              lambda name, r=rank: vrng.dropout_seed(2, name, 0, r), num_gpus=2)
+        losses.append(float(blobs["loss"].detach()))
+        total = {n: g.clone() for n, g in grads.items()} if total is None else {n: total[n] + grads[n] for n in total}
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    for rank in range(2):
+        assert abs(results[rank]["_loss"] - losses[rank]) < 1e-4 * abs(losses[rank]), (rank, results[rank]["_loss"], losses[rank])
+    for n in CHECK:
+        assert np.array_equal(results[0][n], results[1][n]), "ranks disagree after all-reduce: " + n
+        assert rel(results[0][n], total[n].numpy()) < 5e-3, (n, rel(results[0][n], total[n].numpy()))   # fp32 path bar (test_model_gpu)
+    assert not np.array_equal(results[0]["_mask_row0"], results[1]["_mask_row0"]), "replicas share a dropout mask"
+
+
+def test_data_parallel_refuses_a_job_size_that_differs_from_num_gpus():
+    """enable_data_parallel: the loss scale and the per-GPU batch come from cfg.NUM_GPUS"""
+    import collections
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      VLFB_DIST_FORCE="1", VLFB_DIST_BACKEND="gloo")
+    from vlfb import dist, hip
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb.engine import Engine
+    from oracle import model as om
+    try:
+        dist.init_from_env()
+        load_preset("charades_r50_baseline", ["NUM_GPUS", 2, "TRAIN.BATCH_SIZE", 2] + OV)   # 2 GPUs configured, 1 rank
+        model = ModelBuilder(train=True, split="train", name="dp")
+        model.build_model(suffix="_train")
+        eng = Engine(model, "fp32", device="cuda:0", base_seed=2)
+        inputs = om.synth_inputs(cfg, 1, "train", seed=2, crop=64, frames=16)
+        eng.plan(collections.OrderedDict((k + "_train", v.shape) for k, v in inputs.items()))
+        with pytest.raises(hip.VlfbError):
+            eng.enable_data_parallel()
+    finally:
+        for k in ("VLFB_DIST_FORCE", "VLFB_DIST_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()

@@ -10,8 +10,14 @@ Tolerances (relative L2 per tensor; measured values are printed with -s):
       backward signal by 1/sqrt(262k) = 2e-3 (measured: the error appears at the first masked
       backward op and stays flat; torch-CPU fp32 vs fp64 shows the same effect when it hits a tie).
   bf16 path (bf16 storage / MFMA operands, fp32 accumulation, fp32 affinity+softmax+loss):
-      activations 2e-2 (measured 6e-3), prob/loss 1e-3 (measured 8e-4 / 3e-5), parameter gradients
-      90th percentile 0.15, max 0.35 (conv1_w, the end of a ~50-layer bf16 backward chain).
+      activations 2e-2 (measured 6e-3), prob/loss 1e-3 (measured 8e-4 / 3e-5).  Parameter gradients
+      are NOT within 1e-3 and cannot be with bf16 forward storage: oracle/bf16_budget.py re-runs the
+      fp64 oracle with a bf16 rounding at the engine's storage points and attributes the error --
+      backward roundings (incl. the residual-stream gradient accumulators) give p90 3e-3, the forward
+      roundings (activations + weight operands: flipped ReLU / max-pool decisions, perturbed saved
+      activations) give p90 4e-2..6e-2 and 0.17..0.18 on the worst tensor.  The engine is held to that
+      budget per tensor (test_bf16_gradient_error_stays_within_the_forward_rounding_budget) and to the
+      measured envelope here: 90th percentile 0.12, max 0.30 (conv1_w, end of the ~50-layer chain).
 """
 import collections
 
@@ -31,7 +37,7 @@ def rel(a, b):
     return np.linalg.norm((a - b).ravel()) / (d if d > 0 else 1.0)
 
 
-def build(preset, dtype, overrides=SMALL, train=True):
+def build(preset, dtype, overrides=SMALL, train=True, **engine_kw):
     from vlfb.presets import load_preset
     from core.config import config as cfg
     from models.model_builder_video import ModelBuilder
@@ -46,7 +52,7 @@ def build(preset, dtype, overrides=SMALL, train=True):
     inputs = om.synth_inputs(cfg, n_clips, "train", seed=cfg.RNG_SEED, rois_per_clip=[2, 3][:n_clips] if cfg.DATASET == "ava" else None,
                              crop=cfg.TRAIN.CROP_SIZE, frames=cfg.TRAIN.VIDEO_LENGTH)
     params = om.synth_params(cfg, seed=cfg.RNG_SEED)
-    eng = Engine(model, dtype, base_seed=cfg.RNG_SEED)
+    eng = Engine(model, dtype, base_seed=cfg.RNG_SEED, **engine_kw)
     sfx = "_" + split
     eng.plan(collections.OrderedDict((k + sfx, v.shape) for k, v in inputs.items()
                                      if (k + sfx) in model.input_blob_names))
@@ -106,7 +112,93 @@ def test_forward_backward_matches_oracle(preset, dtype):
     if dtype == "fp32":
         assert med < 1e-3 and worst[0][1] < 5e-3, (med, worst)
     else:
-        assert p90 < 0.15 and worst[0][1] < 0.35, (p90, worst)
+        assert p90 < 0.12 and worst[0][1] < 0.30, (p90, worst)
+
+
+@pytest.mark.parametrize("preset", ["charades_r50_baseline", "ava_r50_lfb_nl"])
+def test_bf16_gradient_error_stays_within_the_forward_rounding_budget(preset):
+    """every parameter gradient of the bf16 engine is within a small factor of what the fp64 oracle gives
+    when bf16 roundings are inserted at the engine's storage points (oracle/bf16_budget.py), and the
+    backward-only roundings explain less than a fifth of it (=> fp32 gradient accumulators would not help)"""
+    from oracle import model as om, bf16_budget as bb
+    cfg, model, eng, inputs, params, seed_fn = build(preset, "bf16")
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    budget = bb.gradient_budget(cfg, params, inputs, grads, None, seed_fn)
+    bwd_only = bb.gradient_budget(cfg, params, inputs, grads, dict(bwd=True, bwd_res=True), seed_fn)
+    gmax = max(float(g.norm()) for g in grads.values())
+    names = [n for n in eng.trainable if float(grads[n].norm()) > 1e-9 * gmax]
+    err = {n: rel(eng.fetch_grad(n), grads[n].numpy()) for n in names}
+    p90 = lambda d: float(np.sort([d[n] for n in names])[int(0.9 * (len(names) - 1))])
+    ratio = sorted(((err[n] / (budget[n] + 3e-3), n) for n in names), reverse=True)
+    print("\n[%s] engine p90 %.3e | budget p90 %.3e | backward-only budget p90 %.3e | worst engine/budget %s"
+          % (preset, p90(err), p90(budget), p90(bwd_only), ["%s=%.2f" % (n, r) for r, n in ratio[:4]]))
+    assert p90(bwd_only) < 0.2 * p90(budget) and p90(bwd_only) < 1e-2
+    assert p90(err) < 3.0 * p90(budget), (p90(err), p90(budget))
+    for r, n in ratio:
+        assert r < 4.0, "gradient of %s: engine error %.3e, emulated budget %.3e" % (n, err[n], budget[n])
+
+
+FULL = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 32, "TRAIN.CROP_SIZE", 224]
+
+
+@pytest.mark.parametrize("preset", ["charades_r50_baseline", "ava_r50_lfb_nl"])
+def test_full_size_clip_matches_oracle(preset):
+    """ONE clip at the benchmarked size (32 x 224^2: M = 401 408 / 100 352 / 12 544 / 3 136 rows per stage,
+    K up to 6144, 3136 x 784 non-local affinities, the 256-row pipelined kernels, split wgrads with
+    hundreds of slabs) against the fp64 oracle: forward blobs, loss and EVERY parameter gradient, on the
+    fp32 parity path and on the bf16 path that bench.py times.  The per-tensor table goes to
+    $VLFB_PARITY_DIR (committed under profiles/)."""
+    import os
+    from oracle import model as om
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = None
+    lines = []
+    for dtype in ("fp32", "bf16"):
+        cfg, model, eng, inputs, params, seed_fn = build(preset, dtype, FULL)
+        eng.forward()
+        eng.backward()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+        blobs, grads = ref
+        acts = []
+        for name in CHECK_BLOBS:
+            if name in blobs:
+                got = eng.fetch(name)
+                acts.append((name, rel(got, blobs[name].detach().numpy().reshape(got.shape))))
+        ref_loss = float(blobs["loss"].detach())
+        acts.append(("loss", abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) / abs(ref_loss)))
+        gmax = max(float(g.norm()) for g in grads.values())
+        gerr = [(n, rel(eng.fetch_grad(n), grads[n].numpy())) for n in eng.trainable
+                if float(grads[n].norm()) > 1e-9 * gmax]
+        e = np.sort([x for _, x in gerr])
+        med, p90, mx = float(np.median(e)), float(e[int(0.9 * (len(e) - 1))]), float(e[-1])
+        lines.append("== %s %s, 1 clip 32x224x224: activations/outputs (relative L2 vs fp64 oracle)" % (preset, dtype))
+        lines += ["  %-28s %.3e" % x for x in acts]
+        lines.append("   parameter gradients: median %.3e  p90 %.3e  max %.3e (%d tensors)" % (med, p90, mx, len(gerr)))
+        lines += ["  %-44s %.3e" % x for x in sorted(gerr, key=lambda x: -x[1])]
+        print("\n".join(lines[-(len(gerr) + len(acts) + 2):][:len(acts) + 8]))
+        a = dict(acts)
+        if dtype == "fp32":
+            assert max(a.values()) < 1e-3, acts
+            assert med < 1e-3 and mx < 5e-3, (med, mx)
+        else:
+            assert max(v for k, v in a.items() if k not in ("prob", "loss")) < 2e-2, acts
+            assert a["prob"] < 1e-3 and a["loss"] < 1e-3, acts
+            # measured: charades p90 5e-2 / max 0.24, ava p90 6.8e-2 / max 0.32 (conv1_w, the end of the chain;
+            # 401 408-row tensors amplify the forward-rounding budget of oracle/bf16_budget.py a little further)
+            assert p90 < 0.12 and mx < 0.45, (p90, mx)
+        del eng
+        torch.cuda.empty_cache()
+    out = os.environ.get("VLFB_PARITY_DIR")
+    if out:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_fullsize_%s.txt" % preset), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
 
 
 VARIANTS = {
@@ -151,7 +243,7 @@ def test_roi_head_integer_decisions_are_bit_exact():
     from oracle import model as om
     from oracle.roi_align import roi_align_loop
     from vlfb.engine import RoiAlignMaxStep
-    cfg, model, eng, inputs, params, seed_fn = build("ava_r50_lfb_nl", "fp32")
+    cfg, model, eng, inputs, params, seed_fn = build("ava_r50_lfb_nl", "fp32", debug_roi=True)
     eng.forward()
     torch.cuda.synchronize()
     step = [s for s in eng.steps if isinstance(s, RoiAlignMaxStep)][0]

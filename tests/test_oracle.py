@@ -129,3 +129,26 @@ def test_sigmoid_ce_matches_closed_form():
     bce = torch.nn.functional.binary_cross_entropy_with_logits(x, t.clamp(min=0).double(), reduction="none")
     want = 0.125 * (bce * valid).sum() / valid.sum()
     assert abs(float(om.sigmoid_cross_entropy(x, t, 0.125)) - float(want)) < 1e-12
+
+
+def test_bf16_budget_is_set_by_the_forward_roundings_not_by_gradient_accumulation():
+    """oracle/bf16_budget.py on the small Charades case: rounding every stored activation GRADIENT to bf16
+    (residual-stream accumulators included) perturbs the parameter gradients by a few 1e-3; rounding the
+    forward activations / weight operands by a few 1e-2.  This is the evidence behind keeping activation
+    gradients in bf16 on the throughput path."""
+    import torch
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from oracle import model as om, bf16_budget as bb
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 8,
+                                          "TRAIN.CROP_SIZE", 64])
+    inputs = om.synth_inputs(cfg, 1, "train", seed=cfg.RNG_SEED, crop=64, frames=8)
+    params = om.synth_params(cfg, seed=cfg.RNG_SEED)
+    _, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda name: 3)
+    p90 = lambda d: float(np.sort([v for n, v in d.items() if float(grads[n].norm()) > 0])[int(0.9 * (len(d) - 1))])
+    bwd = bb.gradient_budget(cfg, params, inputs, grads, dict(bwd=True, bwd_res=True), lambda name: 3)
+    fwd = bb.gradient_budget(cfg, params, inputs, grads, dict(fwd=True, w=True), lambda name: 3)
+    exact = bb.gradient_budget(cfg, params, inputs, grads, {}, lambda name: 3)
+    assert max(exact.values()) < 1e-12               # the instrumented oracle without roundings IS the oracle
+    assert p90(bwd) < 1e-2 and p90(fwd) > 3 * p90(bwd), (p90(bwd), p90(fwd))

@@ -99,3 +99,58 @@ def test_infer_bank_train_checkpoint_resume(tmp_path):
     for n, v in want.items():
         assert np.array_equal(eng3.fetch_param(n), v), n
     assert np.array_equal(eng3.fetch_momentum("pred_w"), mom)
+
+
+def test_momentum_correction_on_learning_rate_jumps():
+    """ModelBuilder.UpdateWorkspaceLr / _SetNewLr / _CorrectMomentum (model_builder_video.py:258-314):
+    when the LR changes by more than SOLVER.SCALE_MOMENTUM_THRESHOLD the update history V (= momentum
+    blobs, V := mu V + lr g) of every trainable parameter is scaled by new_lr / old_lr; smaller changes
+    (warm-up ramps) leave it alone; SCALE_MOMENTUM False disables it."""
+    import collections
+    import numpy as np
+    import torch
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb.engine import Engine
+    from vlfb import synth
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64,
+                                          "SOLVER.BASE_LR", 0.02, "SOLVER.LR_POLICY", "steps_with_relative_lrs",
+                                          "SOLVER.STEP_SIZES", [2, 2], "SOLVER.LRS", [1, 0.1], "SOLVER.MAX_ITER", 4,
+                                          "SOLVER.SCALE_MOMENTUM", True, "SOLVER.SCALE_MOMENTUM_THRESHOLD", 1.1])
+    m = ModelBuilder(train=True, split="train", name="train")
+    m.build_model(suffix="_train")
+    eng = Engine(m, "fp32", device="cuda:0", base_seed=2)
+    batch = synth.inputs(cfg, 1, seed=3, crop=64, frames=8)
+    eng.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in m.input_blob_names))
+    eng.init_params(seed=1)
+    for k, v in batch.items():
+        if k in m.input_blob_names:
+            eng.feed(k, v)
+    names = ["pred_w", "res3_1_branch2a_w", "conv1_w"]
+    m.UpdateWorkspaceLr(0)
+    assert abs(eng.lr - 0.02) < 1e-9
+    eng.train_step()
+    m.UpdateWorkspaceLr(1)                         # same LR: the history is untouched
+    v1 = {n: eng.fetch_momentum(n).copy() for n in names}
+    eng.train_step()
+    v2 = {n: eng.fetch_momentum(n).copy() for n in names}
+    m.UpdateWorkspaceLr(2)                         # 0.02 -> 0.002: ratio 10 > 1.1
+    torch.cuda.synchronize()
+    assert abs(eng.lr - 0.002) < 1e-9 and abs(m.current_lr - 0.002) < 1e-9
+    for n in names:
+        assert not np.array_equal(v1[n], v2[n])
+        got = eng.fetch_momentum(n)
+        assert np.allclose(got, v2[n] * np.float32(0.1), rtol=1e-6, atol=0), n
+    # a change below the threshold only moves the LR
+    v3 = {n: eng.fetch_momentum(n).copy() for n in names}
+    m._SetNewLr(m.current_lr, m.current_lr * 1.05)
+    torch.cuda.synchronize()
+    for n in names:
+        assert np.array_equal(eng.fetch_momentum(n), v3[n])
+    # switched off
+    cfg.SOLVER.SCALE_MOMENTUM = False
+    m._SetNewLr(m.current_lr, m.current_lr * 10.0)
+    torch.cuda.synchronize()
+    for n in names:
+        assert np.array_equal(eng.fetch_momentum(n), v3[n])

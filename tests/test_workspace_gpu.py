@@ -111,3 +111,62 @@ def test_checkpoint_round_trip_through_the_device_engine(tmp_path):
     np.testing.assert_allclose(got, np.repeat(w3.sum(axis=2, keepdims=True), 3, axis=2) / 3.0, rtol=1e-6)
     assert np.array_equal(workspace.FetchBlob("gpu_0/pred_w"), pred0)
     workspace.ResetWorkspace()
+
+
+def test_train_and_test_nets_of_one_scope_share_their_parameter_blobs():
+    """tools/train_net.py keeps train_model and test_model in ONE workspace and evaluates the weights being
+    trained (train_net.py:60-77, 113-131).  Here: the test net's parameters alias the train net's, its MFMA
+    operand copies follow the solver steps, FetchBlob('gpu_0/prob') answers from the net that ran last, and
+    a parameter fed once is seen by both nets."""
+    import torch
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb import workspace, synth
+    from vlfb.engine import Engine
+    workspace.ResetWorkspace()
+    workspace.set_compute_dtype("fp32")
+    ov = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TEST.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TEST.VIDEO_LENGTH", 8,
+          "TRAIN.CROP_SIZE", 64, "TEST.CROP_SIZE", 64, "TRAIN.DROPOUT_RATE", 0.0]
+    load_preset("charades_r50_baseline", ov)
+    train = ModelBuilder(train=True, split="train", name="train")
+    train.build_model(suffix="_train")
+    test = ModelBuilder(train=False, split="val", name="val")
+    test.build_model(suffix="_test")
+    workspace.register(train)
+    workspace.register(test)
+    tb = synth.inputs(cfg, 2, seed=5, crop=64, frames=8, suffix="_train")
+    vb = synth.inputs(cfg, 2, seed=6, crop=64, frames=8, suffix="_test")
+    for k, v in list(tb.items()) + list(vb.items()):
+        workspace.FeedBlob("gpu_0/" + k, v)
+    e_train = workspace.CreateNet(train.net)
+    e_test = workspace.CreateNet(test.net)
+    assert e_test.param_views["pred_w"].data_ptr() == e_train.param_views["pred_w"].data_ptr()
+    assert e_test.param_views["conv1_w"].data_ptr() == e_train.param_views["conv1_w"].data_ptr()
+    workspace.RunNet(test.net)
+    p0 = workspace.FetchBlob("gpu_0/prob").copy()              # evaluation before training
+    train.UpdateWorkspaceLr(0)
+    for _ in range(3):
+        workspace.RunNet(train.net)
+    p_train = workspace.FetchBlob("gpu_0/prob").copy()         # the TRAIN net ran last: its prob
+    workspace.RunNet(test.net)
+    p1 = workspace.FetchBlob("gpu_0/prob").copy()              # now the test net's, with the trained weights
+    assert not np.allclose(p1, p0) and not np.array_equal(p1, p_train)
+    # reference: a stand-alone test engine fed with the trained parameters gives the same probabilities
+    ref = Engine(test, "fp32")
+    import collections
+    ref.plan(collections.OrderedDict((n, vb[n].shape) for n in test.input_blob_names))
+    ref.feed_params({n: e_train.fetch_param(n) for n in ref.param_views})
+    for n in test.input_blob_names:
+        ref.feed(n, vb[n])
+    ref.forward()
+    torch.cuda.synchronize()
+    assert np.array_equal(ref.fetch("prob"), p1)
+    test.engine = e_test
+    # one FeedBlob reaches both nets
+    new_b = np.linspace(-1, 1, 157).astype(np.float32)
+    workspace.FeedBlob("gpu_0/pred_b", new_b)
+    assert np.array_equal(e_train.fetch_param("pred_b"), new_b) and np.array_equal(e_test.fetch_param("pred_b"), new_b)
+    workspace.RunNet(test.net)
+    assert not np.array_equal(workspace.FetchBlob("gpu_0/prob"), p1)
+    workspace.ResetWorkspace()

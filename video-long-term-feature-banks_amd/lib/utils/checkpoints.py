@@ -87,10 +87,18 @@ def read_blobs(path):
 
 
 def write_blobs(path, blobs, wrap=True):
-    tmp = path + ".tmp"
-    with open(tmp, "wb") as fh:
-        pickle.dump(dict(blobs=dict(blobs)) if wrap else dict(blobs), fh, protocol=2)
-    os.replace(tmp, path)
+    """atomic: a uniquely named temporary in the destination directory, then rename (several processes --
+    one per GPU -- may run the same start-up code; they must never share a half-written file)"""
+    import tempfile
+    fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=os.path.dirname(path) or ".")
+    try:
+        with os.fdopen(fd, "wb") as fh:
+            pickle.dump(dict(blobs=dict(blobs)) if wrap else dict(blobs), fh, protocol=2)
+        os.replace(tmp, path)
+    except Exception:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise
 
 
 # ---- conversions ------------------------------------------------------------------------------
@@ -136,12 +144,15 @@ def load_and_convert_caffe2_cls_model(model_file_name):
 def convert_model(model_path):
     """CHECKPOINT.CONVERT_MODEL: drop the classifier (`pred*`) and any momentum, pin lr, write
     <checkpoint dir>/converted_model.pkl as a bare dict (checkpoints.py:152-183)"""
+    from vlfb import dist
     out_path = os.path.join(create_and_get_checkpoint_directory(), "converted_model.pkl")
-    blobs = load_and_convert_caffe2_cls_model(model_path)["blobs"]
-    for k in [k for k in blobs if "pred" in k or "momentum" in k]:
-        del blobs[k]
-    blobs["lr"] = 0.00125
-    write_blobs(out_path, blobs, wrap=False)
+    if dist.rank() == 0:          # one process per GPU: rank 0 converts, the others wait for the file
+        blobs = load_and_convert_caffe2_cls_model(model_path)["blobs"]
+        for k in [k for k in blobs if "pred" in k or "momentum" in k]:
+            del blobs[k]
+        blobs["lr"] = 0.00125
+        write_blobs(out_path, blobs, wrap=False)
+    dist.barrier()
     return out_path
 
 
@@ -278,12 +289,19 @@ def load_model_from_params_file(model):
     else:
         start_iter = 0
         logger.info("No checkpoint found; training from scratch...")
+    # the iteration also seeds the dropout masks: a resumed run continues the mask sequence
+    eng = getattr(model, "engine", None)
+    if eng is not None:
+        eng.iteration = int(start_iter)
     return start_iter
 
 
 def save_model_params(model, params_file, model_iter):
     """momentum of the trainable parameters, then all (computed) parameters, `model_iter + 1`, `lr`
     (checkpoints.py:421-459)"""
+    from vlfb import dist
+    if dist.rank() != 0:           # replicas hold identical parameters: rank 0 writes
+        return
     eng = _engine(model)
     out = OrderedDict()
     out["model_iter"] = model_iter + 1

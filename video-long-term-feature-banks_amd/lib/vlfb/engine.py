@@ -505,7 +505,7 @@ class DropoutStep(Step):
         self.inner = self.x.numel // (self.rows * self.ch)
 
     def fwd(self):
-        seed = dropout_seed(self.eng.base_seed, self.out.name, self.eng.iteration)
+        seed = dropout_seed(self.eng.base_seed, self.out.name, self.eng.iteration, self.eng.replica)
         hip.call("vlfb_dropout_fwd", self.x.ptr(), self.out.ptr(), hip.ptr(self.mask), self.eng.code, self.rows,
                  self.inner, self.ch, self.ratio, seed)
 
@@ -536,7 +536,10 @@ class RoiAlignMaxStep(Step):
         self.N, self.Cc, self.H, self.W = self.feat.shape
         self.R = self.rois.shape[0]
         self.argbin = torch.empty(self.R * self.Cc, device=eng.device, dtype=torch.uint8)
-        self.dbg = torch.zeros(self.R * self.pooled * self.pooled * 8, device=eng.device, dtype=torch.int32)
+        # integer decisions of every bilinear sample (thread 0 of a workgroup re-derives them serially):
+        # only recorded when a test asks for them (Engine.debug_roi), never on the hot path
+        self.dbg = (torch.zeros(self.R * self.pooled * self.pooled * 8, device=eng.device, dtype=torch.int32)
+                    if eng.debug_roi else None)
         if eng.train:
             self.dfeat = torch.empty(self.feat.numel, device=eng.device, dtype=torch.float32)
 
@@ -1069,8 +1072,19 @@ class Lowering(object):
 class Engine(object):
     """One per-GPU replica: plan once, then forward()/backward()/allreduce()/sgd_step()."""
 
-    def __init__(self, model, dtype="bf16", device=None, base_seed=None, dry_run=False):
+    def __init__(self, model, dtype="bf16", device=None, base_seed=None, dry_run=False, debug_roi=False,
+                 share_params_with=None):
+        """share_params_with: another Engine of the same scope (the train net's, when this is the test / val
+        net of the same process).  Caffe2 nets of one workspace share their parameter BLOBS
+        (tools/train_net.py builds train_model and test_model in one workspace and evaluates the weights
+        being trained); parameters with the same name and shape then alias the owner's storage here, and the
+        MFMA operand copies of this engine are rebuilt whenever the owner's parameters have changed."""
         hip.lib()   # fail loudly if the native library is missing
+        self.debug_roi = bool(debug_roi)
+        self.param_owner = share_params_with
+        # [version] of the parameter storage, shared by the engines that alias it
+        self._pstate = share_params_with._pstate if share_params_with is not None else [0]
+        self._operand_version = -1
         self.dry_run = bool(dry_run)   # plan on the 'meta' device: shapes/fusion/bytes only, nothing runs
         if not self.dry_run and not torch.cuda.is_available():
             raise hip.VlfbError("vlfb.engine needs a GPU: there is no CPU fallback for the hot path")
@@ -1082,6 +1096,7 @@ class Engine(object):
         self.train = bool(model.train and not model.force_fw_only and model.loss_blob is not None)
         self.base_seed = int(cfg.RNG_SEED if base_seed is None else base_seed)
         self.iteration = 0
+        self.replica = dist.rank()    # folded into the dropout seeds: replicas draw independent masks
         self.trainable = [p for p in model.params if p in model.param_to_grad] if self.train else []
         self._trainable_set = set(self.trainable)
         self.steps = None
@@ -1225,6 +1240,13 @@ class Engine(object):
             self.param_views[n] = self.flat_param[off:off + cnt].view(shape)
         for n, (off, cnt, shape) in self.frozen_layout.items():
             self.param_views[n] = self.flat_frozen[off:off + cnt].view(shape)
+        self.shared_params = set()
+        if self.param_owner is not None and not self.train:
+            for n in list(self.param_views):
+                o = self.param_owner.param_views.get(n)
+                if o is not None and tuple(o.shape) == tuple(self.param_views[n].shape) and o.device == self.param_views[n].device:
+                    self.param_views[n] = o
+                    self.shared_params.add(n)
         # weight decay per parameter (model_builder_video.py:365-372): WEIGHT_DECAY_BN when the name
         # contains '_bn', else WEIGHT_DECAY; neighbours with the same value share one solver launch
         self.wd_ranges = []
@@ -1335,6 +1357,7 @@ class Engine(object):
             if name not in self.param_views:
                 raise KeyError("unknown parameter %r" % name)
             self.param_views[name].copy_(self._to_kernel_layout(name, arr).to(self.device))
+        self._pstate[0] += 1
         self.refresh_operands(all_params=True)
 
     def init_params(self, seed=None):
@@ -1342,6 +1365,8 @@ class Engine(object):
         gen = np.random.default_rng(self.base_seed if seed is None else seed)
         out = {}
         for name in self.model.params:
+            if name in getattr(self, "shared_params", ()):
+                continue                      # owned (and initialised / trained) by the engine we share with
             f = self.model.param_init_net.fills[name]
             shape = f.shape
             if f.fill == "ConstantFill":
@@ -1411,6 +1436,7 @@ class Engine(object):
         for st in self.steps:
             if isinstance(st, ConvStep) and st.eff_bias is not None and (all_params or st.params):
                 st.refresh_bias()
+        self._operand_version = self._pstate[0]
 
     # ---- data ---------------------------------------------------------------------------------
     def feed(self, name, arr):
@@ -1487,6 +1513,9 @@ class Engine(object):
 
     # ---- execution ----------------------------------------------------------------------------
     def forward(self):
+        if self._operand_version != self._pstate[0]:
+            # parameters were changed through another engine that shares them (the train net's solver)
+            self.refresh_operands(all_params=True)
         for st in self.steps:
             st.fwd()
 
@@ -1500,9 +1529,25 @@ class Engine(object):
         for i, st in enumerate(self.bwd_steps):
             st.bwd()
             if self.comm is not None and self.comm.due(i):
-                self.join_side_stream()       # the bucket's gradients were produced on the side stream
-                self.comm.after_step(i)
+                self._issue_buckets(i)
         self.join_side_stream()
+
+    def _issue_buckets(self, i):
+        """all-reduce the buckets that became final with backward step i WITHOUT stalling the dgrad chain:
+        their gradients were produced on the side stream (wgrads, bias column sums) or, for the classifier,
+        on the main stream.  The reduction is issued with the SIDE stream current, after the side stream has
+        been made to wait for the main stream's position: ProcessGroupNCCL orders the collective behind the
+        stream that is current at the call, so the bucket waits for exactly its producers and the main
+        stream keeps running dgrads (it only joins the side stream once, at the end of backward)."""
+        if self.side is None:
+            self.comm.after_step(i)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            self.comm.after_step(i)
+        self.side_dirty = True
 
     def set_lr(self, lr):
         self.lr = float(lr)
@@ -1514,6 +1559,11 @@ class Engine(object):
         from vlfb.comm import GradComm
         if not (self.train and (dist.world_size() > 1 or (dist.forced() and dist.initialized()))):
             return
+        # the loss is pre-scaled by 1/NUM_GPUS and the per-GPU batch is BATCH_SIZE/NUM_GPUS
+        # (resnet_video.py:333-338, misc.py:68-72): a job of another size would silently mis-scale gradients
+        if dist.world_size() != int(cfg.NUM_GPUS):
+            raise hip.VlfbError("data parallel: %d ranks but cfg.NUM_GPUS = %d (loss scale and per-GPU batch come "
+                                "from NUM_GPUS)" % (dist.world_size(), int(cfg.NUM_GPUS)))
         td.broadcast(self.flat_param, 0)
         td.broadcast(self.flat_frozen, 0)
         self.refresh_operands(all_params=True)
@@ -1546,6 +1596,7 @@ class Engine(object):
             hip.call("vlfb_sgd_update", hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off,
                      hip.ptr(self.flat_mom) + 4 * off, end - off, self.lr, wd, float(sol.MOMENTUM),
                      int(bool(sol.NESTEROV)))
+        self._pstate[0] += 1
         self.refresh_operands()
         self.iteration += 1
 

@@ -11,8 +11,17 @@ from collections import OrderedDict
 import numpy as np
 
 
+def rois_per_clip_draw(n_clips, seed=2):
+    """RoIs per clip ~ U{1..5} (so R ~ 3 per clip on average)"""
+    gen = np.random.default_rng(seed + 7919)
+    return [int(gen.integers(1, 6)) for _ in range(n_clips)]
+
+
 def inputs(cfg, n_clips, rois_per_clip=3, seed=2, crop=None, frames=None, suffix="_train"):
+    """rois_per_clip: an int (every clip) or a list with one count per clip"""
     gen = np.random.default_rng(seed)
+    per_clip = list(rois_per_clip) if isinstance(rois_per_clip, (list, tuple)) else [int(rois_per_clip)] * n_clips
+    assert len(per_clip) == n_clips
     crop = crop or cfg.TRAIN.CROP_SIZE
     frames = frames or cfg.TRAIN.VIDEO_LENGTH
     out = OrderedDict()
@@ -21,7 +30,7 @@ def inputs(cfg, n_clips, rois_per_clip=3, seed=2, crop=None, frames=None, suffix
     if cfg.DATASET == "ava":
         rows = []
         for c in range(n_clips):
-            for _ in range(rois_per_clip):
+            for _ in range(per_clip[c]):
                 x1, y1 = gen.uniform(0, crop - 9, 2)
                 rows.append([c, x1, y1, gen.uniform(x1 + 8, crop - 1), gen.uniform(y1 + 8, crop - 1)])
         out["proposals" + suffix] = np.asarray(rows, dtype=np.float32)

@@ -7,9 +7,10 @@ objects, blobs are device tensors owned by the model's Engine.
 """
 import numpy as np
 
-_engines = {}      # id(net) -> engine
+_engines = {}      # id(net) -> engine (insertion order = CreateNet order)
 _models = {}       # id(net) -> model
 _dtype = {"value": "bf16"}
+_clock = {"t": 0}  # RunNet counter: a blob that several nets of one scope produce belongs to the last one run
 
 
 def set_compute_dtype(name):
@@ -28,12 +29,31 @@ def _unscoped(name):
     return name[name.rfind("/") + 1:]
 
 
-def _engine_for_blob(name):
+def _scope_engines(name):
     scope = str(name).split("/")[0] + "/" if "/" in str(name) else None
-    for eng in _engines.values():
-        if scope is None or eng.model.scope == scope:
-            return eng
-    raise KeyError("no engine owns blob %r (CreateNet the model first)" % name)
+    return [e for e in _engines.values() if scope is None or e.model.scope == scope]
+
+
+def _has(eng, base):
+    if base in eng.param_views or base == "lr":
+        return True
+    if base.endswith("_momentum") and eng.train and base[:-9] in eng.train_layout:
+        return True
+    if base.endswith("_grad") and eng.train and base[:-5] in eng.grad_views:
+        return True
+    b = eng.env.get(base) or (eng.env.get(base[:-5]) if base.endswith("_grad") else None)
+    return b is not None and not getattr(b.root, "dead", False)
+
+
+def _engine_for_blob(name):
+    """Caffe2 semantics: the nets of one workspace share a blob namespace per device scope, so
+    `gpu_0/prob` is whatever the LAST net that ran wrote there.  Among the engines of the scope that
+    have the blob, the one that ran most recently answers (parameters are shared storage anyway)."""
+    base = _unscoped(name)
+    cands = [e for e in _scope_engines(name) if _has(e, base)]
+    if not cands:
+        raise KeyError("no engine owns blob %r (CreateNet the model first)" % name)
+    return max(cands, key=lambda e: getattr(e, "_last_run", -1))
 
 
 def CreateNet(net, input_shapes=None, dtype=None):
@@ -42,7 +62,10 @@ def CreateNet(net, input_shapes=None, dtype=None):
     fed with FeedBlob before (their shapes are taken from the fed arrays)."""
     from vlfb.engine import Engine
     model = _models[id(net)]
-    eng = Engine(model, dtype or _dtype["value"])
+    # a second net of the same scope (test_model next to train_model, tools/train_net.py:60-77) shares the
+    # parameter blobs of the first one that trains
+    owner = next((e for e in _engines.values() if e.model.scope == model.scope and e.train), None)
+    eng = Engine(model, dtype or _dtype["value"], share_params_with=owner if not (model.train and not model.force_fw_only) else None)
     shapes = dict(input_shapes or {})
     for k, v in _pending.items():
         if k in model.input_blob_names and k not in shapes:
@@ -73,6 +96,8 @@ def RunNetOnce(net):
 def RunNet(net, num_iter=1):
     """one (or more) forward[+backward+update] passes, like workspace.RunNet(model.net)"""
     eng = _engines[id(net) if not isinstance(net, str) else next(k for k, e in _engines.items() if e.model.net.name == net)]
+    _clock["t"] += 1
+    eng._last_run = _clock["t"]
     for _ in range(num_iter):
         eng.forward()
         if eng.train:
@@ -87,20 +112,26 @@ def RunNet(net, num_iter=1):
 def FeedBlob(name, arr):
     arr = np.asarray(arr)
     base = _unscoped(name)
-    for eng in _engines.values():
+    fed = False
+    done = set()           # storages already written (engines of one scope alias their parameters)
+    for eng in _scope_engines(name):
         if base in eng.model.input_blob_names:
             eng.feed(base, arr)
-            return True
-        if base in eng.param_views:
-            eng.feed_params({base: arr})
-            return True
-        if base.endswith("_momentum") and eng.train and base[:-9] in eng.train_layout:
+            fed = True
+        elif base in eng.param_views:
+            key = eng.param_views[base].data_ptr()
+            if key not in done:
+                eng.feed_params({base: arr})
+                done.add(key)
+            fed = True
+        elif base.endswith("_momentum") and eng.train and base[:-9] in eng.train_layout:
             eng.feed_momentum({base[:-9]: arr})
-            return True
-        if base == "lr":
+            fed = True
+        elif base == "lr":
             eng.set_lr(float(arr))
-            return True
-    _pending[base] = arr
+            fed = True
+    if not fed:
+        _pending[base] = arr
     return True
 
 
