@@ -264,6 +264,11 @@ int vlfb_fc_bwd(const void* x, int dtype, const float* w, const float* dlogits, 
  * dlogits = scale * (prob - t) / normalizer (0 where ignored).  loss: 1 float. */
 int vlfb_sigmoid_ce(const float* logits, const int32_t* labels, float* prob, float* loss,
                     float* dlogits, int64_t rows, int64_t cols, float scale, vlfb_stream_t stream);
+/* Single-label heads (EPIC-Kitchens; Softmax / SoftmaxWithLoss, resnet_video.py:339-347): prob = softmax over
+ * `cols`; with labels [rows] (class indices): loss = scale * sum_r -log(max(prob[r][label_r], 1e-20)) / rows and
+ * dlogits = scale * (prob - onehot) / rows (Caffe2 SoftmaxWithLoss without weights).  labels NULL = test mode. */
+int vlfb_softmax_ce(const float* logits, const int32_t* labels, float* prob, float* loss, float* dlogits,
+                    int64_t rows, int64_t cols, float scale, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * RoI head.  Replaces RoIAlign + 7x7 MaxPool (head_helper.py:88-123, lfb_helper.py:130-152).
@@ -342,6 +347,13 @@ int vlfb_lfb_sample_window(const vlfb_lfb_desc* d, const void* bank, const int32
 int vlfb_lfb_sample_compact(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
                             const int32_t* query, int64_t rows, int window, void* out,
                             int out_dtype, vlfb_stream_t stream);
+/* The same with up to `max_per_step` features per step (slot order), packed in step order until `window`
+ * rows are filled: EPIC-Kitchens verb banks (one clip feature per step, lib/datasets/epic.py:310-331,
+ * max_per_step = 1) and noun banks (detector features per frame, epic.py:338-374, max_per_step =
+ * EPIC.MAX_NUM_FEATS_PER_NOUN_LFB_FRAME). */
+int vlfb_lfb_sample_packed(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
+                           const int32_t* query, int64_t rows, int window, int max_per_step, void* out,
+                           int out_dtype, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Clip preprocessing on the device.  Replaces the per-frame cv2 / NumPy chain of

@@ -5,6 +5,7 @@ CPU restatement of the reference's long-term-feature-bank construction and sampl
   * construct_frame_level_lfb    tools/lfb_loader.py:49-76    bank[video][frame] = feat
   * sample_lfb (AVA)             lib/datasets/ava.py:300-323
   * sample_lfb (Charades)        lib/datasets/charades.py:251-276
+  * sample_verb_lfb / sample_noun_lfb (EPIC-Kitchens)   lib/datasets/epic.py:310-374
 
 Parity unpinned: the reference holds no fixtures for these functions, and its AVA sampler draws
 with `np.random.choice(..., replace=False)` from the global MT19937 stream, which no device kernel
@@ -110,3 +111,41 @@ def charades_lfb_frames(num_frames_per_video, clips_per_second):
     """(video_idx, frame) pairs the bank is inferred on (charades.py:238-248)"""
     sample_freq = FPS // clips_per_second
     return [(v, i) for v, n in enumerate(num_frames_per_video) for i in range(n) if (i + 1) % sample_freq == 0]
+
+
+EPIC_FPS = 30    # lib/datasets/epic.py:46
+
+
+def sample_verb_lfb_epic(center_idx, video_lfb, window_size, dim):
+    """epic.py:310-331 -> (window_size, dim)"""
+    half_len = (window_size * EPIC_FPS) // 2
+    rows = []
+    for frame_idx in range(center_idx - half_len, center_idx + half_len + 1):
+        if frame_idx in video_lfb and len(rows) < window_size:
+            rows.append(video_lfb[frame_idx])
+    out = np.zeros((window_size, dim), dtype=np.float64)
+    if rows:
+        out[:len(rows)] = np.array(rows)
+    return out
+
+
+def sample_noun_lfb_epic(center_idx, video_lfb, window_size, dim, max_per_frame=10, frames_per_second=1):
+    """epic.py:338-374 -> (window_size, dim); `video_lfb[frame]` is an (n, dim) array or []"""
+    secs = float(window_size) / (max_per_frame * frames_per_second)
+    lower = int(center_idx - (secs / 2) * EPIC_FPS)
+    upper = int(lower + secs * EPIC_FPS)
+    chunks, num_feat = [], 0
+    for frame_idx in range(lower, upper + 1):
+        if frame_idx in video_lfb:
+            frame_lfb = video_lfb[frame_idx]
+            if not (isinstance(frame_lfb, list) and len(frame_lfb) == 0):
+                curr = min(max_per_frame, frame_lfb.shape[0])
+                num_feat += curr
+                chunks.append(frame_lfb[:curr])
+                if num_feat >= window_size:
+                    break
+    out = np.zeros((window_size, dim), dtype=np.float64)
+    if chunks:
+        got = np.vstack(chunks)[:window_size]
+        out[:got.shape[0]] = got
+    return out

@@ -198,7 +198,10 @@ def synth_inputs(cfg, n_clips, split="train", seed=2, rois_per_clip=None, crop=N
                 r0 += k
             blobs["lfb"] = lfb
     else:
-        blobs["labels"] = (gen.uniform(size=(n_clips, ncls)) < 0.05).astype(np.int32)
+        if cfg.MODEL.MULTI_LABEL:
+            blobs["labels"] = (gen.uniform(size=(n_clips, ncls)) < 0.05).astype(np.int32)
+        else:   # EPIC-Kitchens: one class index per clip (epic.py:135, epic_data_input.py)
+            blobs["labels"] = gen.integers(0, ncls, size=(n_clips,)).astype(np.int32)
         if cfg.LFB.ENABLED:
             K = cfg.LFB.WINDOW_SIZE
             lfb = (np.maximum(gen.standard_normal((n_clips, K, cfg.LFB.LFB_DIM)), 0) * 0.5).astype(np.float32)
@@ -376,6 +379,14 @@ def sigmoid_cross_entropy(logits, labels, scale):
     return scale * (l * valid).sum() / normalizer
 
 
+def softmax_with_loss(logits, labels, scale):
+    """Caffe2 SoftmaxWithLoss, integer labels, no weights (upstream
+    caffe2/operators/softmax_with_loss_op.cc): loss = scale * sum_i -log(max(P[i][label_i], 1e-20)) / N"""
+    p = torch.softmax(logits, dim=1)
+    picked = p.gather(1, labels.to(torch.int64).view(-1, 1)).clamp_min(1e-20)
+    return scale * (-torch.log(picked)).sum() / logits.shape[0]
+
+
 def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torch.float64,
             dropout_seed_fn=None, suffix="", num_gpus=None):
     """resnet_video.create_model (lib/models/resnet_video.py:133-351).
@@ -460,11 +471,16 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
         h = _dropout(cx, h, "pool5_dropout", cfg.TRAIN.DROPOUT_RATE)
     logits = F.linear(h.flatten(1), params["pred_w"], params["pred_b"])
     B["pred"] = logits
-    assert cfg.MODEL.MULTI_LABEL, "EPIC softmax head is a later row (SURVEY.md 8f rank 4)"
-    B["prob"] = torch.sigmoid(logits)
-    if split == "train":
-        scale = 1.0 / (num_gpus if num_gpus is not None else cfg.NUM_GPUS)
-        B["loss"] = sigmoid_cross_entropy(logits, inputs["labels"], scale)
+    scale = 1.0 / (num_gpus if num_gpus is not None else cfg.NUM_GPUS)
+    if cfg.MODEL.MULTI_LABEL:
+        B["prob"] = torch.sigmoid(logits)
+        if split == "train":
+            B["loss"] = sigmoid_cross_entropy(logits, inputs["labels"], scale)
+    else:
+        # Softmax / SoftmaxWithLoss (resnet_video.py:339-350; EPIC-Kitchens verb / noun classification)
+        B["prob"] = torch.softmax(logits, dim=1)
+        if split == "train":
+            B["loss"] = softmax_with_loss(logits, inputs["labels"], scale)
     return B
 
 

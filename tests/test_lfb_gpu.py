@@ -162,3 +162,46 @@ def test_bank_feeds_the_model_input_without_leaving_the_device():
     eng2.feed("lfb_train", want.astype(np.float32))
     eng2.forward()
     assert float(eng2.fetch("loss").reshape(-1)[0]) == loss_dev
+
+
+def test_epic_verb_and_noun_banks_match_the_reference_samplers():
+    """EPIC-Kitchens banks on the device (epic.py:310-374): verb = one clip feature per second, the first
+    WINDOW_SIZE of them inside +-(WINDOW_SIZE * 30) // 2 frames; noun = up to 10 detector features per
+    sampled frame, frames in order, truncated to WINDOW_SIZE rows.  Bit-exact against oracle/lfb.py on
+    fp32 banks, incl. empty frames, clip centres near both ends of a video and windows that overflow."""
+    import torch
+    from vlfb.lfb_bank import DeviceBank
+    from oracle import lfb as ol
+    rng = np.random.default_rng(11)
+    D = 64
+    # ---- verb ----
+    n_frames = [5400, 900, 31]
+    verb = {v: {f: rng.standard_normal(D).astype(np.float32) for f in range(0, n, 30) if rng.uniform() > 0.15}
+            for v, n in enumerate(n_frames)}
+    bank = DeviceBank.from_epic(verb, noun=False, dtype="fp32")
+    for W in (40, 7):
+        vids, centres = [], []
+        for v, n in enumerate(n_frames):
+            for c in list(rng.integers(0, n, 6)) + [0, n - 1, 15, 29, 30]:
+                vids.append(v); centres.append(int(c))
+        got = bank.sample_epic_verb(vids, centres, W).cpu().numpy()
+        for i, (v, c) in enumerate(zip(vids, centres)):
+            want = ol.sample_verb_lfb_epic(c, verb[v], W, D)
+            assert np.array_equal(got[i], want.astype(np.float32)), (W, v, c)
+    # ---- noun ----
+    noun = {}
+    for v, n in enumerate(n_frames):
+        noun[v] = {}
+        for f in range(0, n, 30):
+            k = int(rng.integers(0, 15))
+            noun[v][f] = rng.standard_normal((k, D)).astype(np.float32) if k else []
+    nbank = DeviceBank.from_epic(noun, noun=True, dtype="fp32")
+    for W in (120, 25):
+        vids, centres = [], []
+        for v, n in enumerate(n_frames):
+            for c in list(rng.integers(0, n, 6)) + [0, n - 1, 45, 170]:
+                vids.append(v); centres.append(int(c))
+        got = nbank.sample_epic_noun(vids, centres, W, max_per_frame=10).cpu().numpy()
+        for i, (v, c) in enumerate(zip(vids, centres)):
+            want = ol.sample_noun_lfb_epic(c, noun[v], W, D, 10, 1)
+            assert np.array_equal(got[i], want.astype(np.float32)), (W, v, c)

@@ -96,3 +96,32 @@ def test_device_bank_step_window_equals_the_reference_frame_window():
                 want = [f for f in range(begin, end + 1) if f >= 0 and (f + 1) % freq == 0]
                 got = [freq * (t + 1) - 1 for t in range(max(int(l), 0), int(h) + 1)]
                 assert got == want, (cps, window, c)
+
+
+def test_epic_window_arithmetic_matches_the_reference_loops():
+    """host index math of DeviceBank.sample_epic_verb / sample_epic_noun (bank steps that lie inside the frame
+    window) against the frame loops of epic.py:310-374 restated in oracle/lfb.py, incl. negative windows (Python
+    int() truncates toward zero) and clip centres at the start of a video"""
+    from vlfb.lfb_bank import epic_verb_window_steps, epic_noun_window_steps
+    rng = np.random.default_rng(5)
+    for window in (40, 30, 7):
+        centres = np.concatenate([rng.integers(0, 20000, 40), np.arange(0, 40), [299, 300, 301, 599, 600]])
+        lo, hi = epic_verb_window_steps(centres, window)
+        for c, l, h in zip(centres, lo, hi):
+            half = (window * ol.EPIC_FPS) // 2
+            frames = [f for f in range(int(c) - half, int(c) + half + 1) if f % 30 == 0]
+            want = (frames[0] // 30, frames[-1] // 30) if frames else None
+            if want is None:
+                assert l > h
+            else:
+                assert (l, h) == want, (window, c)
+        lo, hi = epic_noun_window_steps(centres, window)
+        for c, l, h in zip(centres, lo, hi):
+            secs = float(window) / 10
+            lower = int(c - (secs / 2) * 30)
+            upper = int(lower + secs * 30)
+            frames = [f for f in range(lower, upper + 1) if f % 30 == 0]
+            if frames:
+                assert (l, h) == (frames[0] // 30, frames[-1] // 30), (window, c)
+            else:
+                assert l > h

@@ -152,3 +152,20 @@ def test_bf16_budget_is_set_by_the_forward_roundings_not_by_gradient_accumulatio
     exact = bb.gradient_budget(cfg, params, inputs, grads, {}, lambda name: 3)
     assert max(exact.values()) < 1e-12               # the instrumented oracle without roundings IS the oracle
     assert p90(bwd) < 1e-2 and p90(fwd) > 3 * p90(bwd), (p90(bwd), p90(fwd))
+
+
+def test_softmax_with_loss_matches_closed_form_and_autograd():
+    """the single-label head of the oracle (Caffe2 SoftmaxWithLoss, resnet_video.py:343-344): value against
+    log-sum-exp, gradient against scale * (P - onehot) / N"""
+    import torch
+    from oracle import model as om
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 11, generator=g, dtype=torch.float64, requires_grad=True)
+    t = torch.tensor([0, 10, 3, 3, 7], dtype=torch.int32)
+    loss = om.softmax_with_loss(x, t, 0.25)
+    want = 0.25 * sum(float(torch.logsumexp(x[i], 0) - x[i, int(t[i])]) for i in range(5)) / 5
+    assert abs(float(loss) - want) < 1e-12
+    loss.backward()
+    p = torch.softmax(x.detach(), 1)
+    p[torch.arange(5), t.long()] -= 1
+    assert torch.allclose(x.grad, 0.25 * p / 5, atol=1e-14)

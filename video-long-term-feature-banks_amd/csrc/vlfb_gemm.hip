@@ -17,6 +17,8 @@
 // MFMA operands are swapped (weights as A, activations as B) so that each lane ends up holding
 // 4 consecutive output channels of one output row -> 8/16-byte epilogue stores.
 #include "vlfb_gemm_common.h"
+#include <string>
+#include <unordered_map>
 
 namespace vlfb {
 namespace {
@@ -1015,12 +1017,7 @@ struct Plan {
   long long ws_elems;
 };
 
-int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
-  // development override of the kernel family (probe / A-B runs only)
-  static const int env_algo = [] { const char* e = getenv("VLFB_FORCE_ALGO"); return e ? atoi(e) : 0; }();
-  vlfb_conv_desc d_copy = *d_in;
-  if (env_algo && d_copy.algo == 0) d_copy.algo = env_algo;
-  const vlfb_conv_desc* d = &d_copy;
+int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   GP& g = pl->gp;
   ::memset(&g, 0, sizeof(g));
   VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "conv: bad dtype %d", d->dtype);
@@ -1108,20 +1105,17 @@ int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
     }
     // few output rows (res2 / stem, Cout = 64): widen the Q tile so a workgroup still has
     // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
-    static const int env_tr = [] { const char* e = getenv("VLFB_TN_TR"); return e ? atoi(e) : 1; }();
-    pl->tn_tr = env_tr && d->dtype == VLFB_BF16 && d->Cn % 8 == 0;
+    pl->tn_tr = d->dtype == VLFB_BF16 && d->Cn % 8 == 0;
     if (pl->tn8) pl->tn_tr = 1;
     if (!pl->tn_tr && pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
-    static const int env_stem = [] { const char* e = getenv("VLFB_STEM_WGRAD"); return e ? atoi(e) : 1; }();
-    if (env_stem && pl->tn_tr && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
+    if (pl->tn_tr && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
         d->dt == 1 && d->dh == 1 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && (d->Ws * 8) % 16 == 0) {
       const int taps_ab = d->kt * d->kh;
       const long long npieces = (long long)taps_ab * (d->Ws * 8 / 16);
       const long long stage = npieces * 16 + (long long)d->Wr * 128;
       const long long tiles_total = (long long)d->N * d->Tr * d->Hr;
       if (npieces <= 4096 && taps_ab * 2 <= 8 * kStemCT && 2 * stage <= 160 * 1024 && tiles_total >= 2) {
-        static const int env_wgs = [] { const char* e = getenv("VLFB_STEM_WGS"); return e ? atoi(e) : 256; }();
-        const long long wgs = tiles_total < env_wgs ? tiles_total : env_wgs;
+        const long long wgs = tiles_total < 256 ? tiles_total : 256;          // one workgroup per CU
         const long long tpw = (tiles_total + wgs - 1) / wgs;
         const int splits = (int)((tiles_total + tpw - 1) / tpw);
         g.tiles_m = (int)tiles_total;
@@ -1146,8 +1140,7 @@ int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
         // the main stream: rounds of 256 (one workgroup per CU, half the slab traffic) measured best
         // end to end (336 vs 331 clips/s at 512, 323 at 128).
         const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
-        static const int env_slots = [] { const char* e = getenv("VLFB_WGRAD_SLOTS"); return e ? atoi(e) : 256; }();
-        const long long slots = env_slots > 0 ? env_slots : 256;
+        const long long slots = 256;
         long long maxs = (M + 8 * bk - 1) / (8 * bk);
         const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
         if (maxs > slab_cap) maxs = slab_cap;
@@ -1218,14 +1211,9 @@ int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
   pl->pre = 0;
   pl->threads = kThreads;
   if (d->mode == VLFB_CONV_WGRAD && pl->tn_tr && pl->bm == 128 && pl->bn == 128) {
-    static const int env_tw = [] { const char* e = getenv("VLFB_TN_WAVES"); return e ? atoi(e) : 8; }();
-    if (env_tw == 8) pl->threads = 512;
+    pl->threads = 512;       // 8 waves per workgroup
   }
-  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16 && pl->rb == 128) {
-    static const int env_nw = [] { const char* e = getenv("VLFB_NT_WAVES"); return e ? atoi(e) : 8; }();
-    static const int env_nw64 = [] { const char* e = getenv("VLFB_NT_WAVES64"); return e ? atoi(e) : 8; }();
-    if ((pl->bn == 128 ? env_nw : env_nw64) == 8) pl->threads = 512;
-  }
+  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16) pl->threads = 512;   // 8 waves (2 x 4), both tile widths
   {
     // extents behind the buffer descriptors of the DMA kernels (one batch element)
     const long long a_rows = pl->ident ? M : (long long)d->N * d->Ts * d->Hs * d->Ws;
@@ -1239,8 +1227,7 @@ int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
   }
   pl->ut = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
-    static const int env_ut = [] { const char* e = getenv("VLFB_NT_UT"); return e ? atoi(e) : 1; }();
-    pl->ut = env_ut && !pl->ident && !d->pack_w && ((long long)d->Cs * es) % pl->rb == 0 &&
+    pl->ut = !pl->ident && !d->pack_w && ((long long)d->Cs * es) % pl->rb == 0 &&
              (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1));
     const long long ktiles = (K * es + pl->rb - 1) / pl->rb;
     const size_t buf = (size_t)(pl->bm + pl->bn) * pl->rb;
@@ -1248,8 +1235,7 @@ int make_plan(const vlfb_conv_desc* d_in, Plan* pl) {
     const size_t tile = (size_t)pl->bm * pl->bn * 4;
     g.epi = (int)((tile + pl->lds - 1) / pl->lds);
     if (g.epi > 2) { pl->lds = tile / 2; g.epi = 2; }
-    static const int env_pre = [] { const char* e = getenv("VLFB_NT_PRE"); return e ? atoi(e) : 1; }();
-    pl->pre = env_pre && g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
+    pl->pre = g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
   } else {
     pl->lds = (size_t)2 * (pl->bm + pl->bn) * 128;
     if (pl->stem) { pl->lds = pl->stem_lds; pl->threads = 512; }
@@ -1284,23 +1270,14 @@ template <typename T, typename OutT, bool IDENT, bool DGRAD, bool PACKW>
 void launch_nt(const Plan& pl, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr bool CAN_PRE = BF && sizeof(OutT) == 2 && !PACKW;
-  if (BF && pl.threads == 512) {   // 8 waves per workgroup (bf16)
-    if (pl.bn == 64) {
-      if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>(pl, s);
-      else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>(pl, s);
-      return;
-    }
-    if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, BF ? 8 : 4>(pl, s);
-    else launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, BF ? 8 : 4>(pl, s);
+  constexpr int NW = BF ? 8 : 4;        // bf16: 8 waves (2 x 4) per workgroup; fp32 parity path: 4 (2 x 2)
+  if (pl.bn == 64) {
+    if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, NW>(pl, s);
+    else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, NW>(pl, s);
     return;
   }
-  if (CAN_PRE && pl.pre) {
-    if (pl.bn == 128) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>(pl, s);
-    else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, CAN_PRE, 4>(pl, s);
-    return;
-  }
-  if (pl.bn == 128) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, 4>(pl, s);
-  else launch_nt_shape<T, OutT, 128, 64, IDENT, DGRAD, PACKW, 128, false, 4>(pl, s);
+  if (CAN_PRE && pl.pre) launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, CAN_PRE, NW>(pl, s);
+  else launch_nt_shape<T, OutT, 128, 128, IDENT, DGRAD, PACKW, 128, false, NW>(pl, s);
 }
 template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn(const Plan& pl, hipStream_t s) {
@@ -1313,8 +1290,7 @@ void launch_tn(const Plan& pl, hipStream_t s) {
 
 template <typename OutT, bool IDENT, bool PACKW>
 void launch_tn_tr(const Plan& pl, hipStream_t s) {
-  if (pl.bm == 128 && pl.bn == 128 && pl.threads == 512) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW, 8>, pl, s);
-  else if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW>, pl, s);
+  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW, 8>, pl, s);   // 8 waves
   else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 64, 128, IDENT, PACKW>, pl, s);
   else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<OutT, 128, 64, IDENT, PACKW>, pl, s);
   else launch_k(gemm_tn_tr_kernel<OutT, 64, 64, IDENT, PACKW>, pl, s);
@@ -1376,9 +1352,24 @@ extern "C" void vlfb_conv_desc_init(vlfb_conv_desc* d) {
   d->alpha = 1.0f;
 }
 
+// Plans are pure functions of the descriptor: cached per thread, keyed by the descriptor bytes (a training
+// step replays the same ~280 descriptors; the planner's split search is not free).
+static int cached_plan(const vlfb_conv_desc* d, Plan* out) {
+  static thread_local std::unordered_map<std::string, Plan> cache;
+  const std::string key(reinterpret_cast<const char*>(d), sizeof(*d));
+  auto it = cache.find(key);
+  if (it != cache.end()) { *out = it->second; return VLFB_OK; }
+  const int rc = make_plan(d, out);
+  if (rc == VLFB_OK) {
+    if (cache.size() > 4096) cache.clear();
+    cache.emplace(key, *out);
+  }
+  return rc;
+}
+
 extern "C" int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d) {
   Plan pl;
-  if (make_plan(d, &pl) != VLFB_OK) return -1;
+  if (cached_plan(d, &pl) != VLFB_OK) return -1;
   return pl.ws_elems * 4;
 }
 
@@ -1387,7 +1378,7 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
                              const void* Mask, void* workspace, int64_t workspace_bytes,
                              vlfb_stream_t stream) {
   Plan pl;
-  int rc = make_plan(d, &pl);
+  int rc = cached_plan(d, &pl);
   if (rc != VLFB_OK) return rc;
   VLFB_REQUIRE(A && O, "conv: A and O are required");
   if (d->mode == VLFB_CONV_WGRAD) VLFB_REQUIRE(P != nullptr, "conv: WGRAD needs P");

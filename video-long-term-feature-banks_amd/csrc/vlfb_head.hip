@@ -203,6 +203,39 @@ __global__ void sigmoid_ce_kernel(const float* __restrict__ logits, const int32_
   }
 }
 
+// ---- Softmax / SoftmaxWithLoss (single-label heads: EPIC-Kitchens verb / noun, resnet_video.py:339-347) ----
+// Caffe2 SoftmaxWithLoss with integer labels and no weights: P = softmax(logits) over the class axis,
+// loss = scale * sum_r -log(max(P[r][label_r], 1e-20)) / rows, dlogits = scale * (P - onehot) / rows.
+// One workgroup; a wave per row (rows = clips per GPU, cols = 125 / 352 classes).
+__global__ void softmax_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                  float* __restrict__ prob, float* __restrict__ loss,
+                                  float* __restrict__ dlogits, int rows, int cols, float scale) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ls = 0.f;
+  for (int r = wave; r < rows; r += 4) {
+    const float* x = logits + (long long)r * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, x[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float z = 0.f;
+    for (int c = lane; c < cols; c += 64) z += expf(x[c] - m);
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+    const float inv = 1.0f / z;
+    const int t = labels ? labels[r] : -1;
+    for (int c = lane; c < cols; c += 64) {
+      const float p = expf(x[c] - m) * inv;
+      if (prob) prob[(long long)r * cols + c] = p;
+      if (dlogits) dlogits[(long long)r * cols + c] = scale * (p - (c == t ? 1.f : 0.f)) / (float)rows;
+      if (c == t) ls += -logf(fmaxf(p, 1e-20f));
+    }
+  }
+  if (!labels || !loss) return;
+  for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o);
+  ls = block_sum(lane == 0 ? ls : 0.f, red);
+  if (threadIdx.x == 0) loss[0] = scale * ls / (float)rows;
+}
+
 // ---- FBO-NL attention core, one query per row (lfb_helper.py:170-263) ----------------------------
 // one block (256 threads) per row r
 template <typename T>
@@ -537,6 +570,15 @@ extern "C" int vlfb_sigmoid_ce(const float* logits, const int32_t* labels, float
   hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels,
                      prob, loss, dlogits, (long long)(rows * cols), scale);
   return check_launch("sigmoid_ce");
+}
+
+extern "C" int vlfb_softmax_ce(const float* logits, const int32_t* labels, float* prob, float* loss,
+                               float* dlogits, int64_t rows, int64_t cols, float scale, vlfb_stream_t stream) {
+  VLFB_REQUIRE(logits && rows > 0 && cols > 0 && rows < (1 << 24) && cols < (1 << 24), "softmax_ce: bad args");
+  VLFB_REQUIRE(labels || (!loss && !dlogits), "softmax_ce: loss/dlogits need labels");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, prob, loss,
+                     dlogits, (int)rows, (int)cols, scale);
+  return check_launch("softmax_ce");
 }
 
 extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,

@@ -140,11 +140,14 @@ __global__ void lfb_sample_window_kernel(BankP b, const char* __restrict__ bank,
   }
 }
 
-// frame-level banks (Charades): the first `window` occupied steps of [first, last], packed to the
-// front, zeros behind (charades.py:251-276).  One workgroup per query.
-__global__ void lfb_sample_compact_kernel(BankP b, const char* __restrict__ bank, const int32_t* __restrict__ count,
-                                          const int32_t* __restrict__ query, int window, void* out, int odt) {
-  extern __shared__ int found[];        // [window] step indices, then the number found
+// frame-level banks (Charades, EPIC verb: one feature per step; EPIC noun: up to `max_per_step` detector
+// features per step): walk the steps of [first, last] in order, take the first min(count, max_per_step)
+// features of every occupied step, pack them to the front of the `window` output rows, zeros behind
+// (charades.py:251-276, epic.py:310-374).  One workgroup per query.
+__global__ void lfb_sample_packed_kernel(BankP b, const char* __restrict__ bank, const int32_t* __restrict__ count,
+                                         const int32_t* __restrict__ query, int window, int max_per_step, void* out,
+                                         int odt) {
+  extern __shared__ int found[];        // [window] source rows (step * capacity + slot), then the number found
   const int r = blockIdx.x;
   const int video = query[3 * r];
   int first = query[3 * r + 1], last = query[3 * r + 2];
@@ -153,8 +156,11 @@ __global__ void lfb_sample_compact_kernel(BankP b, const char* __restrict__ bank
     if (video >= 0 && video < b.n_videos) {
       if (first < 0) first = 0;
       if (last > b.n_steps - 1) last = b.n_steps - 1;
-      for (int s = first; s <= last && k < window; ++s)
-        if (count[(long long)video * b.n_steps + s] > 0) found[k++] = s;
+      for (int s = first; s <= last && k < window; ++s) {
+        int n = count[(long long)video * b.n_steps + s];
+        if (n > max_per_step) n = max_per_step;
+        for (int i = 0; i < n && k < window; ++i) found[k++] = s * b.capacity + i;
+      }
     }
     found[window] = k;
   }
@@ -162,7 +168,7 @@ __global__ void lfb_sample_compact_kernel(BankP b, const char* __restrict__ bank
   const int k = found[window];
   for (int i = 0; i < window; ++i) {
     const long long o = ((long long)r * window + i) * b.dim;
-    if (i < k) row_copy(out, odt, o, bank, b.dtype, (((long long)video * b.n_steps + found[i]) * b.capacity) * (long long)b.dim, b.dim);
+    if (i < k) row_copy(out, odt, o, bank, b.dtype, ((long long)video * b.n_steps * b.capacity + found[i]) * (long long)b.dim, b.dim);
     else row_copy(out, odt, o, nullptr, 0, 0, b.dim);
   }
 }
@@ -219,18 +225,25 @@ extern "C" int vlfb_lfb_sample_window(const vlfb_lfb_desc* d, const void* bank, 
   return check_launch("lfb_sample_window");
 }
 
-extern "C" int vlfb_lfb_sample_compact(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
-                                       const int32_t* query, int64_t rows, int window, void* out,
-                                       int out_dtype, vlfb_stream_t stream) {
+extern "C" int vlfb_lfb_sample_packed(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
+                                      const int32_t* query, int64_t rows, int window, int max_per_step, void* out,
+                                      int out_dtype, vlfb_stream_t stream) {
   BankP b;
   int rc = check_desc(d, &b);
   if (rc != VLFB_OK) return rc;
-  VLFB_REQUIRE(bank && count && query && out, "lfb_sample_compact: NULL buffer");
-  VLFB_REQUIRE(out_dtype == VLFB_F32 || out_dtype == VLFB_BF16, "lfb_sample_compact: out dtype must be f32 or bf16");
-  VLFB_REQUIRE(window > 0 && window <= 8192, "lfb_sample_compact: window out of range");
-  VLFB_REQUIRE(rows >= 0 && rows < (1 << 20), "lfb_sample_compact: rows out of range");
+  VLFB_REQUIRE(bank && count && query && out, "lfb_sample_packed: NULL buffer");
+  VLFB_REQUIRE(out_dtype == VLFB_F32 || out_dtype == VLFB_BF16, "lfb_sample_packed: out dtype must be f32 or bf16");
+  VLFB_REQUIRE(window > 0 && window <= 8192, "lfb_sample_packed: window out of range");
+  VLFB_REQUIRE(max_per_step > 0, "lfb_sample_packed: max_per_step must be positive");
+  VLFB_REQUIRE(rows >= 0 && rows < (1 << 20), "lfb_sample_packed: rows out of range");
   if (rows == 0) return VLFB_OK;
-  hipLaunchKernelGGL(lfb_sample_compact_kernel, dim3((unsigned)rows), dim3(256), (size_t)(window + 1) * sizeof(int),
-                     (hipStream_t)stream, b, (const char*)bank, count, query, window, out, out_dtype);
-  return check_launch("lfb_sample_compact");
+  hipLaunchKernelGGL(lfb_sample_packed_kernel, dim3((unsigned)rows), dim3(256), (size_t)(window + 1) * sizeof(int),
+                     (hipStream_t)stream, b, (const char*)bank, count, query, window, max_per_step, out, out_dtype);
+  return check_launch("lfb_sample_packed");
+}
+
+extern "C" int vlfb_lfb_sample_compact(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
+                                       const int32_t* query, int64_t rows, int window, void* out,
+                                       int out_dtype, vlfb_stream_t stream) {
+  return vlfb_lfb_sample_packed(d, bank, count, query, rows, window, 1, out, out_dtype, stream);
 }

@@ -640,11 +640,13 @@ LOSS_RING = 64
 
 
 class LossStep(Step):
-    """Sigmoid + SigmoidCrossEntropyLoss (resnet_video.py:333-338); test mode: Sigmoid only"""
+    """Sigmoid + SigmoidCrossEntropyLoss (multi-label: AVA, Charades; resnet_video.py:333-338) or
+    Softmax / SoftmaxWithLoss (single-label: EPIC-Kitchens; :339-347); test mode: the probabilities only"""
 
-    def __init__(self, eng, logits, labels, prob, loss, scale):
+    def __init__(self, eng, logits, labels, prob, loss, scale, kind="sigmoid"):
         Step.__init__(self, eng)
         self.logits, self.labels, self.prob, self.loss, self.scale = logits, labels, prob, loss, scale
+        self.kernel = {"sigmoid": "vlfb_sigmoid_ce", "softmax": "vlfb_softmax_ce"}[kind]
         self.inputs = [logits]
         self.outputs = [b for b in (prob, loss) if b is not None]
 
@@ -663,7 +665,7 @@ class LossStep(Step):
             self.ring = torch.zeros(LOSS_RING, device=self.eng.device, dtype=torch.float32)
 
     def fwd(self):
-        hip.call("vlfb_sigmoid_ce", self.logits.ptr(), self.labels.ptr() if self.labels is not None else None,
+        hip.call(self.kernel, self.logits.ptr(), self.labels.ptr() if self.labels is not None else None,
                  self.prob.ptr() if self.prob is not None else None,
                  self.loss.ptr() if self.loss is not None else None, hip.ptr(self.dlogits), self.rows, self.cols,
                  self.scale)
@@ -1057,6 +1059,30 @@ class Lowering(object):
         self.env[op.outputs[0]] = prob
         return i + 1
 
+    def lower_SoftmaxWithLoss(self, i):
+        """[logits, labels] -> [prob, loss] (resnet_video.py:343-344); labels are class indices, one per row"""
+        op, ins, outs = self.ssa[i]
+        logits, labels = self.get(op.inputs[0]), self.get(op.inputs[1])
+        assert labels.numel == logits.shape[0], "SoftmaxWithLoss: one label per row expected, got %r" % (labels.shape,)
+        prob = self.new_blob(op.outputs[0], logits.shape, 1, "f32")
+        loss = self.new_blob(op.outputs[1], (1,), 0, "f32")
+        self.add_step(LossStep(self.eng, logits, labels, prob, loss, float(op.args["scale"]), kind="softmax"))
+        self.env[op.outputs[0]] = prob
+        self.env[op.outputs[1]] = loss
+        return i + 1
+
+    def lower_Softmax(self, i):
+        """the test-mode head of single-label models (resnet_video.py:349-350); the softmaxes of the non-local
+        blocks never get here (they are consumed by lower_BatchMatMul)"""
+        op, ins, outs = self.ssa[i]
+        logits = self.get(op.inputs[0])
+        assert op.args.get("axis", 1) == 1 and len(logits.shape) == 2 and logits.kind == "f32", \
+            "Softmax outside the classifier head: %r" % (op,)
+        prob = self.new_blob(op.outputs[0], logits.shape, 1, "f32")
+        self.add_step(LossStep(self.eng, logits, None, prob, None, 1.0, kind="softmax"))
+        self.env[op.outputs[0]] = prob
+        return i + 1
+
     def lower_SigmoidCrossEntropyLoss(self, i):
         op, ins, outs = self.ssa[i]
         logits, labels = self.get(op.inputs[0]), self.get(op.inputs[1])
@@ -1073,7 +1099,7 @@ class Engine(object):
     """One per-GPU replica: plan once, then forward()/backward()/allreduce()/sgd_step()."""
 
     def __init__(self, model, dtype="bf16", device=None, base_seed=None, dry_run=False, debug_roi=False,
-                 share_params_with=None):
+                 share_params_with=None, side_stream=True):
         """share_params_with: another Engine of the same scope (the train net's, when this is the test / val
         net of the same process).  Caffe2 nets of one workspace share their parameter BLOBS
         (tools/train_net.py builds train_model and test_model in one workspace and evaluates the weights
@@ -1081,6 +1107,7 @@ class Engine(object):
         MFMA operand copies of this engine are rebuilt whenever the owner's parameters have changed."""
         hip.lib()   # fail loudly if the native library is missing
         self.debug_roi = bool(debug_roi)
+        self.use_side_stream = bool(side_stream)   # parameter-gradient kernels on a second HIP stream
         self.param_owner = share_params_with
         # [version] of the parameter storage, shared by the engines that alias it
         self._pstate = share_params_with._pstate if share_params_with is not None else [0]
@@ -1194,8 +1221,7 @@ class Engine(object):
         self._allocate()
         if not self.dry_run:
             self.refresh_operands(all_params=True)
-            import os
-            if self.train and os.environ.get("VLFB_SIDE_STREAM", "1") != "0":
+            if self.train and self.use_side_stream:
                 self.side = torch.cuda.Stream(device=self.device)
         return self
 

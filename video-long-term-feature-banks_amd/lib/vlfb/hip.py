@@ -112,6 +112,7 @@ _SIGS = {
     "vlfb_fc_fwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _I64, _I64, _I64, _P]),
     "vlfb_fc_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, _P]),
     "vlfb_sigmoid_ce": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, _P]),
+    "vlfb_softmax_ce": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, _P]),
     "vlfb_roi_align_max_fwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
                                          C.c_int, C.c_float, _P]),
     "vlfb_roi_align_max_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
@@ -127,6 +128,7 @@ _SIGS = {
     "vlfb_lfb_sample_window": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, C.c_int, C.c_uint64,
                                          _P, C.c_int, _P]),
     "vlfb_lfb_sample_compact": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),
+    "vlfb_lfb_sample_packed": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, C.c_int, _P, C.c_int, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

@@ -37,6 +37,37 @@ def frame_window_steps(center_frames, window, clips_per_second):
     return lo, hi
 
 
+EPIC_FPS = 30   # lib/datasets/epic.py:46 / cfg.EPIC.FPS
+
+
+def _ceil_div(a, b):
+    return -((-a) // b)
+
+
+def epic_verb_window_steps(center_frames, window, clips_per_second=1, fps=EPIC_FPS):
+    """first / last bank step of sample_verb_lfb (epic.py:310-318): frames [centre - half, centre + half] with
+    half = (window * FPS) // 2.  Verb banks hold the frames f with f % sample_freq == 0
+    (epic.py:286-303), bank step t = frame t * sample_freq."""
+    sf = int(fps) // int(clips_per_second)
+    c = np.asarray(center_frames, dtype=np.int64).reshape(-1)
+    half = (int(window) * int(fps)) // 2
+    lo = _ceil_div(c - half, sf)
+    hi = (c + half) // sf
+    return lo, hi
+
+
+def epic_noun_window_steps(center_frames, window, max_per_frame=10, frames_per_second=1, fps=EPIC_FPS):
+    """first / last bank step of sample_noun_lfb (epic.py:338-350): secs = window / (max_per_frame * fps_lfb),
+    lower = int(centre - secs / 2 * FPS)  (Python int(): truncation toward zero), upper = int(lower + secs * FPS).
+    Noun banks hold one detector frame per 1 / frames_per_second seconds: step t = frame t * (FPS // fps_lfb)."""
+    sf = int(fps) // int(frames_per_second)
+    secs = float(window) / (int(max_per_frame) * int(frames_per_second))
+    c = np.asarray(center_frames, dtype=np.float64).reshape(-1)
+    lower = np.trunc(c - (secs / 2.0) * fps).astype(np.int64)
+    upper = np.trunc(lower + secs * fps).astype(np.int64)
+    return _ceil_div(lower, sf), upper // sf
+
+
 class DeviceBank(object):
     """bank[video][step][slot][dim] + count[video][step] on one GPU.
 
@@ -153,6 +184,55 @@ class DeviceBank(object):
                  rows, int(window), hip.ptr(out), hip.dtype_code(out.dtype))
         torch.cuda.current_stream().synchronize()
         return out
+
+    def _sample_packed(self, videos, lo, hi, window, max_per_step, out, out_dtype):
+        rows = len(videos)
+        qd = self._dev_i32(np.stack([self._rows_of(videos), lo, hi], axis=1))
+        out = self._out(out, (rows, int(window), self.dim), out_dtype)
+        hip.call("vlfb_lfb_sample_packed", C.byref(self.desc), hip.ptr(self.bank), hip.ptr(self.count), hip.ptr(qd),
+                 rows, int(window), int(max_per_step), hip.ptr(out), hip.dtype_code(out.dtype))
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def sample_epic_verb(self, videos, center_frames, window, clips_per_second=1, out=None, out_dtype=None):
+        """EPIC-Kitchens verb model (epic.py:310-331): -> (N, window, dim), the first `window` bank clips whose
+        centre frame lies within +-(window * FPS) // 2 frames of the clip centre, zero padded"""
+        lo, hi = epic_verb_window_steps(center_frames, window, clips_per_second)
+        return self._sample_packed(videos, lo, hi, window, 1, out, out_dtype)
+
+    def sample_epic_noun(self, videos, center_frames, window, max_per_frame=10, frames_per_second=1, out=None,
+                         out_dtype=None):
+        """EPIC-Kitchens noun model (epic.py:338-374): detector features, at most `max_per_frame` per bank frame
+        in stored order, frames in time order, truncated to `window` rows, zero padded"""
+        lo, hi = epic_noun_window_steps(center_frames, window, max_per_frame, frames_per_second)
+        return self._sample_packed(videos, lo, hi, window, max_per_frame, out, out_dtype)
+
+    @classmethod
+    def from_epic(cls, lfb, noun, sample_freq=EPIC_FPS, capacity=None, dtype="bf16", device="cuda:0"):
+        """`lfb` as the EPIC datasets hold it: verb {video: {frame: feat}} (frames % sample_freq == 0), noun
+        {video: {frame: (n, dim) array or []}} (epic.py:191-199)"""
+        vids = sorted(lfb)
+        frames = [f for v in lfb.values() for f in v]
+        assert all(f % sample_freq == 0 for f in frames), "EPIC bank frames must be multiples of the sampling period"
+        n_steps = max(frames) // sample_freq + 1 if frames else 1
+        feats = [np.asarray(x, dtype=np.float32).reshape(-1, np.shape(x)[-1]) for v in lfb.values() for x in v.values()
+                 if np.size(x)]
+        dim = feats[0].shape[1]
+        cap = capacity or (max(f.shape[0] for f in feats) if noun else 1)
+        bank = cls(len(vids), n_steps, cap, dim, dtype, device, 0, vids)
+        for v in vids:
+            rows, ks = [], []
+            for f in sorted(lfb[v]):
+                x = lfb[v][f]
+                if not np.size(x):
+                    continue
+                x = np.asarray(x, dtype=np.float32).reshape(-1, dim)
+                rows.append(x[:cap])
+                ks += [f // sample_freq] * min(cap, x.shape[0])
+            if rows:
+                bank.append(torch.as_tensor(np.concatenate(rows)), [v] * len(ks), ks)
+        bank.check_no_drops()
+        return bank
 
     # ---- interchange with the reference's pickles -----------------------------------------------
     @classmethod

@@ -41,6 +41,31 @@ _AVA = {
     "CHECKPOINT": {"CHECKPOINT_PERIOD": 4000, "CONVERT_MODEL": True},
 }
 
+_EPIC = {
+    "DATASET": "epic", "DATADIR": "data/epic/frames",
+    "MODEL": {"MULTI_LABEL": False, "DILATIONS_AFTER_CONV5": False},
+    "TRAIN": {"JITTER_SCALES": [256, 320], "SAMPLE_RATE": 2, "DATASET_SIZE": 23191,
+              "PARAMS_FILE": "pretrained_weights/r50_k400_pretrained.pkl"},
+    "TEST": {"DATA_TYPE": "val", "SAMPLE_RATE": 2, "DATASET_SIZE": 5281},
+    "CHECKPOINT": {"CONVERT_MODEL": True},
+}
+_EPIC_VERB = {
+    "MODEL": {"NUM_CLASSES": 125},
+    "TRAIN": {"EVAL_PERIOD": 4000},
+    "SOLVER": {"BASE_LR": 0.001, "STEP_SIZES": [28000, 4000, 4000], "LRS": [1, 0.1, 0.01], "MAX_ITER": 36000,
+               "WEIGHT_DECAY": 0.000001},
+    "CHECKPOINT": {"CHECKPOINT_PERIOD": 4000},
+    "EPIC": {"CLASS_TYPE": "verb"},
+}
+_EPIC_NOUN = {
+    "MODEL": {"NUM_CLASSES": 352},
+    "TRAIN": {"EVAL_PERIOD": 5000},
+    "SOLVER": {"BASE_LR": 0.0003, "STEP_SIZES": [40000, 5000, 5000], "LRS": [1, 0.1, 0.01], "MAX_ITER": 50000,
+               "WEIGHT_DECAY": 0.00001},
+    "CHECKPOINT": {"CHECKPOINT_PERIOD": 4000},
+    "EPIC": {"CLASS_TYPE": "noun", "MAX_NUM_FEATS_PER_NOUN_LFB_FRAME": 10, "NOUN_LFB_FRAMES_PER_SECOND": 1},
+}
+
 PRESETS = {
     "charades_r50_baseline": [_COMMON, _CHARADES, {
         "TRAIN": {"PARAMS_FILE": "pretrained_weights/r50_k400_pretrained.pkl"},
@@ -67,6 +92,14 @@ PRESETS = {
     }],
     "ava_r50_lfb_max": [_COMMON, _AVA, {
         "LFB": {"ENABLED": True, "FBO_TYPE": "max", "WRITE_LFB": True, "WINDOW_SIZE": 60},
+    }],
+    # EPIC-Kitchens: single-label heads (Softmax / SoftmaxWithLoss), clip-level pooling, no res5 dilation
+    "epic_verb_r50_baseline": [_COMMON, _EPIC, _EPIC_VERB, {}],
+    "epic_verb_r50_lfb_nl": [_COMMON, _EPIC, _EPIC_VERB, {
+        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 40},
+    }],
+    "epic_noun_r50_lfb_nl": [_COMMON, _EPIC, _EPIC_NOUN, {
+        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "LOAD_LFB": True, "LOAD_LFB_PATH": "data/epic/noun_lfb", "WINDOW_SIZE": 120},
     }],
     "ava_r101_lfb_nl_3l": [_COMMON, _AVA, {
         "MODEL": {"DEPTH": 101, "VIDEO_ARC_CHOICE": 4},
