@@ -28,7 +28,7 @@ for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT)
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                           # HBM3E spec peak (same guide; ~6.3 TB/s measured copy)
 FWD_BWD_GFLOP_PER_CLIP = 1106.1                 # R50-I3D-NL backbone, 3x fwd - conv1 dgrad
 
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ava_r50_lfb_nl",
                     help="ava_r50_lfb_nl (metric config) | charades_r50_baseline | charades_r50_lfb_nl | ava_r101_lfb_nl_3l")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--clips-per-gpu", type=int, default=8)
     ap.add_argument("--rois-per-clip", type=int, default=0,
                     help="0 = SURVEY 8d C4 draw U{1..5} per clip (seeded per rank); N > 0 = exactly N per clip")
@@ -219,7 +219,7 @@ def main():
         ("model_flops_utilisation", round(value * FWD_BWD_GFLOP_PER_CLIP / 1e3 / (world * peak), 4)),
         ("host_enqueue_ms_per_step", round(host_ms, 2)),
     ])
-    if world == 1 and args.dtype == "bf16" and not args.no_fp32_line:
+    if world == 1 and args.dtype != "fp32" and not args.no_fp32_line:
         # the parity-grade path (exact-fp32 MFMA, fp32 storage: outputs AND gradients within 1e-3 of the fp64
         # oracle) on the same workload, so that the number next to the parity claim exists
         try:

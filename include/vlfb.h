@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* vlfb_stream_t;
 
-enum { VLFB_F32 = 0, VLFB_BF16 = 1 };
+enum { VLFB_F32 = 0, VLFB_BF16 = 1, VLFB_F16 = 2 };
 
 enum {
   VLFB_OK = 0,

@@ -3,10 +3,10 @@ import torch
 
 from vlfb import hip
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 # relative-L2 bars: the fp32 path (exact-fp32 MFMA) is held to the north-star 1e-3 with margin;
-# the bf16 path rounds every stored tensor to 8 mantissa bits (2^-9 = 2e-3 per rounding).
-TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+# the bf16 path rounds every stored tensor to 8 mantissa bits (2^-9 = 2e-3 per rounding), fp16 to 11 (2^-12).
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-2, torch.float16: 1.5e-3}
 
 
 def dev():

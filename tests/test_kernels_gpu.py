@@ -439,7 +439,8 @@ def test_fc_and_sigmoid_ce(dtype):
     DW = torch.empty(cout, cin, device=dev())
     DB = torch.empty(cout, device=dev())
     hip.call("vlfb_fc_bwd", hip.ptr(X), code, gp(w), hip.ptr(dl), hip.ptr(DX), hip.ptr(DW), hip.ptr(DB), rows, cin, cout, 0)
-    assert rel_err(DX.float(), gx) < TOL[dtype]
+    # dx ~ 1e-5 lies in the fp16 subnormal range here (the engine scales the loss gradient by 1024 for that reason)
+    assert rel_err(DX.float(), gx) < (5e-3 if dtype == torch.float16 else TOL[dtype])
     assert rel_err(DW, gw) < 1e-4 and rel_err(DB, gb) < 1e-4
 
 

@@ -20,6 +20,7 @@ Tolerances (relative L2 per tensor; measured values are printed with -s):
       measured envelope here: 90th percentile 0.12, max 0.30 (conv1_w, end of the ~50-layer chain).
 """
 import collections
+import math
 
 import numpy as np
 import pytest
@@ -140,6 +141,78 @@ def test_bf16_gradient_error_stays_within_the_forward_rounding_budget(preset):
     assert p90(err) < 3.0 * p90(budget), (p90(err), p90(budget))
     for r, n in ratio:
         assert r < 4.0, "gradient of %s: engine error %.3e, emulated budget %.3e" % (n, err[n], budget[n])
+
+
+@pytest.mark.parametrize("preset", ["charades_r50_baseline", "ava_r50_lfb_nl"])
+def test_fp16_path_matches_oracle(preset):
+    """fp16 storage + v_mfma_f32_16x16x32_f16 (BASELINE.json configs[4] names fp16 MFMA) with the static,
+    shape-derived loss scale (a power of two, divided out by the solver): three more mantissa bits than bf16,
+    so the forward-rounding budget of oracle/bf16_budget.py shrinks ~8x.  Measured: activations 8e-4, prob 1e-4,
+    parameter gradients p90 1e-2..2e-2 / max 7e-2 (conv1_w)."""
+    from oracle import model as om
+    cfg, model, eng, inputs, params, seed_fn = build(preset, "fp16")
+    assert eng.loss_scale >= 1024.0 and math.log2(eng.loss_scale) == int(math.log2(eng.loss_scale))
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    acts = []
+    for name in CHECK_BLOBS:
+        if name in blobs:
+            got = eng.fetch(name)
+            acts.append((name, rel(got, blobs[name].detach().numpy().reshape(got.shape))))
+    ref_loss = float(blobs["loss"].detach())
+    loss_err = abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) / abs(ref_loss)
+    gmax = max(float(g.norm()) for g in grads.values())
+    gerr = sorted(((rel(eng.fetch_grad(n), grads[n].numpy()), n) for n in eng.trainable if float(grads[n].norm()) > 1e-9 * gmax),
+                  reverse=True)
+    e = np.sort([x for x, _ in gerr])
+    p90 = float(e[int(0.9 * (len(e) - 1))])
+    print("\n[%s fp16] activations max %.2e, prob %.2e, loss %.2e; gradients median %.2e p90 %.2e worst %s"
+          % (preset, max(v for _, v in acts), dict(acts)["prob"], loss_err, float(np.median(e)), p90,
+             ["%s=%.2e" % (n, x) for x, n in gerr[:4]]))
+    assert max(v for _, v in acts) < 3e-3 and dict(acts)["prob"] < 1e-3 and loss_err < 1e-3, acts
+    assert p90 < 3e-2 and gerr[0][0] < 0.1, (p90, gerr[:3])
+    # the solver divides the loss scale out: one step moves the weights like the fp32 engine's step does
+    w0 = eng.fetch_param("pred_w").copy()
+    g0 = eng.fetch_grad("pred_w").astype(np.float64)
+    eng.sgd_step(0.01)
+    torch.cuda.synchronize()
+    wd, mu = float(cfg.SOLVER.WEIGHT_DECAY), float(cfg.SOLVER.MOMENTUM)
+    want = w0 - (1 + mu) * 0.01 * (g0 + wd * w0)
+    assert rel(eng.fetch_param("pred_w"), want) < 1e-5
+
+
+def test_c5_r101_64_frame_clip_fp16_full_size():
+    """BASELINE.json configs[4] / SURVEY 8d C5 at real size: ava_r101_lfb_nl_3l (R101-I3D-NL, 23 res4 blocks,
+    3-layer FBO-NL), ONE 64-frame 224^2 clip (pool stride 32, 8 non-local groups in res3, res4 affinities
+    6272 x 1568), fp16 MFMA path, every output and parameter gradient against the fp64 oracle"""
+    import os
+    from oracle import model as om
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ov = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 64, "TEST.VIDEO_LENGTH", 64, "TRAIN.CROP_SIZE", 224]
+    cfg, model, eng, inputs, params, seed_fn = build("ava_r101_lfb_nl_3l", "fp16", ov)
+    att = [s for s in eng.steps if type(s).__name__ == "AttentionStep" and not s.single]
+    assert att[0].theta.shape[0] == 8 and (att[-1].L1, att[-1].L2) == (6272, 1568)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    for name in ("res5_2_branch2c_bn", "pool5", "prob"):
+        got = eng.fetch(name)
+        assert rel(got, blobs[name].detach().numpy().reshape(got.shape)) < (1e-3 if name == "prob" else 3e-3), name
+    ref_loss = float(blobs["loss"].detach())
+    assert abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) < 1e-3 * abs(ref_loss)
+    gmax = max(float(g.norm()) for g in grads.values())
+    ge = sorted(((rel(eng.fetch_grad(n), grads[n].numpy()), n, float(grads[n].norm())) for n in eng.trainable
+                 if float(grads[n].norm()) > 1e-9 * gmax), reverse=True)
+    e = np.sort([x for x, _, _ in ge])
+    print("\n[C5 r101 64f fp16] %d gradients: median %.2e p90 %.2e max %.2e; worst %s" % (
+        len(e), np.median(e), e[int(0.9 * (len(e) - 1))], e[-1], ["%s=%.2e (|g| %.1e)" % (n, x, g) for x, n, g in ge[:8]]))
+    # measured: median 2.3e-2, p90 3.7e-2; max 0.24 on the theta / phi weights of ONE res4 non-local block (13) whose
+    # synthetic attention is peaky -- the same three tensors are the worst ones of the bf16 path too (unchanged by the
+    # fp16 range scalings, i.e. forward-rounding sensitivity, not underflow)
+    assert e[int(0.9 * (len(e) - 1))] < 5e-2 and e[-1] < 0.35
 
 
 FULL = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 32, "TRAIN.CROP_SIZE", 224]

@@ -9,6 +9,16 @@
 namespace vlfb {
 
 typedef unsigned short bf16_t;  // raw bf16 storage
+struct f16_t { unsigned short v; };   // raw IEEE fp16 storage (a distinct type so that kernels can be instantiated for it)
+
+inline bool is16(int dtype) { return dtype == VLFB_BF16 || dtype == VLFB_F16; }
+inline bool dtype_ok(int dtype) { return dtype == VLFB_F32 || is16(dtype); }
+// run the statement(s) with T16 = the 16-bit element type `dtype` names
+#define VLFB_WITH_T16(dtype, ...)                                               \
+  do {                                                                          \
+    if ((dtype) == VLFB_F16) { typedef ::vlfb::f16_t T16; __VA_ARGS__; }        \
+    else { typedef ::vlfb::bf16_t T16; __VA_ARGS__; }                           \
+  } while (0)
 
 // ---- error plumbing -----------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);
@@ -31,17 +41,35 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+__device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // round-nearest-even
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int EPC = 4;  // elements per 16-byte chunk
   __device__ static __forceinline__ float ld(const float* p) { return *p; }
   __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  // (the packed-pair helpers only exist so that `sizeof(T) == 4 ? ... : ...` code compiles for float)
+  __device__ static __forceinline__ uint32_t pack2(float, float) { return 0u; }
+  __device__ static __forceinline__ float lo(uint32_t) { return 0.f; }
+  __device__ static __forceinline__ float hi(uint32_t) { return 0.f; }
 };
 template <> struct Elem<bf16_t> {
   static constexpr int EPC = 8;
   __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  // two elements packed in a 32-bit word (low half first)
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
+  __device__ static __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  __device__ static __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+};
+template <> struct Elem<f16_t> {
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(p->v); }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f2h(v); }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16); }
+  __device__ static __forceinline__ float lo(uint32_t w) { return h2f((unsigned short)(w & 0xffffu)); }
+  __device__ static __forceinline__ float hi(uint32_t w) { return h2f((unsigned short)(w >> 16)); }
 };
 
 // 16-byte vector of T viewed as floats
@@ -56,24 +84,26 @@ template <> struct Vec16<float> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
 };
-template <> struct Vec16<bf16_t> {
+template <typename T> struct Vec16x16bit {
   static constexpr int N = 8;
-  __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+  __device__ static __forceinline__ void load(const T* p, float (&v)[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
     uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      v[2 * i] = __uint_as_float(w[i] << 16);
-      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      v[2 * i] = Elem<T>::lo(w[i]);
+      v[2 * i + 1] = Elem<T>::hi(w[i]);
     }
   }
-  __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+  __device__ static __forceinline__ void store(T* p, const float (&v)[8]) {
     uint4 t;
-    t.x = pack_bf2(v[0], v[1]); t.y = pack_bf2(v[2], v[3]);
-    t.z = pack_bf2(v[4], v[5]); t.w = pack_bf2(v[6], v[7]);
+    t.x = Elem<T>::pack2(v[0], v[1]); t.y = Elem<T>::pack2(v[2], v[3]);
+    t.z = Elem<T>::pack2(v[4], v[5]); t.w = Elem<T>::pack2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = t;
   }
 };
+template <> struct Vec16<bf16_t> : Vec16x16bit<bf16_t> {};
+template <> struct Vec16<f16_t> : Vec16x16bit<f16_t> {};
 
 inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {
   int64_t g = (work_items + block - 1) / block;

@@ -88,7 +88,7 @@ extern "C" int vlfb_clip_preprocess(const vlfb_clip_desc* d, const uint8_t* fram
                    (d->flip ? d->x0 - (d->crop_w - 1) >= 0 : d->x0 + d->crop_w <= d->resized_w),
                "clip_preprocess: crop window leaves the resized frame");
   VLFB_REQUIRE(d->c_pad >= 3 && d->w_left >= 0 && d->w_total >= d->w_left + d->crop_w, "clip_preprocess: bad destination row");
-  VLFB_REQUIRE(dst_dtype == VLFB_F32 || dst_dtype == VLFB_BF16, "clip_preprocess: dst dtype must be f32 or bf16");
+  VLFB_REQUIRE(dst_dtype == VLFB_F32 || is16(dst_dtype), "clip_preprocess: dst dtype must be f32 or bf16");
   ClipP p;
   p.src = frames; p.xofs = xofs; p.xcoef = xcoef; p.yofs = yofs; p.ycoef = ycoef;
   p.T = d->frames; p.Hs = d->src_h; p.Ws = d->src_w; p.Hr = d->resized_h; p.Wr = d->resized_w;
@@ -101,6 +101,6 @@ extern "C" int vlfb_clip_preprocess(const vlfb_clip_desc* d, const uint8_t* fram
   if (dst_dtype == VLFB_F32)
     hipLaunchKernelGGL(clip_preprocess_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (float*)dst);
   else
-    hipLaunchKernelGGL(clip_preprocess_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)dst);
+    VLFB_WITH_T16(dst_dtype, hipLaunchKernelGGL(clip_preprocess_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (T16*)dst));
   return check_launch("clip_preprocess");
 }

@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
         if (sizeof(OutT) == 4) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
-                                                    pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
+          *reinterpret_cast<uint4*>(o) = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
+                                                    Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
         }
       }
     }
@@ -374,6 +374,9 @@ __device__ __forceinline__ void transpose_block(const uint4 (&in)[8], uint4 (&ou
     }
     out[c] = make_uint4(o[0], o[1], o[2], o[3]);
   }
+}
+__device__ __forceinline__ void transpose_block(const uint4 (&in)[8], uint4 (&out)[8], f16_t) {
+  transpose_block(in, out, bf16_t());      // a pure 16-bit shuffle
 }
 __device__ __forceinline__ void transpose_block(const uint4 (&in)[4], uint4 (&out)[4], float) {
   out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
@@ -622,10 +625,10 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
 // the row so that the 8 rows touched by a 32-lane half of a tr-read fall on 8 different 32-byte
 // bank segments (the DMA destination is lane-linear, so the XOR is applied on the SOURCE chunk).
 // =============================================================================================
-template <typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4>
+template <typename T, typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   // NW = 4: waves 2 (p) x 2 (q).  NW = 8: waves 2 x 4 on the same tile -- twice the wavefronts per CU.
-  typedef bf16_t T;
+  typedef typename V16<T>::V vec_t;
   constexpr int NTHR = 64 * NW;
   constexpr int NWQ = NW / 2;
   constexpr int BK = 64;                         // positions per k-tile
@@ -748,16 +751,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
     const char* qt = pt + BK * RSP;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_v pf[FP], qf[FQ];
+      vec_t pf[FP], qf[FQ];
 #pragma unroll
-      for (int i = 0; i < FP; ++i) pf[i] = tr_frag<RSP>(pt, wp * WP + i * 16, ks, lane);
+      for (int i = 0; i < FP; ++i) pf[i] = tr_frag<RSP, vec_t>(pt, wp * WP + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < FQ; ++j) qf[j] = tr_frag<RSQ>(qt, wq * WQ + j * 16, ks, lane);
+      for (int j = 0; j < FQ; ++j) qf[j] = tr_frag<RSQ, vec_t>(qt, wq * WQ + j * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < FQ; ++j)
 #pragma unroll
         for (int i = 0; i < FP; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = V16<T>::mma(qf[j], pf[i], acc[j][i]);
     }
   }
 
@@ -809,7 +812,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
 // 6x fewer DMA pieces, the gradient is read once.
 // =============================================================================================
 constexpr int kStemCT = 9;    // column tiles (16 of the K columns each) per wave
+template <typename T>
 __global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
+  typedef typename V16<T>::V vec_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -894,11 +899,11 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
     for (int ks = 0; ks < ksteps; ++ks) {
       const int r0 = ks * 32 + 8 * g + (pl >> 2);            // position read by this lane (first half)
       const bool live = ks * 32 + 8 * g < p.Wr;              // Wr % 8 == 0: the 8 positions of a group live or die together
-      bf16x8_v pf[4];
+      vec_t pf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        pf[i] = tr_frag<128>(gt, i * 16, ks, lane);
-        if (!live) pf[i] = bf16x8_v{0, 0, 0, 0, 0, 0, 0, 0};
+        pf[i] = tr_frag<128, vec_t>(gt, i * 16, ks, lane);
+        if (!live) pf[i] = vec_t{0, 0, 0, 0, 0, 0, 0, 0};
       }
       // dead positions read position Wr-1 instead (finite data x the zeroed gradient fragment)
       const int q0 = min(r0, p.Wr - 1), q1 = min(r0 + 4, p.Wr - 1);
@@ -906,12 +911,12 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
       const int a1 = (q1 * p.sw - p.pw) * 8 + (pl & 3) * 8;
       // all 9 fragments first, then the 36 MFMAs (no control flow in between: the column tiles past
       // the end of K, on the last wave only, recompute the last real tile and are dropped at the store)
-      bf16x8_v qf[kStemCT];
+      vec_t qf[kStemCT];
 #pragma unroll
       for (int j = 0; j < kStemCT; ++j) {
         const int ct = min(ct0 + j, ncts - 1);
         const char* rowp = rows + (ct >> 1) * rbytes + (ct & 1) * 32;
-        union { struct { s16x4_v a, b; } s; bf16x8_v v; } u;
+        union { struct { s16x4_v a, b; } s; vec_t v; } u;
         u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(rowp + a0));
         u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(rowp + a1));
         qf[j] = u.v;
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
       for (int j = 0; j < kStemCT; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = V16<T>::mma(qf[j], pf[i], acc[j][i]);
     }
   }
 
@@ -1020,7 +1025,7 @@ struct Plan {
 int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   GP& g = pl->gp;
   ::memset(&g, 0, sizeof(g));
-  VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "conv: bad dtype %d", d->dtype);
+  VLFB_REQUIRE(dtype_ok(d->dtype), "conv: bad dtype %d", d->dtype);
   VLFB_REQUIRE(d->out_dtype == VLFB_F32 || d->out_dtype == d->dtype, "conv: bad out_dtype");
   VLFB_REQUIRE(d->mode >= 0 && d->mode <= 2, "conv: bad mode %d", d->mode);
   const int es = d->dtype == VLFB_F32 ? 4 : 2;
@@ -1093,10 +1098,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
     // 256 x 256 phase-pipelined kernel (vlfb_gemm8.hip): plain-row bf16 operands with at least 128 of each
     {
-      const bool ok = d->dtype == VLFB_BF16 && pl->ident && d->Cn % 8 == 0 && K % 8 == 0 && d->Cn >= 128 && K >= 128 &&
+      const bool ok = is16(d->dtype) && pl->ident && d->Cn % 8 == 0 && K % 8 == 0 && d->Cn >= 128 && K >= 128 &&
                       g.lda % 8 == 0 && g.ldp % 8 == 0;
       if (d->algo == VLFB_ALGO_PIPE256)
-        VLFB_REQUIRE(ok, "conv: algo = PIPE256 WGRAD needs bf16 plain-row operands with Cn, K >= 128 (multiples of 8)");
+        VLFB_REQUIRE(ok, "conv: algo = PIPE256 WGRAD needs bf16 / f16 plain-row operands with Cn, K >= 128 (multiples of 8)");
       // library choice: every workgroup writes a 256 KiB fp32 slab, so only the large weights win
       // (Cn * K >= 1 M elements: res5 1x1x1 wgrads 1.3-1.66x; 0.5 M and below 0.6-0.97x, scratch/nt8_probe.cpp)
       pl->tn8 = ok && d->algo != VLFB_ALGO_TILE128 &&
@@ -1105,9 +1110,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     }
     // few output rows (res2 / stem, Cout = 64): widen the Q tile so a workgroup still has
     // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
-    pl->tn_tr = d->dtype == VLFB_BF16 && d->Cn % 8 == 0;
+    pl->tn_tr = is16(d->dtype) && d->Cn % 8 == 0;
     if (pl->tn8) pl->tn_tr = 1;
-    if (!pl->tn_tr && pl->bm == 64 && K >= 256 && d->dtype == VLFB_BF16) pl->bn = 256;
+    if (!pl->tn_tr && pl->bm == 64 && K >= 256 && is16(d->dtype)) pl->bn = 256;
     if (pl->tn_tr && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
         d->dt == 1 && d->dh == 1 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && (d->Ws * 8) % 16 == 0) {
       const int taps_ab = d->kt * d->kh;
@@ -1181,9 +1186,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // for DGRAD) and at most 32 taps (one validity bit per tap and row)
     const bool gather_ok = pl->ident || (!d->pack_w && ((long long)d->Cs * es) % 128 == 0 && taps <= 32 &&
                                          (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
-    const bool ok = d->dtype == VLFB_BF16 && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024;
+    const bool ok = is16(d->dtype) && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024;
     if (d->algo == VLFB_ALGO_PIPE256)
-      VLFB_REQUIRE(ok, "conv: algo = PIPE256 needs bf16, Cn >= 128, K >= 128, M >= 1024, 16-byte aligned rows and "
+      VLFB_REQUIRE(ok, "conv: algo = PIPE256 needs bf16 / f16, Cn >= 128, K >= 128, M >= 1024, 16-byte aligned rows and "
                        "taps spanning whole k-tiles");
     // Library choice (measured per layer on MI355X at the 8-clip shapes, scratch/nt8_probe.cpp, tables in
     // profiles/): with ONE 128-160 KiB workgroup per CU the prologue and the epilogue of a tile are exposed,
@@ -1194,7 +1199,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // fill half the chip) the 128x128 kernel with 2-3 co-resident workgroups is 1.1-1.6x faster.
     const bool want = d->algo == VLFB_ALGO_PIPE256 ||
                       (ok && ((d->Cn == 512 && K >= 1024) ||
-                              (batch > 1 && K >= 768 && d->Cn >= 256 && d->Cn <= 512 && d->out_dtype == VLFB_BF16)));
+                              (batch > 1 && K >= 768 && d->Cn >= 256 && d->Cn <= 512 && d->out_dtype == d->dtype)));
     if (ok && want) {
       const int pad256 = (d->Cn + 255) / 256 * 256, pad128 = (d->Cn + 127) / 128 * 128;
       pl->nt8 = pad256 <= pad128 ? 256 : 128;
@@ -1213,7 +1218,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   if (d->mode == VLFB_CONV_WGRAD && pl->tn_tr && pl->bm == 128 && pl->bn == 128) {
     pl->threads = 512;       // 8 waves per workgroup
   }
-  if (d->mode != VLFB_CONV_WGRAD && d->dtype == VLFB_BF16) pl->threads = 512;   // 8 waves (2 x 4), both tile widths
+  if (d->mode != VLFB_CONV_WGRAD && is16(d->dtype)) pl->threads = 512;   // 8 waves (2 x 4), both tile widths
   {
     // extents behind the buffer descriptors of the DMA kernels (one batch element)
     const long long a_rows = pl->ident ? M : (long long)d->N * d->Ts * d->Hs * d->Ws;
@@ -1288,37 +1293,37 @@ void launch_tn(const Plan& pl, hipStream_t s) {
   else launch_k(gemm_tn_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
 }
 
-template <typename OutT, bool IDENT, bool PACKW>
+template <typename T, typename OutT, bool IDENT, bool PACKW>
 void launch_tn_tr(const Plan& pl, hipStream_t s) {
-  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 128, 128, IDENT, PACKW, 8>, pl, s);   // 8 waves
-  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<OutT, 64, 128, IDENT, PACKW>, pl, s);
-  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<OutT, 128, 64, IDENT, PACKW>, pl, s);
-  else launch_k(gemm_tn_tr_kernel<OutT, 64, 64, IDENT, PACKW>, pl, s);
+  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<T, OutT, 128, 128, IDENT, PACKW, 8>, pl, s);   // 8 waves
+  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<T, OutT, 64, 128, IDENT, PACKW>, pl, s);
+  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<T, OutT, 128, 64, IDENT, PACKW>, pl, s);
+  else launch_k(gemm_tn_tr_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
 }
 
 template <typename T, typename OutT>
 int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
-  if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.stem) {
-    static bool configured = false;
-    if (!configured) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      configured = true;
+  if constexpr (sizeof(T) == 2) {
+    if (d->mode == VLFB_CONV_WGRAD && pl.stem) {
+      static bool configured = false;     // per element type (template instance)
+      if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+      }
+      hipLaunchKernelGGL(stem_wgrad_kernel<T>, pl.grid, dim3(512), pl.lds, s, pl.gp);
+      return check_launch("conv wgrad (stem) kernel");
     }
-    hipLaunchKernelGGL(stem_wgrad_kernel, pl.grid, dim3(512), pl.lds, s, pl.gp);
-    return check_launch("conv wgrad (stem) kernel");
-  }
-  if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn8)
-    return launch_tn8(pl.gp, pl.grid, sizeof(OutT) == 4, s);
-  if (d->mode == VLFB_CONV_WGRAD && sizeof(T) == 2 && pl.tn_tr) {
-    if (pl.ident) launch_tn_tr<OutT, true, false>(pl, s);
-    else if (pl.packw) launch_tn_tr<OutT, false, true>(pl, s);
-    else launch_tn_tr<OutT, false, false>(pl, s);
-    return check_launch("conv wgrad (tr) kernel");
-  }
-  if (d->mode != VLFB_CONV_WGRAD && pl.nt8) {
-    if constexpr (sizeof(T) == 2)
-      return launch_nt8(pl.gp, pl.nt8_bm, pl.nt8, pl.nt8_mode, sizeof(OutT) == 4, (unsigned)(d->batch > 0 ? d->batch : 1), s);
+    if (d->mode == VLFB_CONV_WGRAD && pl.tn8) return launch_tn8(pl.gp, pl.grid, d->dtype, sizeof(OutT) == 4, s);
+    if (d->mode == VLFB_CONV_WGRAD && pl.tn_tr) {
+      if (pl.ident) launch_tn_tr<T, OutT, true, false>(pl, s);
+      else if (pl.packw) launch_tn_tr<T, OutT, false, true>(pl, s);
+      else launch_tn_tr<T, OutT, false, false>(pl, s);
+      return check_launch("conv wgrad (tr) kernel");
+    }
+    if (d->mode != VLFB_CONV_WGRAD && pl.nt8)
+      return launch_nt8(pl.gp, pl.nt8_bm, pl.nt8, pl.nt8_mode, d->dtype, sizeof(OutT) == 4,
+                        (unsigned)(d->batch > 0 ? d->batch : 1), s);
   }
   if (d->mode == VLFB_CONV_WGRAD) {
     if (pl.ident) launch_tn<T, OutT, true, false>(pl, s);
@@ -1394,8 +1399,8 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
   if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
-  else if (d->out_dtype == VLFB_F32) rc = dispatch<bf16_t, float>(d, pl, s);
-  else rc = dispatch<bf16_t, bf16_t>(d, pl, s);
+  else if (d->dtype == VLFB_F16) rc = d->out_dtype == VLFB_F32 ? dispatch<f16_t, float>(d, pl, s) : dispatch<f16_t, f16_t>(d, pl, s);
+  else rc = d->out_dtype == VLFB_F32 ? dispatch<bf16_t, float>(d, pl, s) : dispatch<bf16_t, bf16_t>(d, pl, s);
   if (rc != VLFB_OK) return rc;
   if (pl.splits > 1) {
     const long long n = (long long)d->Cn * g.K;
@@ -1406,6 +1411,8 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
                      dim3(CC * GG), 0, s, g.ws, g.O, rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate)
     if (d->out_dtype == VLFB_F32) {
       if (G == 16) VLFB_REDUCE(float, 16, 16); else if (G == 4) VLFB_REDUCE(float, 4, 64); else VLFB_REDUCE(float, 1, 64);
+    } else if (d->out_dtype == VLFB_F16) {
+      if (G == 16) VLFB_REDUCE(f16_t, 16, 16); else if (G == 4) VLFB_REDUCE(f16_t, 4, 64); else VLFB_REDUCE(f16_t, 1, 64);
     } else {
       if (G == 16) VLFB_REDUCE(bf16_t, 16, 16); else if (G == 4) VLFB_REDUCE(bf16_t, 4, 64); else VLFB_REDUCE(bf16_t, 1, 64);
     }

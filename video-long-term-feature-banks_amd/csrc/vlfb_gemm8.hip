@@ -63,9 +63,9 @@ __device__ __forceinline__ unsigned tap_delta_bytes(const GP& p, const TapCur& u
 // 196 k positions per frame at every stage, and 8 clips x 16 frames give 256 k tiles of 196 rows --
 // whole rounds of workgroups on 256 CUs -- where 256-row tiles leave a quarter of the chip idle).  With
 // RV = 98 the seventh fragment of a wave row is partly padding (zero-filled rows, 7/8 of the MFMAs).
-template <typename OutT, int BN, int MODE, bool KTAIL, int RV>
+template <typename T, typename OutT, int BN, int MODE, bool KTAIL, int RV>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
-  typedef bf16_t T;
+  typedef typename V16<T>::V vec_t;
   static_assert(RV == 128 || RV == 98, "rows per wave row");
   constexpr int FM1 = (RV - 64 + 15) / 16;      // fragments of the second quadrant row (4 or 3)
   constexpr int NBH = BN / 128;                  // B half-tiles per k-tile
@@ -187,22 +187,22 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
   for (int j = 0; j < FN; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_v{0.f, 0.f, 0.f, 0.f};
-  bf16x8_v xa[4][2], wb[NBH][2][2];
+  vec_t xa[4][2], wb[NBH][2][2];
 
   auto read_a = [&](const char* buf, int ah) {
     const char* s = buf + ah * HT + ra;
 #pragma unroll
     for (int ii = 0; ii < (ah ? FM1 : 4); ++ii) {
-      xa[ii][0] = *reinterpret_cast<const bf16x8_v*>(s + ii * 2048 + kof0);
-      xa[ii][1] = *reinterpret_cast<const bf16x8_v*>(s + ii * 2048 + kof1);
+      xa[ii][0] = *reinterpret_cast<const vec_t*>(s + ii * 2048 + kof0);
+      xa[ii][1] = *reinterpret_cast<const vec_t*>(s + ii * 2048 + kof1);
     }
   };
   auto read_b = [&](const char* buf, int bh) {
     const char* s = buf + (2 + bh) * HT + rb;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      wb[bh][jj][0] = *reinterpret_cast<const bf16x8_v*>(s + jj * 2048 + kof0);
-      wb[bh][jj][1] = *reinterpret_cast<const bf16x8_v*>(s + jj * 2048 + kof1);
+      wb[bh][jj][0] = *reinterpret_cast<const vec_t*>(s + jj * 2048 + kof0);
+      wb[bh][jj][1] = *reinterpret_cast<const vec_t*>(s + jj * 2048 + kof1);
     }
   };
   auto mma_quadrant = [&](int ah, int bh) {
@@ -213,8 +213,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int ii = 0; ii < (ah ? FM1 : 4); ++ii)
-          acc[bh * 2 + jj][ah * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              wb[bh][jj][ks], xa[ii][ks], acc[bh * 2 + jj][ah * 4 + ii], 0, 0, 0);
+          acc[bh * 2 + jj][ah * 4 + ii] = V16<T>::mma(wb[bh][jj][ks], xa[ii][ks], acc[bh * 2 + jj][ah * 4 + ii]);
     __builtin_amdgcn_s_setprio(0);
   };
   // one phase: the reads were issued by the caller; DMA issue, counted wait, barrier, MFMAs, barrier
@@ -353,8 +352,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
         if (sizeof(OutT) == 4) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2 % EPT], v[3 % EPT]),
-                                                    pack_bf2(v[4 % EPT], v[5 % EPT]), pack_bf2(v[6 % EPT], v[7 % EPT]));
+          *reinterpret_cast<uint4*>(o) = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
+                                                    Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
         }
       }
     }
@@ -372,8 +371,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
 // as they lie (DMA, 32-byte segments XOR-swizzled on the source side) and read TRANSPOSED by
 // ds_read_b64_tr_b16.  Split along positions: fp32 slabs + wgrad_reduce_kernel (vlfb_gemm.hip).
 // =============================================================================================
-template <typename OutT>
+template <typename T, typename OutT>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const GP p) {
+  typedef typename V16<T>::V vec_t;
   constexpr int HT = 64 * 256;                   // bytes of one sub-tile (64 positions x 128 channels)
   constexpr int BUFSZ = 4 * HT;                  // P0 P1 Q0 Q1
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -446,19 +446,19 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const GP p) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_v{0.f, 0.f, 0.f, 0.f};
-  bf16x8_v pf[4][2], qf[2][2][2];
+  vec_t pf[4][2], qf[2][2][2];
 
   auto read_p = [&](const char* buf, int ph) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) pf[ii][ks] = tr_frag<256>(buf + ph * HT, wp * 64 + ii * 16, ks, lane);
+      for (int ks = 0; ks < 2; ++ks) pf[ii][ks] = tr_frag<256, vec_t>(buf + ph * HT, wp * 64 + ii * 16, ks, lane);
   };
   auto read_q = [&](const char* buf, int qh) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) qf[qh][jj][ks] = tr_frag<256>(buf + (2 + qh) * HT, wq * 32 + jj * 16, ks, lane);
+      for (int ks = 0; ks < 2; ++ks) qf[qh][jj][ks] = tr_frag<256, vec_t>(buf + (2 + qh) * HT, wq * 32 + jj * 16, ks, lane);
   };
   auto mma_quadrant = [&](int ph, int qh) {
     __builtin_amdgcn_s_setprio(1);
@@ -468,8 +468,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const GP p) {
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
-          acc[qh * 2 + jj][ph * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              qf[qh][jj][ks], pf[ii][ks], acc[qh * 2 + jj][ph * 4 + ii], 0, 0, 0);
+          acc[qh * 2 + jj][ph * 4 + ii] = V16<T>::mma(qf[qh][jj][ks], pf[ii][ks], acc[qh * 2 + jj][ph * 4 + ii]);
     __builtin_amdgcn_s_setprio(0);
   };
 #define VLFB_PHASE_TAIL(N_INFLIGHT, PH, QH)           \
@@ -552,41 +551,47 @@ void launch8(K kernel, const GP& gp, dim3 grid, size_t lds, hipStream_t s) {
   hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, gp);
 }
 
-template <typename OutT, int BN, int RV>
+template <typename T, typename OutT, int BN, int RV>
 void launch_nt8_bn(const GP& gp, int mode, dim3 grid, hipStream_t s) {
   constexpr size_t lds = (BN == 256 ? 2 : 3) * (size_t)(2 + BN / 128) * 16384;
   const bool ktail = (gp.K & 63) != 0;
   if (mode == 0) {
-    if (ktail) launch8(gemm_nt8_kernel<OutT, BN, 0, true, RV>, gp, grid, lds, s);
-    else launch8(gemm_nt8_kernel<OutT, BN, 0, false, RV>, gp, grid, lds, s);
+    if (ktail) launch8(gemm_nt8_kernel<T, OutT, BN, 0, true, RV>, gp, grid, lds, s);
+    else launch8(gemm_nt8_kernel<T, OutT, BN, 0, false, RV>, gp, grid, lds, s);
   } else if (mode == 1) {
-    launch8(gemm_nt8_kernel<OutT, BN, 1, false, RV>, gp, grid, lds, s);
+    launch8(gemm_nt8_kernel<T, OutT, BN, 1, false, RV>, gp, grid, lds, s);
   } else {
-    launch8(gemm_nt8_kernel<OutT, BN, 2, false, RV>, gp, grid, lds, s);
+    launch8(gemm_nt8_kernel<T, OutT, BN, 2, false, RV>, gp, grid, lds, s);
   }
 }
-template <typename OutT, int BN>
-void launch_nt8_rv(const GP& gp, int mode, int bm, dim3 grid, hipStream_t s) {
-  if (bm == 196) launch_nt8_bn<OutT, BN, 98>(gp, mode, grid, s);
-  else launch_nt8_bn<OutT, BN, 128>(gp, mode, grid, s);
+template <typename T, typename OutT>
+void launch_nt8_t(const GP& gp, int mode, int bm, int bn, dim3 grid, hipStream_t s) {
+  if (bn == 256) {
+    if (bm == 196) launch_nt8_bn<T, OutT, 256, 98>(gp, mode, grid, s); else launch_nt8_bn<T, OutT, 256, 128>(gp, mode, grid, s);
+  } else {
+    if (bm == 196) launch_nt8_bn<T, OutT, 128, 98>(gp, mode, grid, s); else launch_nt8_bn<T, OutT, 128, 128>(gp, mode, grid, s);
+  }
 }
 
 }  // namespace
 
-int launch_nt8(const GP& gp, int bm, int bn, int mode, bool out_f32, unsigned batch, hipStream_t s) {
+int launch_nt8(const GP& gp, int bm, int bn, int mode, int dtype, bool out_f32, unsigned batch, hipStream_t s) {
   const dim3 grid((unsigned)(gp.tiles_m * gp.tiles_n), 1, batch);
-  if (out_f32) {
-    if (bn == 256) launch_nt8_rv<float, 256>(gp, mode, bm, grid, s); else launch_nt8_rv<float, 128>(gp, mode, bm, grid, s);
+  if (dtype == VLFB_F16) {
+    if (out_f32) launch_nt8_t<f16_t, float>(gp, mode, bm, bn, grid, s); else launch_nt8_t<f16_t, f16_t>(gp, mode, bm, bn, grid, s);
   } else {
-    if (bn == 256) launch_nt8_rv<bf16_t, 256>(gp, mode, bm, grid, s); else launch_nt8_rv<bf16_t, 128>(gp, mode, bm, grid, s);
+    if (out_f32) launch_nt8_t<bf16_t, float>(gp, mode, bm, bn, grid, s); else launch_nt8_t<bf16_t, bf16_t>(gp, mode, bm, bn, grid, s);
   }
   return check_launch("conv kernel (256-row pipelined)");
 }
 
-int launch_tn8(const GP& gp, dim3 grid, bool out_f32, hipStream_t s) {
+int launch_tn8(const GP& gp, dim3 grid, int dtype, bool out_f32, hipStream_t s) {
   constexpr size_t lds = 2 * 4 * 16384;
-  if (out_f32) launch8(gemm_tn8_kernel<float>, gp, grid, lds, s);
-  else launch8(gemm_tn8_kernel<bf16_t>, gp, grid, lds, s);
+  if (dtype == VLFB_F16) {
+    if (out_f32) launch8(gemm_tn8_kernel<f16_t, float>, gp, grid, lds, s); else launch8(gemm_tn8_kernel<f16_t, f16_t>, gp, grid, lds, s);
+  } else {
+    if (out_f32) launch8(gemm_tn8_kernel<bf16_t, float>, gp, grid, lds, s); else launch8(gemm_tn8_kernel<bf16_t, bf16_t>, gp, grid, lds, s);
+  }
   return check_launch("conv wgrad kernel (256x256 pipelined)");
 }
 

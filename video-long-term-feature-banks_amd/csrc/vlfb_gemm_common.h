@@ -38,14 +38,15 @@ struct GP {
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered
-// FPROP, 2 = gathered unit-stride DGRAD (taps must span whole 64-element k-tiles); bf16 operands.
-int launch_nt8(const GP& gp, int bm, int bn, int mode, bool out_f32, unsigned batch, hipStream_t s);
+// FPROP, 2 = gathered unit-stride DGRAD (taps must span whole 64-element k-tiles); dtype = VLFB_BF16 | VLFB_F16.
+int launch_nt8(const GP& gp, int bm, int bn, int mode, int dtype, bool out_f32, unsigned batch, hipStream_t s);
 // 256 x 256 phase-pipelined TN kernel (plain rows: wgrad of 1x1x1 convs, attention products); grid as planned
-int launch_tn8(const GP& gp, dim3 grid, bool out_f32, hipStream_t s);
+int launch_tn8(const GP& gp, dim3 grid, int dtype, bool out_f32, hipStream_t s);
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
 typedef __attribute__((ext_vector_type(4))) float f32x4_v;
 
 constexpr int kThreads = 256;
@@ -184,19 +185,29 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 
 // ---- MFMA wrappers --------------------------------------------------------------------------
 template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
+// 16-bit element types: the MFMA operand vector (8 k per lane) and the instruction
+template <typename T> struct V16;
+template <> struct V16<bf16_t> {
+  typedef bf16x8_v V;
+  __device__ static __forceinline__ f32x4_v mma(V a, V b, f32x4_v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct V16<f16_t> {
+  typedef f16x8_v V;
+  __device__ static __forceinline__ f32x4_v mma(V a, V b, f32x4_v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <typename T> struct Mma16 {
   static constexpr int KSTEPS = 2;   // per 128-byte row (a 64-byte row is one k-step)
-  struct Frag { bf16x8_v v; };
+  struct Frag { typename V16<T>::V v; };
   template <int RB = 128>
   __device__ static __forceinline__ Frag load(const char* tile, int row, int ks, int g) {
     Frag f;
-    f.v = *reinterpret_cast<const bf16x8_v*>(tile + lds_off<RB>(row, ks * 4 + g));
+    f.v = *reinterpret_cast<const typename V16<T>::V*>(tile + lds_off<RB>(row, ks * 4 + g));
     return f;
   }
-  __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
-  }
+  __device__ static __forceinline__ f32x4_v mma(const Frag& a, const Frag& b, f32x4_v c) { return V16<T>::mma(a.v, b.v, c); }
 };
+template <> struct Mma<bf16_t> : Mma16<bf16_t> {};
+template <> struct Mma<f16_t> : Mma16<f16_t> {};
 template <> struct Mma<float> {
   static constexpr int KSTEPS = 1;
   struct Frag { float v[8]; };
@@ -229,7 +240,7 @@ __device__ __forceinline__ void store4(char* base, long long idx, const float (&
     if (sizeof(OutT) == 4) {
       *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-      *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      *reinterpret_cast<uint2*>(o) = make_uint2(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2], v[3]));
     }
   } else {
     for (int i = 0; i < count; ++i) Elem<OutT>::st(o + i, v[i]);
@@ -248,13 +259,13 @@ __device__ __forceinline__ void load_elems(const T* p, float (&v)[N]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      v[(2 * i) % N] = __uint_as_float(w[i] << 16);
-      v[(2 * i + 1) % N] = __uint_as_float(w[i] & 0xffff0000u);
+      v[(2 * i) % N] = Elem<T>::lo(w[i]);
+      v[(2 * i + 1) % N] = Elem<T>::hi(w[i]);
     }
   } else {  // 4 bf16 = 8 bytes
     const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2 % N] = __uint_as_float(t.y << 16); v[3 % N] = __uint_as_float(t.y & 0xffff0000u);
+    v[0] = Elem<T>::lo(t.x); v[1] = Elem<T>::hi(t.x);
+    v[2 % N] = Elem<T>::lo(t.y); v[3 % N] = Elem<T>::hi(t.y);
   }
 }
 
@@ -268,8 +279,8 @@ __device__ __forceinline__ void unpack_elems(const uint4& t, float (&v)[N]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      v[(2 * i) % N] = __uint_as_float(w[i] << 16);
-      v[(2 * i + 1) % N] = __uint_as_float(w[i] & 0xffff0000u);
+      v[(2 * i) % N] = Elem<T>::lo(w[i]);
+      v[(2 * i + 1) % N] = Elem<T>::hi(w[i]);
     }
   }
 }
@@ -290,8 +301,8 @@ template <int RS> __device__ __forceinline__ int tr_key(int row) {
   return RS == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
 // fragment: channels c0..c0+15 (lane -> c0 + (l & 15)), positions ks*32 + 8*(l>>4) .. +7
-template <int RS>
-__device__ __forceinline__ bf16x8_v tr_frag(const char* tile, int c0, int ks, int lane) {
+template <int RS, typename V = bf16x8_v>
+__device__ __forceinline__ V tr_frag(const char* tile, int c0, int ks, int lane) {
   const int g = lane >> 4, pl = lane & 15;
   const int seg = c0 >> 4;
   const int r0 = ks * 32 + 8 * g + (pl >> 2);
@@ -300,7 +311,7 @@ __device__ __forceinline__ bf16x8_v tr_frag(const char* tile, int c0, int ks, in
       (__attribute__((address_space(3))) s16x4_v*)(tile + r0 * RS + ((seg ^ tr_key<RS>(r0)) << 5) + ((pl & 3) << 3)));
   const s16x4_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4_v*)(tile + r1 * RS + ((seg ^ tr_key<RS>(r1)) << 5) + ((pl & 3) << 3)));
-  union { struct { s16x4_v a, b; } s; bf16x8_v v; } u;
+  union { struct { s16x4_v a, b; } s; V v; } u;
   u.s.a = lo; u.s.b = hi;
   return u.v;
 }

@@ -475,6 +475,7 @@ using namespace vlfb;
 #define DISPATCH_T(dtype, NAME, ...)                                             \
   if ((dtype) == VLFB_F32) { NAME<float> __VA_ARGS__; }                          \
   else if ((dtype) == VLFB_BF16) { NAME<bf16_t> __VA_ARGS__; }                   \
+  else if ((dtype) == VLFB_F16) { NAME<f16_t> __VA_ARGS__; }                     \
   else return set_error(VLFB_ERR_ARG, "bad dtype %d", (int)(dtype));
 
 extern "C" int vlfb_layernorm_fwd(const void* x, void* y, float* rstd, int dtype, int64_t rows,
@@ -484,8 +485,8 @@ extern "C" int vlfb_layernorm_fwd(const void* x, void* y, float* rstd, int dtype
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rstd, (long long)rows, (int)cols, eps);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rstd, (long long)rows, (int)cols, eps);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, rstd, (long long)rows, (int)cols, eps));
   else return set_error(VLFB_ERR_ARG, "layernorm_fwd: bad dtype");
   return check_launch("layernorm_fwd");
 }
@@ -496,8 +497,8 @@ extern "C" int vlfb_layernorm_bwd(const void* dy, const void* y, const float* rs
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)y, rstd, (float*)dx, (long long)rows, (int)cols);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, rstd, (bf16_t*)dx, (long long)rows, (int)cols);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)dy, (const T16*)y, rstd, (T16*)dx, (long long)rows, (int)cols));
   else return set_error(VLFB_ERR_ARG, "layernorm_bwd: bad dtype");
   return check_launch("layernorm_bwd");
 }
@@ -510,8 +511,8 @@ extern "C" int vlfb_dropout_fwd(const void* x, void* y, uint8_t* mask, int dtype
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(dropout_fwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed));
   else return set_error(VLFB_ERR_ARG, "dropout_fwd: bad dtype");
   return check_launch("dropout_fwd");
 }
@@ -522,8 +523,8 @@ extern "C" int vlfb_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, i
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, mask, (float*)dx, (long long)n, ratio);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, mask, (bf16_t*)dx, (long long)n, ratio);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(dropout_bwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)dy, mask, (T16*)dx, (long long)n, ratio));
   else return set_error(VLFB_ERR_ARG, "dropout_bwd: bad dtype");
   return check_launch("dropout_bwd");
 }
@@ -535,8 +536,8 @@ extern "C" int vlfb_fc_fwd(const void* x, int dtype, const float* w, const float
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(fc_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, b, logits, (long long)rows, (int)cin, (int)cout);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(fc_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, b, logits, (long long)rows, (int)cin, (int)cout);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fc_fwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, w, b, logits, (long long)rows, (int)cin, (int)cout));
   else return set_error(VLFB_ERR_ARG, "fc_fwd: bad dtype");
   return check_launch("fc_fwd");
 }
@@ -545,20 +546,20 @@ extern "C" int vlfb_fc_bwd(const void* x, int dtype, const float* w, const float
                            int accumulate, vlfb_stream_t stream) {
   VLFB_REQUIRE(x && w && dlogits && rows > 0 && cin > 0 && cout > 0, "fc_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype != VLFB_F32 && dtype != VLFB_BF16) return set_error(VLFB_ERR_ARG, "fc_bwd: bad dtype");
+  if (!dtype_ok(dtype)) return set_error(VLFB_ERR_ARG, "fc_bwd: bad dtype");
   if (dx) {
     int grid = grid_for(rows * cin, 256);
     if (dtype == VLFB_F32)
       hipLaunchKernelGGL(fc_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, s, w, dlogits, (float*)dx, (long long)rows, (int)cin, (int)cout);
     else
-      hipLaunchKernelGGL(fc_bwd_dx_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, dlogits, (bf16_t*)dx, (long long)rows, (int)cin, (int)cout);
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fc_bwd_dx_kernel<T16>, dim3(grid), dim3(256), 0, s, w, dlogits, (T16*)dx, (long long)rows, (int)cin, (int)cout));
   }
   if (dw) {
     int grid = grid_for(cout * cin, 256);
     if (dtype == VLFB_F32)
       hipLaunchKernelGGL(fc_bwd_dw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, dlogits, dw, db, (long long)rows, (int)cin, (int)cout, accumulate);
     else
-      hipLaunchKernelGGL(fc_bwd_dw_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, dlogits, dw, db, (long long)rows, (int)cin, (int)cout, accumulate);
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fc_bwd_dw_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, dlogits, dw, db, (long long)rows, (int)cin, (int)cout, accumulate));
   }
   return check_launch("fc_bwd");
 }
@@ -590,7 +591,7 @@ extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void*
   hipStream_t s = (hipStream_t)stream;
   {
     const int v = dtype == VLFB_F32 ? 4 : 8;
-    if ((dtype == VLFB_F32 || dtype == VLFB_BF16) && d % (8 * v) == 0 && ld % v == 0) {
+    if ((dtype == VLFB_F32 || is16(dtype)) && d % (8 * v) == 0 && ld % v == 0) {
       // chip-wide path: logits into p (fp32 [R][K]), then softmax in place + weighted sum of g
       const long long rk = (long long)r * k;
       const unsigned g1 = (unsigned)((rk * 64 + 255) / 256);
@@ -600,8 +601,8 @@ extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void*
         hipLaunchKernelGGL(fbo_dot_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)theta, (const float*)phi, p, rk, (int)k, (int)d, (long long)ld, scale);
         hipLaunchKernelGGL((fbo_mix_kernel<float, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const float*)g, (float*)t, (int)k, (int)d, (long long)ld, scale);
       } else {
-        hipLaunchKernelGGL(fbo_dot_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, (const bf16_t*)theta, (const bf16_t*)phi, p, rk, (int)k, (int)d, (long long)ld, scale);
-        hipLaunchKernelGGL((fbo_mix_kernel<bf16_t, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const bf16_t*)g, (bf16_t*)t, (int)k, (int)d, (long long)ld, scale);
+        VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_dot_kernel<T16>, dim3(g1), dim3(256), 0, s, (const T16*)theta, (const T16*)phi, p, rk, (int)k, (int)d, (long long)ld, scale));
+        VLFB_WITH_T16(dtype, hipLaunchKernelGGL((fbo_mix_kernel<T16, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const T16*)g, (T16*)t, (int)k, (int)d, (long long)ld, scale));
       }
       hipLaunchKernelGGL((fbo_rowfix_kernel<false>), dim3((unsigned)r), dim3(256), lds, s, p, (const float*)nullptr, (int)k, scale);
       return check_launch("fbo_attn_fwd");
@@ -609,8 +610,8 @@ extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void*
   }
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(fbo_attn_fwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)t, (int)k, (int)d, (long long)ld, scale);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(fbo_attn_fwd_kernel<bf16_t>, dim3((unsigned)r), dim3(256), lds, s, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, p, (bf16_t*)t, (int)k, (int)d, (long long)ld, scale);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_attn_fwd_kernel<T16>, dim3((unsigned)r), dim3(256), lds, s, (const T16*)theta, (const T16*)phi, (const T16*)g, p, (T16*)t, (int)k, (int)d, (long long)ld, scale));
   else return set_error(VLFB_ERR_ARG, "fbo_attn_fwd: bad dtype");
   return check_launch("fbo_attn_fwd");
 }
@@ -626,7 +627,7 @@ extern "C" int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* 
   size_t lds = (size_t)(k + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   int grid2 = grid_for(r * k * (d / v), 256);
-  if ((dtype == VLFB_F32 || dtype == VLFB_BF16) && d % (8 * v) == 0) {
+  if ((dtype == VLFB_F32 || is16(dtype)) && d % (8 * v) == 0) {
     // chip-wide path: dp = <dt, g[k]> into ds_ws, then ds (in place) + dtheta = sum_k ds[k] phi[k]
     const long long rk = (long long)r * k;
     const unsigned g1 = (unsigned)((rk * 64 + 255) / 256);
@@ -638,19 +639,19 @@ extern "C" int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* 
       hipLaunchKernelGGL((fbo_rowfix_kernel<true>), dim3((unsigned)r), dim3(256), lds, s, ds_ws, p, (int)k, scale);
       hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<float>, dim3(grid2), dim3(256), 0, s, (const float*)dt, (const float*)theta, p, (const float*)ds_ws, (float*)dphi, (float*)dg, (long long)r, (int)k, (int)d, (long long)ld);
     } else {
-      hipLaunchKernelGGL(fbo_dot_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, (const bf16_t*)dt, (const bf16_t*)g, ds_ws, rk, (int)k, (int)d, (long long)ld, 1.0f);
-      hipLaunchKernelGGL((fbo_mix_kernel<bf16_t, true>), g2, dim3(256), lds2, s, (const float*)ds_ws, p, (const bf16_t*)phi, (bf16_t*)dtheta, (int)k, (int)d, (long long)ld, scale);
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_dot_kernel<T16>, dim3(g1), dim3(256), 0, s, (const T16*)dt, (const T16*)g, ds_ws, rk, (int)k, (int)d, (long long)ld, 1.0f));
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL((fbo_mix_kernel<T16, true>), g2, dim3(256), lds2, s, (const float*)ds_ws, p, (const T16*)phi, (T16*)dtheta, (int)k, (int)d, (long long)ld, scale));
       hipLaunchKernelGGL((fbo_rowfix_kernel<true>), dim3((unsigned)r), dim3(256), lds, s, ds_ws, p, (int)k, scale);
-      hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<bf16_t>, dim3(grid2), dim3(256), 0, s, (const bf16_t*)dt, (const bf16_t*)theta, p, (const float*)ds_ws, (bf16_t*)dphi, (bf16_t*)dg, (long long)r, (int)k, (int)d, (long long)ld);
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<T16>, dim3(grid2), dim3(256), 0, s, (const T16*)dt, (const T16*)theta, p, (const float*)ds_ws, (T16*)dphi, (T16*)dg, (long long)r, (int)k, (int)d, (long long)ld));
     }
     return check_launch("fbo_attn_bwd");
   }
   if (dtype == VLFB_F32) {
     hipLaunchKernelGGL(fbo_attn_bwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)dt, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)dtheta, ds_ws, (int)k, (int)d, (long long)ld, scale);
     hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<float>, dim3(grid2), dim3(256), 0, s, (const float*)dt, (const float*)theta, p, (const float*)ds_ws, (float*)dphi, (float*)dg, (long long)r, (int)k, (int)d, (long long)ld);
-  } else if (dtype == VLFB_BF16) {
-    hipLaunchKernelGGL(fbo_attn_bwd_kernel<bf16_t>, dim3((unsigned)r), dim3(256), lds, s, (const bf16_t*)dt, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, p, (bf16_t*)dtheta, ds_ws, (int)k, (int)d, (long long)ld, scale);
-    hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<bf16_t>, dim3(grid2), dim3(256), 0, s, (const bf16_t*)dt, (const bf16_t*)theta, p, (const float*)ds_ws, (bf16_t*)dphi, (bf16_t*)dg, (long long)r, (int)k, (int)d, (long long)ld);
+  } else if (is16(dtype)) {
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_attn_bwd_kernel<T16>, dim3((unsigned)r), dim3(256), lds, s, (const T16*)dt, (const T16*)theta, (const T16*)phi, (const T16*)g, p, (T16*)dtheta, ds_ws, (int)k, (int)d, (long long)ld, scale));
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_attn_bwd_kv_kernel<T16>, dim3(grid2), dim3(256), 0, s, (const T16*)dt, (const T16*)theta, p, (const float*)ds_ws, (T16*)dphi, (T16*)dg, (long long)r, (int)k, (int)d, (long long)ld));
   } else return set_error(VLFB_ERR_ARG, "fbo_attn_bwd: bad dtype");
   return check_launch("fbo_attn_bwd");
 }

@@ -32,10 +32,12 @@ __host__ __device__ __forceinline__ uint32_t lfb_key(uint64_t seed, uint32_t sam
 }
 
 __device__ __forceinline__ float ld_any(const void* p, int dtype, long long i) {
-  return dtype == VLFB_F32 ? reinterpret_cast<const float*>(p)[i] : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+  return dtype == VLFB_F32 ? reinterpret_cast<const float*>(p)[i]
+         : dtype == VLFB_F16 ? h2f(reinterpret_cast<const unsigned short*>(p)[i]) : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
 }
 __device__ __forceinline__ void st_any(void* p, int dtype, long long i, float v) {
   if (dtype == VLFB_F32) reinterpret_cast<float*>(p)[i] = v;
+  else if (dtype == VLFB_F16) reinterpret_cast<unsigned short*>(p)[i] = f2h(v);
   else reinterpret_cast<bf16_t*>(p)[i] = f2bf(v);
 }
 __device__ __forceinline__ int esize(int dtype) { return dtype == VLFB_F32 ? 4 : 2; }
@@ -176,7 +178,7 @@ __global__ void lfb_sample_packed_kernel(BankP b, const char* __restrict__ bank,
 int check_desc(const vlfb_lfb_desc* d, BankP* b) {
   VLFB_REQUIRE(d != nullptr, "lfb: descriptor is NULL");
   VLFB_REQUIRE(d->n_videos > 0 && d->n_steps > 0 && d->capacity > 0 && d->dim > 0, "lfb: empty bank geometry");
-  VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "lfb: bank dtype must be f32 or bf16");
+  VLFB_REQUIRE(dtype_ok(d->dtype), "lfb: bank dtype must be f32, bf16 or f16");
   b->n_videos = d->n_videos; b->n_steps = d->n_steps; b->capacity = d->capacity; b->dim = d->dim; b->dtype = d->dtype;
   b->step_base = d->step_base;
   return VLFB_OK;
@@ -199,7 +201,7 @@ extern "C" int vlfb_lfb_append(const vlfb_lfb_desc* d, void* bank, int32_t* coun
   int rc = check_desc(d, &b);
   if (rc != VLFB_OK) return rc;
   VLFB_REQUIRE(bank && count && feats && keys, "lfb_append: NULL buffer");
-  VLFB_REQUIRE(feat_dtype == VLFB_F32 || feat_dtype == VLFB_BF16, "lfb_append: feature dtype must be f32 or bf16");
+  VLFB_REQUIRE(dtype_ok(feat_dtype), "lfb_append: feature dtype must be f32, bf16 or f16");
   VLFB_REQUIRE(rows >= 0 && rows < (1 << 20), "lfb_append: rows out of range");
   if (rows == 0) return VLFB_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -216,7 +218,7 @@ extern "C" int vlfb_lfb_sample_window(const vlfb_lfb_desc* d, const void* bank, 
   int rc = check_desc(d, &b);
   if (rc != VLFB_OK) return rc;
   VLFB_REQUIRE(bank && count && query && out, "lfb_sample_window: NULL buffer");
-  VLFB_REQUIRE(out_dtype == VLFB_F32 || out_dtype == VLFB_BF16, "lfb_sample_window: out dtype must be f32 or bf16");
+  VLFB_REQUIRE(dtype_ok(out_dtype), "lfb_sample_window: out dtype must be f32, bf16 or f16");
   VLFB_REQUIRE(window > 0 && max_per_step > 0 && max_per_step <= 64, "lfb_sample_window: need 0 < max_per_step <= 64, window > 0");
   VLFB_REQUIRE(rows >= 0 && rows < 65536, "lfb_sample_window: rows out of range");
   if (rows == 0) return VLFB_OK;
@@ -232,7 +234,7 @@ extern "C" int vlfb_lfb_sample_packed(const vlfb_lfb_desc* d, const void* bank, 
   int rc = check_desc(d, &b);
   if (rc != VLFB_OK) return rc;
   VLFB_REQUIRE(bank && count && query && out, "lfb_sample_packed: NULL buffer");
-  VLFB_REQUIRE(out_dtype == VLFB_F32 || out_dtype == VLFB_BF16, "lfb_sample_packed: out dtype must be f32 or bf16");
+  VLFB_REQUIRE(dtype_ok(out_dtype), "lfb_sample_packed: out dtype must be f32, bf16 or f16");
   VLFB_REQUIRE(window > 0 && window <= 8192, "lfb_sample_packed: window out of range");
   VLFB_REQUIRE(max_per_step > 0, "lfb_sample_packed: max_per_step must be positive");
   VLFB_REQUIRE(rows >= 0 && rows < (1 << 20), "lfb_sample_packed: rows out of range");

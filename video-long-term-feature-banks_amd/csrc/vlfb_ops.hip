@@ -420,8 +420,8 @@ __device__ __forceinline__ void load_elems4(const T* p, float (&v)[4]) {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   } else {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[0] = Elem<T>::lo(t.x); v[1] = Elem<T>::hi(t.x);
+    v[2] = Elem<T>::lo(t.y); v[3] = Elem<T>::hi(t.y);
   }
 }
 
@@ -488,7 +488,7 @@ __global__ void softmax_fwd_rowreg_kernel(const float* __restrict__ s, T* __rest
         if (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(pr + 4 * c) = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
         } else {
-          *reinterpret_cast<uint2*>(pr + 4 * c) = make_uint2(pack_bf2(v[i].x * inv, v[i].y * inv), pack_bf2(v[i].z * inv, v[i].w * inv));
+          *reinterpret_cast<uint2*>(pr + 4 * c) = make_uint2(Elem<T>::pack2(v[i].x * inv, v[i].y * inv), Elem<T>::pack2(v[i].z * inv, v[i].w * inv));
         }
       }
     }
@@ -545,7 +545,7 @@ __global__ void softmax_bwd_rowreg_kernel(const float* __restrict__ dp, const T*
         const float a = scale * q[i].x * (d[i].x - dot), b = scale * q[i].y * (d[i].y - dot);
         const float e = scale * q[i].z * (d[i].z - dot), f = scale * q[i].w * (d[i].w - dot);
         if (sizeof(T) == 4) *reinterpret_cast<float4*>(o + 4 * c) = make_float4(a, b, e, f);
-        else *reinterpret_cast<uint2*>(o + 4 * c) = make_uint2(pack_bf2(a, b), pack_bf2(e, f));
+        else *reinterpret_cast<uint2*>(o + 4 * c) = make_uint2(Elem<T>::pack2(a, b), Elem<T>::pack2(e, f));
       }
     }
   }
@@ -650,7 +650,7 @@ PoolP to_poolp(const vlfb_pool_desc* d) {
   return p;
 }
 int check_pool(const vlfb_pool_desc* d) {
-  VLFB_REQUIRE(d->dtype == VLFB_F32 || d->dtype == VLFB_BF16, "pool: bad dtype");
+  VLFB_REQUIRE(d->dtype == VLFB_F32 || is16(d->dtype), "pool: bad dtype");
   const int v = d->dtype == VLFB_F32 ? 4 : 8;
   VLFB_REQUIRE(d->C % v == 0, "pool: C=%d must be a multiple of %d", d->C, v);
   VLFB_REQUIRE(d->kt * d->kh * d->kw <= 65535, "pool: window too large for a 16-bit argmax");
@@ -665,7 +665,7 @@ using namespace vlfb;
 
 extern "C" const char* vlfb_last_error(void) { return g_err; }
 extern "C" int vlfb_version(void) { return 100; }
-extern "C" int vlfb_dtype_size(int dtype) { return dtype == VLFB_F32 ? 4 : dtype == VLFB_BF16 ? 2 : 0; }
+extern "C" int vlfb_dtype_size(int dtype) { return dtype == VLFB_F32 ? 4 : is16(dtype) ? 2 : 0; }
 
 extern "C" int vlfb_affine_nd_fwd(const float* x, const float* scale, const float* bias, float* y,
                                   int64_t n, int64_t c, int64_t inner, vlfb_stream_t stream) {
@@ -697,9 +697,9 @@ extern "C" int vlfb_ncthw_to_nthwc(const float* src, void* dst, int dtype, int64
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(ncthw_to_nthwc_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        src, (float*)dst, (long long)n, (int)c, (long long)thw, (int)c_pad);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(ncthw_to_nthwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       src, (bf16_t*)dst, (long long)n, (int)c, (long long)thw, (int)c_pad);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(ncthw_to_nthwc_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       src, (T16*)dst, (long long)n, (int)c, (long long)thw, (int)c_pad));
   else return set_error(VLFB_ERR_ARG, "ncthw_to_nthwc: bad dtype");
   return check_launch("ncthw_to_nthwc");
 }
@@ -710,9 +710,9 @@ extern "C" int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(nthwc_to_ncthw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)src, dst, (long long)n, (int)c, (long long)thw);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(nthwc_to_ncthw_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)src, dst, (long long)n, (int)c, (long long)thw);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(nthwc_to_ncthw_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const T16*)src, dst, (long long)n, (int)c, (long long)thw));
   else return set_error(VLFB_ERR_ARG, "nthwc_to_ncthw: bad dtype");
   return check_launch("nthwc_to_ncthw");
 }
@@ -721,14 +721,14 @@ extern "C" int vlfb_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
   if (n == 0) return VLFB_OK;
   int grid = grid_for(n, 256);
   hipStream_t s = (hipStream_t)stream;
-  if (sd == VLFB_F32 && dd == VLFB_BF16)
-    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, (long long)n);
-  else if (sd == VLFB_BF16 && dd == VLFB_F32)
-    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, (long long)n);
+  if (sd == VLFB_F32 && is16(dd))
+    VLFB_WITH_T16(dd, hipLaunchKernelGGL((cast_kernel<float, T16>), dim3(grid), dim3(256), 0, s, (const float*)src, (T16*)dst, (long long)n));
+  else if (is16(sd) && dd == VLFB_F32)
+    VLFB_WITH_T16(sd, hipLaunchKernelGGL((cast_kernel<T16, float>), dim3(grid), dim3(256), 0, s, (const T16*)src, (float*)dst, (long long)n));
   else if (sd == VLFB_F32 && dd == VLFB_F32)
     hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, (long long)n);
-  else if (sd == VLFB_BF16 && dd == VLFB_BF16)
-    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long long)n);
+  else if (is16(sd) && sd == dd)
+    VLFB_WITH_T16(dd, hipLaunchKernelGGL((cast_kernel<T16, T16>), dim3(grid), dim3(256), 0, s, (const T16*)src, (T16*)dst, (long long)n));
   else return set_error(VLFB_ERR_ARG, "cast: bad dtypes %d -> %d", sd, dd);
   return check_launch("cast");
 }
@@ -740,8 +740,8 @@ extern "C" int vlfb_transpose2d(const void* src, void* dst, int dtype, int64_t b
   dim3 block(32, 8);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(transpose2d_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, (float*)dst, (long long)rows, (long long)cols);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(transpose2d_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, (long long)rows, (long long)cols);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(transpose2d_kernel<T16>, grid, block, 0, (hipStream_t)stream, (const T16*)src, (T16*)dst, (long long)rows, (long long)cols));
   else return set_error(VLFB_ERR_ARG, "transpose2d: bad dtype");
   return check_launch("transpose2d");
 }
@@ -749,7 +749,7 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
                                 int dtype, int64_t cout, int64_t taps, int64_t cin,
                                 vlfb_stream_t stream) {
   VLFB_REQUIRE(w && (w_fprop || w_dgrad) && cout > 0 && taps > 0 && cin > 0, "weight_prep: bad args");
-  VLFB_REQUIRE(dtype == VLFB_F32 || dtype == VLFB_BF16, "weight_prep: bad dtype");
+  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype), "weight_prep: bad dtype");
   VLFB_REQUIRE(taps < 65536, "weight_prep: too many taps");
   hipStream_t s = (hipStream_t)stream;
   const long long total = cout * taps * cin;
@@ -758,14 +758,14 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
     if (dtype == VLFB_F32)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, (float*)w_fprop, (long long)(taps * cin), total);
     else
-      hipLaunchKernelGGL(weight_prep_fprop_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, scale, (bf16_t*)w_fprop, (long long)(taps * cin), total);
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_fprop_kernel<T16>, dim3(grid), dim3(256), 0, s, w, scale, (T16*)w_fprop, (long long)(taps * cin), total));
   }
   if (w_dgrad) {
     dim3 grid((unsigned)((cin + 31) / 32), (unsigned)((cout + 31) / 32), (unsigned)taps);
     if (dtype == VLFB_F32)
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<float>, grid, dim3(32, 8), 0, s, w, scale, (float*)w_dgrad, (int)cout, (int)taps, (int)cin);
     else
-      hipLaunchKernelGGL(weight_prep_dgrad_kernel<bf16_t>, grid, dim3(32, 8), 0, s, w, scale, (bf16_t*)w_dgrad, (int)cout, (int)taps, (int)cin);
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_dgrad_kernel<T16>, grid, dim3(32, 8), 0, s, w, scale, (T16*)w_dgrad, (int)cout, (int)taps, (int)cin));
   }
   return check_launch("weight_prep");
 }
@@ -788,9 +788,9 @@ extern "C" int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y,
   else if (d->dtype == VLFB_F32)
     hipLaunchKernelGGL((maxpool_fwd_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, (uint16_t*)argmax, p);
   else if (!wide)
-    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, uint8_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (uint8_t*)argmax, p);
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T16, uint8_t>), dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, (uint8_t*)argmax, p));
   else
-    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, uint16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (uint16_t*)argmax, p);
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T16, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, (uint16_t*)argmax, p));
   return check_launch("maxpool_fwd");
 }
 extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax,
@@ -808,9 +808,9 @@ extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const v
   else if (d->dtype == VLFB_F32)
     hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint16_t*)argmax, (float*)dx, (const float*)add, (const float*)mask, p, 1.f);
   else if (!wide)
-    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const uint8_t*)argmax, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, 1.f);
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint8_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f));
   else
-    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const uint16_t*)argmax, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, 1.f);
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f));
   return check_launch("maxpool_bwd");
 }
 extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream) {
@@ -828,13 +828,13 @@ extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y,
     if (d->dtype == VLFB_F32)
       hipLaunchKernelGGL(global_avgpool_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, rows, p.C);
     else
-      hipLaunchKernelGGL(global_avgpool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, p.C);
+      VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL(global_avgpool_kernel<T16>, grid, dim3(256), 0, s, (const T16*)x, (T16*)y, rows, p.C));
   } else {
     int grid = grid_for((long long)p.N * p.To * p.Ho * p.Wo * (p.C / v), 256);
     if (d->dtype == VLFB_F32)
       hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, p);
     else
-      hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, p);
+      VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, p));
   }
   return check_launch("avgpool_fwd");
 }
@@ -851,7 +851,7 @@ extern "C" int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* d
   if (d->dtype == VLFB_F32)
     hipLaunchKernelGGL((pool_bwd_kernel<float, false, uint8_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const uint8_t*)nullptr, (float*)dx, (const float*)add, (const float*)mask, p, inv);
   else
-    hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false, uint8_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const uint8_t*)nullptr, (bf16_t*)dx, (const bf16_t*)add, (const bf16_t*)mask, p, inv);
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, false, uint8_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T16*)dy, (const uint8_t*)nullptr, (T16*)dx, (const T16*)add, (const T16*)mask, p, inv));
   return check_launch("avgpool_bwd");
 }
 
@@ -859,22 +859,22 @@ extern "C" int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows
                                 float scale, vlfb_stream_t stream) {
   VLFB_REQUIRE(s && p && rows > 0 && cols > 0 && cols < (1ll << 31), "softmax_fwd: bad args");
   int grid = grid_for(rows * 64, 256);
-  if (cols % 4 == 0 && cols <= 64 * 4 * 8 && (dtype == VLFB_F32 || dtype == VLFB_BF16)) {
+  if (cols % 4 == 0 && cols <= 64 * 4 * 8 && (dtype == VLFB_F32 || is16(dtype))) {
     hipStream_t st = (hipStream_t)stream;
     const bool small = cols <= 64 * 4 * 4;
     if (dtype == VLFB_F32) {
       if (small) hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<float, 4>), dim3(grid), dim3(256), 0, st, s, (float*)p, (long long)rows, (int)cols, scale);
       else hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<float, 8>), dim3(grid), dim3(256), 0, st, s, (float*)p, (long long)rows, (int)cols, scale);
     } else {
-      if (small) hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, s, (bf16_t*)p, (long long)rows, (int)cols, scale);
-      else hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, s, (bf16_t*)p, (long long)rows, (int)cols, scale);
+      if (small) VLFB_WITH_T16(dtype, hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<T16, 4>), dim3(grid), dim3(256), 0, st, s, (T16*)p, (long long)rows, (int)cols, scale));
+      else VLFB_WITH_T16(dtype, hipLaunchKernelGGL((softmax_fwd_rowreg_kernel<T16, 8>), dim3(grid), dim3(256), 0, st, s, (T16*)p, (long long)rows, (int)cols, scale));
     }
     return check_launch("softmax_fwd");
   }
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (float*)p, (long long)rows, (int)cols, scale);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, (long long)rows, (int)cols, scale);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (T16*)p, (long long)rows, (int)cols, scale));
   else return set_error(VLFB_ERR_ARG, "softmax_fwd: bad dtype");
   return check_launch("softmax_fwd");
 }
@@ -882,22 +882,22 @@ extern "C" int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dt
                                 int64_t cols, float scale, vlfb_stream_t stream) {
   VLFB_REQUIRE(dp && p && ds && rows > 0 && cols > 0 && cols < (1ll << 31), "softmax_bwd: bad args");
   int grid = grid_for(rows * 64, 256);
-  if (cols % 4 == 0 && cols <= 64 * 4 * 8 && (dtype == VLFB_F32 || dtype == VLFB_BF16)) {
+  if (cols % 4 == 0 && cols <= 64 * 4 * 8 && (dtype == VLFB_F32 || is16(dtype))) {
     hipStream_t st = (hipStream_t)stream;
     const bool small = cols <= 64 * 4 * 4;
     if (dtype == VLFB_F32) {
       if (small) hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<float, 4>), dim3(grid), dim3(256), 0, st, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
       else hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<float, 8>), dim3(grid), dim3(256), 0, st, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
     } else {
-      if (small) hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, dp, (const bf16_t*)p, (bf16_t*)ds, (long long)rows, (int)cols, scale);
-      else hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, dp, (const bf16_t*)p, (bf16_t*)ds, (long long)rows, (int)cols, scale);
+      if (small) VLFB_WITH_T16(dtype, hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<T16, 4>), dim3(grid), dim3(256), 0, st, dp, (const T16*)p, (T16*)ds, (long long)rows, (int)cols, scale));
+      else VLFB_WITH_T16(dtype, hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<T16, 8>), dim3(grid), dim3(256), 0, st, dp, (const T16*)p, (T16*)ds, (long long)rows, (int)cols, scale));
     }
     return check_launch("softmax_bwd");
   }
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (const float*)p, (float*)ds, (long long)rows, (int)cols, scale);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (const bf16_t*)p, (bf16_t*)ds, (long long)rows, (int)cols, scale);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (const T16*)p, (T16*)ds, (long long)rows, (int)cols, scale));
   else return set_error(VLFB_ERR_ARG, "softmax_bwd: bad dtype");
   return check_launch("softmax_bwd");
 }
@@ -910,8 +910,8 @@ extern "C" int vlfb_add(const void* a, const void* b, void* y, const void* mask,
   int grid = grid_for((n + v - 1) / v, 256);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, (const float*)mask, (long long)n, relu);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (const bf16_t*)mask, (long long)n, relu);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(add_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T16*)a, (const T16*)b, (T16*)y, (const T16*)mask, (long long)n, relu));
   else return set_error(VLFB_ERR_ARG, "add: bad dtype");
   return check_launch("add");
 }
@@ -939,8 +939,8 @@ extern "C" int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols,
   dim3 grid((unsigned)cblocks, (unsigned)slabs);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)g, (long long)rows, (int)cols, (long long)ld, out);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, (long long)rows, (int)cols, (long long)ld, out);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(colsum_kernel<T16>, grid, dim3(256), 0, s, (const T16*)g, (long long)rows, (int)cols, (long long)ld, out));
   else return set_error(VLFB_ERR_ARG, "colsum: bad dtype");
   return check_launch("colsum");
 }
@@ -951,8 +951,8 @@ extern "C" int vlfb_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd,
   int grid = grid_for(rows * cols, 256);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(copy2d_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, (long long)lds, (float*)dst, (long long)ldd, (long long)rows, (long long)cols);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long long)lds, (bf16_t*)dst, (long long)ldd, (long long)rows, (long long)cols);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(copy2d_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T16*)src, (long long)lds, (T16*)dst, (long long)ldd, (long long)rows, (long long)cols));
   else return set_error(VLFB_ERR_ARG, "copy2d: bad dtype");
   return check_launch("copy2d");
 }
@@ -969,8 +969,8 @@ extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_
   dim3 block(32, 8);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(weight_prep_batched_kernel<float>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(weight_prep_batched_kernel<bf16_t>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_batched_kernel<T16>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items));
   else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
   return check_launch("weight_prep_batched");
 }
@@ -983,8 +983,8 @@ extern "C" int vlfb_ncthw_to_nthwc_wpad(const float* src, void* dst, int dtype, 
   int grid = grid_for(n * rows * w_total, 256);
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(ncthw_to_nthwc_wpad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long long)n, (int)c, (long long)rows, (int)w, (int)c_pad, (int)wpad_left, (int)w_total);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(ncthw_to_nthwc_wpad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n, (int)c, (long long)rows, (int)w, (int)c_pad, (int)wpad_left, (int)w_total);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(ncthw_to_nthwc_wpad_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (T16*)dst, (long long)n, (int)c, (long long)rows, (int)w, (int)c_pad, (int)wpad_left, (int)w_total));
   else return set_error(VLFB_ERR_ARG, "ncthw_to_nthwc_wpad: bad dtype");
   return check_launch("ncthw_to_nthwc_wpad");
 }

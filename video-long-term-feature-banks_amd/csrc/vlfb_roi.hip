@@ -208,8 +208,8 @@ extern "C" int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(roi_align_max_fwd_kernel<float>, dim3((unsigned)r), dim3(threads), lds, s, (const float*)feat, rois, (float*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(roi_align_max_fwd_kernel<bf16_t>, dim3((unsigned)r), dim3(threads), lds, s, (const bf16_t*)feat, rois, (bf16_t*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(roi_align_max_fwd_kernel<T16>, dim3((unsigned)r), dim3(threads), lds, s, (const T16*)feat, rois, (T16*)out, argbin, dbg, (int)h, (int)w, (int)c, pooled, spatial_scale));
   else return set_error(VLFB_ERR_ARG, "roi_align_fwd: bad dtype");
   return check_launch("roi_align_max_fwd");
 }
@@ -223,8 +223,8 @@ extern "C" int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
     hipLaunchKernelGGL(roi_align_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale);
-  else if (dtype == VLFB_BF16)
-    hipLaunchKernelGGL(roi_align_max_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale);
+  else if (is16(dtype))
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(roi_align_max_bwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale));
   else return set_error(VLFB_ERR_ARG, "roi_align_bwd: bad dtype");
   return check_launch("roi_align_max_bwd");
 }

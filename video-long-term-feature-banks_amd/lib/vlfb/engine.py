@@ -59,6 +59,7 @@ class Blob(object):
         self.detached = False
         self.slot = None              # GradSlot (root only)
         self.producer = None
+        self.grad_scale = 1.0         # the stored gradient is the true one times this power of two (fp16 range)
 
     @property
     def numel(self):
@@ -195,6 +196,9 @@ class ConvStep(Step):
         self.pack = 8 if self.stem else 0
         code = eng.code
         common = dict(dtype=code, **self._geom())
+        # the gradient arriving at `out` may be stored scaled (fp16 attention logits): divide it out in the
+        # epilogues of the kernels that consume it
+        self.gscale = float(self.out.root.grad_scale)
         if self.stem:
             # the data blob is stored with 4 zero pixels on both sides of every W row
             wpad = getattr(self.x.root, "pad_w", 0) or getattr(self.x, "pad_w", 0)
@@ -208,11 +212,12 @@ class ConvStep(Step):
         if self.x.needs_grad and not self.x.detached:
             assert not self.stem
             self.d_d = hip.conv_desc(mode=hip.DGRAD, out_dtype=code, N=N, Tr=T, Hr=H, Wr=W, Ts=To,
-                                     Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, **common)
+                                     Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, alpha=1.0 / self.gscale, **common)
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
-                                     Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, **common)
+                                     Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
+                                     **common)
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
         # operand copies
         wshape = eng.kernel_shape(self.wname)
@@ -297,6 +302,8 @@ class ConvStep(Step):
                          hip.ptr(gb), 1, Cout, 1)
             else:
                 hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
+            if self.gscale != 1.0:
+                hip.call("vlfb_scale_inplace", hip.ptr(gb), gb.numel(), 1.0 / self.gscale)
 
 
 class PoolStep(Step):
@@ -365,11 +372,22 @@ class AttentionStep(Step):
         self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2)
         self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci)
         self.d_dp = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2)
-        self.d_dth = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci)
+        # fp16: dS = scale * P o (dP - <dP, P>) is ~ 1 / L2 of an activation gradient and would leave the fp16
+        # range (6e-8) for long key axes (1568 keys in 64-frame clips); it is stored times a power of two, which
+        # the two products that consume it divide out again in their epilogues (alpha).  Exact; 1 elsewhere.
+        self.ds_scale = float(16 << max(L2 - 1, 1).bit_length()) if eng.tdtype == torch.float16 else 1.0
+        # ... and the gradients of theta / phi themselves (again ~ 1 / L2 of an activation gradient) are stored
+        # times Blob.grad_scale (set at lowering), which the theta / phi convs divide out (ConvStep.gscale)
+        gs_th, gs_ph = float(self.theta.root.grad_scale), float(self.phi.root.grad_scale)
+        self.d_dth = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
+                          alpha=gs_th / self.ds_scale)
         # contract over L1: out[L2][Ci] = sum_l P[l][L2] * A[l][Ci]
         self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                   Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
                                   o_bstride=L2 * Ci, splits=1)
+        self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
+                                      Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
+                                      o_bstride=L2 * Ci, splits=1, alpha=gs_ph / self.ds_scale)
         eng.need_scratch_f32(B * L1 * L2)
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
 
@@ -409,11 +427,11 @@ class AttentionStep(Step):
         act = eng.scratch_act(B * L1 * L2 + B * Ci * L2)
         dS = act[:B * L1 * L2]
         phT = act[B * L1 * L2:]
-        hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2, self.scale)
+        hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2, self.scale * self.ds_scale)
         hip.call("vlfb_transpose2d", self.phi.ptr(), hip.ptr(phT), eng.code, B, L2, Ci)
         th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
                       supports_add=False, supports_mask=False)
-        ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, self.theta.storage(), None, dS, out),
+        ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.storage(), None, dS, out),
                       supports_add=False, supports_mask=False)
 
 
@@ -658,6 +676,12 @@ class LossStep(Step):
         self.dlogits = None
         self.ring = None
         self.ring_pos = 0
+        if self.loss is not None and self.eng.auto_loss_scale:
+            # fp16: |dlogits| <= scale / normaliser (normaliser = #targets for the sigmoid loss, #rows for the
+            # softmax loss); pick the power of two that puts that bound at 2^6, so that the gradients of a
+            # production step (1/8 loss scale, ~1900 targets) and of a 2-clip test sit in the same fp16 range
+            norm = self.rows * self.cols if self.kernel == "vlfb_sigmoid_ce" else self.rows
+            self.eng.loss_scale = float(2.0 ** round(math.log2(64.0 * norm / self.scale)))
         if self.loss is not None:
             self.dlogits = torch.empty(self.rows * self.cols, device=self.eng.device, dtype=torch.float32)
             # the last LOSS_RING losses stay on the device: the NaN guard (utils.misc.check_nan_losses)
@@ -669,6 +693,8 @@ class LossStep(Step):
                  self.prob.ptr() if self.prob is not None else None,
                  self.loss.ptr() if self.loss is not None else None, hip.ptr(self.dlogits), self.rows, self.cols,
                  self.scale)
+        if self.dlogits is not None and self.eng.loss_scale != 1.0:
+            hip.call("vlfb_scale_inplace", hip.ptr(self.dlogits), self.dlogits.numel(), self.eng.loss_scale)
         if self.ring is not None:
             self.ring.narrow(0, self.ring_pos % LOSS_RING, 1).copy_(self.loss.root.tensor.narrow(0, 0, 1), non_blocking=True)
             self.ring_pos += 1
@@ -960,6 +986,12 @@ class Lowering(object):
         B, Ci, L1 = theta.shape
         L2 = phi.shape[2]
         single = (L1 == 1)
+        if not single and self.eng.tdtype == torch.float16:
+            # fp16: d theta and d phi are about 1 / L2 of a normal activation gradient (they pass the softmax
+            # Jacobian): keep them times a power of two so that they stay in the fp16 normal range
+            for t in (theta, phi):
+                if isinstance(t.root.producer, ConvStep):
+                    t.root.grad_scale = float(1 << max(L2 - 1, 1).bit_length())
         prob = self.new_blob(prob_name, (B, L1, L2), 2, "f32" if single else "act")
         out = self.new_blob(mm.outputs[0], (B, Ci, L1), 1)
         out.needs_grad = True
@@ -1099,7 +1131,7 @@ class Engine(object):
     """One per-GPU replica: plan once, then forward()/backward()/allreduce()/sgd_step()."""
 
     def __init__(self, model, dtype="bf16", device=None, base_seed=None, dry_run=False, debug_roi=False,
-                 share_params_with=None, side_stream=True):
+                 share_params_with=None, side_stream=True, loss_scale=None):
         """share_params_with: another Engine of the same scope (the train net's, when this is the test / val
         net of the same process).  Caffe2 nets of one workspace share their parameter BLOBS
         (tools/train_net.py builds train_model and test_model in one workspace and evaluates the weights
@@ -1116,9 +1148,16 @@ class Engine(object):
         if not self.dry_run and not torch.cuda.is_available():
             raise hip.VlfbError("vlfb.engine needs a GPU: there is no CPU fallback for the hot path")
         self.model = model
-        self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[dtype]
+        self.tdtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "fp32": torch.float32,
+                       "f32": torch.float32}[dtype]
         self.code = hip.dtype_code(self.tdtype)
-        self.esize = 2 if self.tdtype == torch.bfloat16 else 4
+        self.esize = 4 if self.tdtype == torch.float32 else 2
+        # fp16 storage (v_mfma_f32_16x16x32_f16; BASELINE.json configs[4]): 10 mantissa bits instead of bf16's 7,
+        # but gradients of 1e-6 fall below the fp16 normal range, so the loss gradient is scaled by a power of two
+        # (exact) and every parameter gradient carries that factor until the solver divides it out again
+        # (lr / S, weight decay * S: lr/S * (S g + S wd p) = lr * (g + wd p)).  1 on the other paths.
+        self.auto_loss_scale = loss_scale is None and self.tdtype == torch.float16   # set by LossStep.setup from the shapes
+        self.loss_scale = float(loss_scale if loss_scale is not None else 1.0)
         self.device = torch.device("meta") if self.dry_run else torch.device(device or ("cuda:%d" % dist.local_rank()))
         self.train = bool(model.train and not model.force_fw_only and model.loss_blob is not None)
         self.base_seed = int(cfg.RNG_SEED if base_seed is None else base_seed)
@@ -1331,6 +1370,9 @@ class Engine(object):
             for b in st.grad_inputs():
                 live.add(id(b.root))
                 b.root.slot.expected += 1
+        for b in self.all_blobs:
+            if b.root is b and b.grad_scale != 1.0:
+                assert b.slot.expected <= 1, "a scaled gradient (%s) must have a single contributor" % b.name
 
     def _allocate(self):
         dev = self.device
@@ -1411,7 +1453,9 @@ class Engine(object):
         return self._from_kernel_layout(name, self.param_views[name])
 
     def fetch_grad(self, name):
-        return self._from_kernel_layout(name, self.grad_views[name])
+        """parameter gradient in the reference layout (the fp16 loss scale divided out)"""
+        g = self._from_kernel_layout(name, self.grad_views[name])
+        return g / np.float32(self.loss_scale) if self.loss_scale != 1.0 else g
 
     def fetch_momentum(self, name):
         off, cnt, shape = self.train_layout[name]
@@ -1528,6 +1572,8 @@ class Engine(object):
             raise KeyError("blob %r was fused away (its value only exists inside a kernel epilogue)" % name)
         src = b.root.slot.cur if grad else b.root.tensor
         t = src.detach().float().cpu()
+        if grad and self.loss_scale != 1.0:
+            t = t / self.loss_scale
         if getattr(b.root, "pad_c", None) and not grad:
             wpad = getattr(b.root, "pad_w", 0)
             W = b.shape[-1]
@@ -1618,9 +1664,10 @@ class Engine(object):
         if self.comm is not None:
             self.comm.wait()
         sol = cfg.SOLVER
+        S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
         for off, end, wd in self.wd_ranges:       # one launch unless a trainable '_bn' parameter exists
             hip.call("vlfb_sgd_update", hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off,
-                     hip.ptr(self.flat_mom) + 4 * off, end - off, self.lr, wd, float(sol.MOMENTUM),
+                     hip.ptr(self.flat_mom) + 4 * off, end - off, self.lr / S, wd * S, float(sol.MOMENTUM),
                      int(bool(sol.NESTEROV)))
         self._pstate[0] += 1
         self.refresh_operands()

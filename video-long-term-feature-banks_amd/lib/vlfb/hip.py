@@ -10,7 +10,7 @@ import os
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256 = 0, 1, 2
@@ -18,7 +18,7 @@ ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlfb_hip.so")
 
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 
 def dtype_code(t):
@@ -26,6 +26,8 @@ def dtype_code(t):
         return F32
     if t == torch.bfloat16:
         return BF16
+    if t == torch.float16:
+        return F16
     raise TypeError("vlfb: unsupported dtype %r" % (t,))
 
 

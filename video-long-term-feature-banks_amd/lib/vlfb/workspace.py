@@ -14,8 +14,8 @@ _clock = {"t": 0}  # RunNet counter: a blob that several nets of one scope produ
 
 
 def set_compute_dtype(name):
-    """'bf16' (throughput path) or 'fp32' (parity path) for engines created afterwards"""
-    assert name in ("bf16", "fp32")
+    """'bf16' / 'fp16' (throughput paths) or 'fp32' (parity path) for engines created afterwards"""
+    assert name in ("bf16", "fp16", "fp32")
     _dtype["value"] = name
 
 
