@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--crop", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--set", nargs="*", default=[], metavar="KEY VAL",
+                    help="extra cfg overrides, e.g. --set MODEL.FREEZE_BACKBONE False (SURVEY 8d C3 'unfrozen')")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="development: parameter-gradient kernels on the main stream too (uncontended per-launch times for --detail)")
     ap.add_argument("--detail", default="", help="write the per-launch GEMM table of the profiled step to this file")
     return ap.parse_args()
 
@@ -103,10 +107,10 @@ def main():
 
     clips = args.clips_per_gpu
     load_preset(args.workload, ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", clips * world,
-                                "TRAIN.VIDEO_LENGTH", args.frames, "TRAIN.CROP_SIZE", args.crop])
+                                "TRAIN.VIDEO_LENGTH", args.frames, "TRAIN.CROP_SIZE", args.crop] + list(args.set))
     model = ModelBuilder(train=True, split="train", name="bench")
     model.build_model(suffix="_train")
-    eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED)
+    eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED, side_stream=not args.single_stream)
     rois = args.rois_per_clip if args.rois_per_clip > 0 else synth.rois_per_clip_draw(clips, seed=cfg.RNG_SEED + rank)
     batch = synth.inputs(cfg, clips, rois, seed=cfg.RNG_SEED + rank, crop=args.crop, frames=args.frames)
     n_rois = int(batch["proposals_train"].shape[0]) if "proposals_train" in batch else 0
@@ -212,7 +216,8 @@ def main():
         ("config", {"workload": "%s fwd+bwd+allreduce+sgd, %d clips/GPU (global batch %d), %s, %dx%dx%d clips"
                                 % (args.workload, clips, clips * world,
                                    ("%d RoIs/clip" % args.rois_per_clip) if args.rois_per_clip > 0 else
-                                   ("RoIs/clip ~ U{1..5} (%d on rank 0)" % n_rois), args.frames, args.crop, args.crop),
+                                   ("RoIs/clip ~ U{1..5} (%d on rank 0)" % n_rois), args.frames, args.crop, args.crop)
+                                + ((" [" + " ".join(args.set) + "]") if args.set else ""),
                     "parallelism": "dp%d" % world, "final_loss": loss}),
         ("roofline", roof("nt", "gemm_nt_kernel (implicit-GEMM conv fprop+dgrad, attention NT GEMMs)")),
         ("roofline_wgrad", roof("tn", "gemm_tn_kernel (implicit-GEMM conv wgrad, attention TN GEMMs)")),

@@ -217,6 +217,21 @@ int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows, int64_t c
                      vlfb_stream_t stream);
 int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dtype, int64_t rows,
                      int64_t cols, float scale, vlfb_stream_t stream);
+/* The same two operators FUSED with the batched product that feeds them (nonlocal_helper.py:94-121), so the fp32
+ * score matrix never exists in memory:
+ *   fwd:  prob[b][l1][l2] = softmax_l2(scale * sum_c theta[b][l1][c] * phi[b][l2][c])
+ *   bwd:  ds[b][l1][l2]   = scale * prob o (dP - sum_l2(dP o prob)),  dP = sum_c dy[b][l1][c] * g[b][l2][c]
+ * operands / outputs are `dtype` (16-bit types only), row-major as indexed above.  Supported shapes:
+ * 512 <= l2 <= 1024 with l2 % 8 == 0, ci % 64 == 0; otherwise VLFB_ERR_UNSUPPORTED and the caller composes
+ * vlfb_conv_run + vlfb_softmax_*.  vlfb_attn_scores_supported returns 0 or a mask of the flags below: whether the
+ * shape can run at all, and for which direction the fused kernel was MEASURED faster than the composed one on
+ * MI355X (the engine fuses a direction only then). */
+enum { VLFB_ATTN_CAN_RUN = 1, VLFB_ATTN_FWD_FASTER = 2, VLFB_ATTN_BWD_FASTER = 4 };
+int vlfb_attn_scores_supported(int dtype, int64_t l1, int64_t l2, int64_t ci);
+int vlfb_attn_scores_fwd(const void* theta, const void* phi, void* prob, int dtype, int64_t batch, int64_t l1,
+                         int64_t l2, int64_t ci, float scale, vlfb_stream_t stream);
+int vlfb_attn_scores_bwd(const void* dy, const void* g, const void* prob, void* ds, int dtype, int64_t batch,
+                         int64_t l1, int64_t l2, int64_t ci, float scale, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small elementwise / reduction ops (rows x cols matrices of `dtype`, cols contiguous).

@@ -307,6 +307,50 @@ def test_epic_single_label_head_train_and_test(preset):
     assert rel(eng2.fetch("prob"), tb["prob"].numpy()) < 1e-3
 
 
+def _survey_literal_params(cfg, seed=2):
+    """SURVEY.md 8(d), literally: MSRA normal for `*_w` convs of the backbone, N(0, 0.01) for non-local / FC / FBO
+    weights (incl. the normally zero-initialised output convs), affine s ~ U(0.5, 1.5), b ~ N(0, 0.1) -- WITHOUT the
+    smaller residual-exit gains and theta/phi boosts oracle.synth_params applies to keep 16 un-normalised blocks O(1)"""
+    from oracle import model as om
+    gen = np.random.default_rng(seed)
+    out = collections.OrderedDict()
+    for name, sp in om.param_spec(cfg).items():
+        shape, kind = sp["shape"], sp["kind"]
+        if kind == "msra":
+            v = gen.standard_normal(shape) * math.sqrt(2.0 / (shape[0] * int(np.prod(shape[2:]))))
+        elif kind in ("gauss", "nl_out", "fbo_out"):
+            v = gen.standard_normal(shape) * 0.01
+        elif kind == "zero_bias":
+            v = gen.standard_normal(shape) * 0.01
+        elif kind == "affine_s":
+            v = gen.uniform(0.5, 1.5, shape)
+        else:
+            v = gen.standard_normal(shape) * 0.1
+        out[name] = v.astype(np.float32)
+    return out
+
+
+def test_survey_literal_weight_recipe_fp32():
+    """the parity bar does not lean on the tamed synthetic weights: with the survey's literal recipe (activations grow
+    through the un-normalised residual stack) the fp32 path still matches the fp64 oracle on outputs and gradients"""
+    from oracle import model as om
+    cfg, model, eng, inputs, _, seed_fn = build("charades_r50_baseline", "fp32")
+    params = _survey_literal_params(cfg)
+    eng.feed_params(params)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    for name in ("res5_2_branch2c_bn", "pool5", "pred", "prob"):
+        got = eng.fetch(name)
+        assert rel(got, blobs[name].detach().numpy().reshape(got.shape)) < 1e-3, name
+    ref_loss = float(blobs["loss"].detach())
+    assert abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) < 1e-3 * abs(ref_loss)
+    gmax = max(float(g.norm()) for g in grads.values())
+    errs = [rel(eng.fetch_grad(n), grads[n].numpy()) for n in eng.trainable if float(grads[n].norm()) > 1e-9 * gmax]
+    assert np.median(errs) < 1e-3 and max(errs) < 2e-2, (np.median(errs), max(errs))
+
+
 VARIANTS = {
     "charades_r50_lfb_avg": ("charades_r50_lfb_avg", SMALL),
     "ava_r50_lfb_max": ("ava_r50_lfb_max", SMALL),

@@ -388,7 +388,14 @@ class AttentionStep(Step):
         self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                       Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
                                       o_bstride=L2 * Ci, splits=1, alpha=gs_ph / self.ds_scale)
-        eng.need_scratch_f32(B * L1 * L2)
+        # 16-bit paths: scores + row softmax (and their backward) in one kernel each, the fp32 score matrix never
+        # exists (csrc/vlfb_attn.hip) -- per direction, and only where the library reports the fused kernel as
+        # measured faster; otherwise GEMM -> fp32 scratch -> softmax kernels
+        can = hip.lib().vlfb_attn_scores_supported(code, L1, L2, Ci)
+        self.fused_fwd = bool(can & hip.ATTN_FWD_FASTER)
+        self.fused_bwd = bool(can & hip.ATTN_BWD_FASTER)
+        if not (self.fused_fwd and self.fused_bwd):
+            eng.need_scratch_f32(B * L1 * L2)
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
 
     def fwd(self):
@@ -398,9 +405,13 @@ class AttentionStep(Step):
             hip.call("vlfb_fbo_attn_fwd", self.theta.ptr(), self.phi.ptr(), self.g.ptr(), self.prob.ptr(),
                      self.out.ptr(), eng.code, B, L2, Ci, Ci, self.scale)
             return
-        S = eng.scratch_f32(B * L1 * L2)
-        hip.conv_run(self.d_s, self.theta.storage(), self.phi.storage(), None, S)
-        hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
+        if self.fused_fwd:
+            hip.call("vlfb_attn_scores_fwd", self.theta.ptr(), self.phi.ptr(), self.prob.ptr(), eng.code, B, L1, L2, Ci,
+                     self.scale)
+        else:
+            S = eng.scratch_f32(B * L1 * L2)
+            hip.conv_run(self.d_s, self.theta.storage(), self.phi.storage(), None, S)
+            hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
         gT = eng.scratch_act(B * Ci * L2)
         hip.call("vlfb_transpose2d", self.g.ptr(), hip.ptr(gT), eng.code, B, L2, Ci)
         hip.conv_run(self.d_y, self.prob.storage(), gT, None, self.out.storage())
@@ -419,15 +430,21 @@ class AttentionStep(Step):
                      self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), hip.ptr(self.ds_ws),
                      eng.code, B, L2, Ci, Ci, self.scale)
             return
-        dP = eng.scratch_f32(B * L1 * L2)
-        hip.conv_run(self.d_dp, dY, self.g.storage(), None, dP)
         P = self.prob.storage()
+        if not self.fused_bwd:
+            dP = eng.scratch_f32(B * L1 * L2)
+            hip.conv_run(self.d_dp, dY, self.g.storage(), None, dP)
         gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
                       supports_add=False, supports_mask=False)
         act = eng.scratch_act(B * L1 * L2 + B * Ci * L2)
         dS = act[:B * L1 * L2]
         phT = act[B * L1 * L2:]
-        hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2, self.scale * self.ds_scale)
+        if self.fused_bwd:
+            hip.call("vlfb_attn_scores_bwd", hip.ptr(dY), self.g.ptr(), hip.ptr(P), hip.ptr(dS), eng.code, B, L1, L2, Ci,
+                     self.scale * self.ds_scale)
+        else:
+            hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2,
+                     self.scale * self.ds_scale)
         hip.call("vlfb_transpose2d", self.phi.ptr(), hip.ptr(phT), eng.code, B, L2, Ci)
         th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
                       supports_add=False, supports_mask=False)

@@ -14,6 +14,7 @@ F32, BF16, F16 = 0, 1, 2
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256 = 0, 1, 2
+ATTN_CAN_RUN, ATTN_FWD_FASTER, ATTN_BWD_FASTER = 1, 2, 4     # vlfb_attn_scores_supported flags
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlfb_hip.so")
@@ -103,6 +104,9 @@ _SIGS = {
     "vlfb_avgpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P]),
     "vlfb_softmax_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_softmax_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
+    "vlfb_attn_scores_supported": (C.c_int, [C.c_int, _I64, _I64, _I64]),
+    "vlfb_attn_scores_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
+    "vlfb_attn_scores_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
     "vlfb_add": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, C.c_int, _P]),
     "vlfb_relu_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _P]),
     "vlfb_relu_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _P]),
