@@ -12,7 +12,7 @@ def per_family(root, counter):
     fam = collections.defaultdict(lambda: [0, 0.0])
     q = "select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name = ? group by dispatch_id"
     for name, _, v in cur.execute(q, (counter,)):
-        key = 'gemm_nt' if 'gemm_nt_kernel' in name else 'gemm_tn' if ('gemm_tn_' in name or 'stem_wgrad' in name or 'wgrad_reduce' in name) else None
+        key = 'gemm_nt' if ('gemm_nt_kernel' in name or 'gemm_nt8_kernel' in name) else 'gemm_tn' if ('gemm_tn_' in name or 'gemm_tn8_' in name or 'stem_wgrad' in name or 'wgrad_reduce' in name) else None
         if key:
             if 'wgrad_reduce' not in name:
                 fam[key][0] += 1
