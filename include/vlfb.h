@@ -202,6 +202,12 @@ int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, void* argm
  * `add` may alias dx. Gather formulation: deterministic, no atomics. */
 int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax, void* dx,
                      const void* add, const void* mask, vlfb_stream_t stream);
+/* The same backward for a max-pool whose INPUT is a ReLU output and has no other consumer (pool1 after conv1, pool2
+ * after res2: resnet_video.py:183-194, 229-236): the selected element is the pooled value itself, so the ReLU mask
+ * of the input is `y > 0` read at the window's output position -- bit-identical to vlfb_maxpool_bwd(mask = x) and
+ * kt*kh*kw / (st*sh*sw) times less mask traffic. */
+int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax, const void* y, void* dx,
+                          vlfb_stream_t stream);
 /* average over the window (pad 0 only, as every AveragePool in the reference) */
 int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream);
 int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* dx, const void* add,

@@ -305,6 +305,14 @@ def test_maxpool_fwd_bwd(name, dtype):
              gp(to_nthwc(add), dtype), hip.ptr(X))
     ref = torch.where(x.double() > 0, gx + add.double(), torch.zeros_like(gx))
     assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
+    # pool of a ReLU output with no other consumer: mask from the pooled tensor == mask from the input, bit for bit
+    XR = torch.relu(X)
+    hip.call("vlfb_maxpool_fwd", C.byref(d), hip.ptr(XR), hip.ptr(Y), hip.ptr(AM))
+    D1, D2 = torch.empty_like(DX), torch.empty_like(DX)
+    DY = gp(to_nthwc(dy), dtype)
+    hip.call("vlfb_maxpool_bwd", C.byref(d), DY, hip.ptr(AM), hip.ptr(D1), None, hip.ptr(XR))
+    hip.call("vlfb_maxpool_relu_bwd", C.byref(d), DY, hip.ptr(AM), hip.ptr(Y), hip.ptr(D2))
+    assert torch.equal(D1, D2) and float(D1.float().abs().sum()) > 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

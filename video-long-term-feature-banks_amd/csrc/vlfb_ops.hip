@@ -258,7 +258,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 template <typename T, bool IS_MAX, typename IdxT>
 __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict__ argmax,
                                 T* dx, const T* add, const T* __restrict__ mask, PoolP p,
-                                float inv_window) {
+                                float inv_window, const T* __restrict__ ymask = nullptr) {
   constexpr int V = Vec16<T>::N;
   const int cchunks = p.C / V;
   const long long total = (long long)p.N * p.Ti * p.Hi * p.Wi * cchunks;
@@ -289,6 +289,14 @@ __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict
           const long long o = (((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
           float g[V];
           Vec16<T>::load(dy + o * p.C + cc * V, g);
+          if (IS_MAX && ymask) {
+            // max-pool of a ReLU output: the selected element IS the pooled value, so "the input passed its
+            // ReLU" can be read from the (window-times smaller) pooled tensor instead of the input
+            float yv[V];
+            Vec16<T>::load(ymask + o * p.C + cc * V, yv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+          }
           if (IS_MAX && sizeof(IdxT) == 2) {
             const int tap = (a * p.kh + b) * p.kw + c;
             const IdxT* am = argmax + o * p.C + cc * V;
@@ -812,6 +820,26 @@ extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const v
   else
     VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f));
   return check_launch("maxpool_bwd");
+}
+extern "C" int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax, const void* y,
+                                     void* dx, vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(dy && argmax && dx && y, "maxpool_relu_bwd: null pointer");
+  PoolP p = to_poolp(d);
+  const int v = d->dtype == VLFB_F32 ? 4 : 8;
+  const bool wide = vlfb_pool_argmax_bytes(d) == 2;
+  int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == VLFB_F32 && !wide)
+    hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint8_t*)argmax, (float*)dx, (const float*)nullptr, (const float*)nullptr, p, 1.f, (const float*)y);
+  else if (d->dtype == VLFB_F32)
+    hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint16_t*)argmax, (float*)dx, (const float*)nullptr, (const float*)nullptr, p, 1.f, (const float*)y);
+  else if (!wide)
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint8_t*)argmax, (T16*)dx, (const T16*)nullptr, (const T16*)nullptr, p, 1.f, (const T16*)y));
+  else
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)nullptr, (const T16*)nullptr, p, 1.f, (const T16*)y));
+  return check_launch("maxpool_relu_bwd");
 }
 extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream) {
   int rc = check_pool(d);

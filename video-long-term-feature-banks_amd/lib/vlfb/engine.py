@@ -337,8 +337,14 @@ class PoolStep(Step):
             return
         g = self.out_grad()
         if self.is_max:
-            fn = lambda out, add, mask: hip.call("vlfb_maxpool_bwd", C.byref(self.desc), hip.ptr(g),
-                                                 hip.ptr(self.argmax), hip.ptr(out), hip.ptr(add), hip.ptr(mask))
+            def fn(out, add, mask):
+                if mask is not None and add is None:
+                    # sole consumer of a ReLU output: the mask is `pooled value > 0` (see vlfb_maxpool_relu_bwd)
+                    hip.call("vlfb_maxpool_relu_bwd", C.byref(self.desc), hip.ptr(g), hip.ptr(self.argmax),
+                             self.out.ptr(), hip.ptr(out))
+                else:
+                    hip.call("vlfb_maxpool_bwd", C.byref(self.desc), hip.ptr(g), hip.ptr(self.argmax), hip.ptr(out),
+                             hip.ptr(add), hip.ptr(mask))
         else:
             fn = lambda out, add, mask: hip.call("vlfb_avgpool_bwd", C.byref(self.desc), hip.ptr(g),
                                                  hip.ptr(out), hip.ptr(add), hip.ptr(mask))
