@@ -86,7 +86,7 @@ int vlfb_affine_nd_bwd(const float* dy, const float* scale, float* dx,
  * ------------------------------------------------------------------------------------------ */
 enum { VLFB_CONV_FPROP = 0, VLFB_CONV_DGRAD = 1, VLFB_CONV_WGRAD = 2 };
 enum { VLFB_BIAS_NONE = 0, VLFB_BIAS_COL = 1, VLFB_BIAS_ROW = 2 };
-enum { VLFB_ALGO_AUTO = 0, VLFB_ALGO_TILE128 = 1, VLFB_ALGO_PIPE256 = 2 };
+enum { VLFB_ALGO_AUTO = 0, VLFB_ALGO_TILE128 = 1, VLFB_ALGO_PIPE256 = 2, VLFB_ALGO_STREAM = 3 };
 
 typedef struct vlfb_conv_desc {
   int32_t mode;
@@ -120,7 +120,9 @@ typedef struct vlfb_conv_desc {
   int32_t splits;     /* WGRAD only: 0 = library chooses */
   int32_t algo;       /* kernel family: 0 = library chooses, 1 = 128x128 tiles (one barrier per k-tile),
                          2 = 256-row phase-pipelined tiles (bf16, MFMA-bound shapes; error if the
-                         problem is not eligible).  Both families give bit-identical results. */
+                         problem is not eligible), 3 = weight-resident streaming kernel (FPROP / DGRAD of
+                         HBM-bound layers whose weight operand fits LDS; error if not eligible).  All
+                         families give bit-identical results. */
 } vlfb_conv_desc;
 
 /* fills the desc with zeros and safe defaults (1x1x1, stride 1, alpha 1, batch 1) */

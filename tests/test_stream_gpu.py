@@ -1,0 +1,145 @@
+"""The weight-resident streaming kernel (csrc/vlfb_gemm_s.hip, conv desc `algo` = VLFB_ALGO_STREAM) against the
+128x128 kernel (algo = VLFB_ALGO_TILE128) and against fp64 torch.
+
+Both families accumulate k in the same order with the same MFMA and apply the same epilogue, so their outputs
+must be BIT-IDENTICAL: one wrong weight row of the permuted LDS image, one wrong tap of the gather or one
+stale prefetched fragment changes bits.  The cases reach every instance of the kernel: 64 / 128 / 256 / 512
+output channels (32- and 16-position blocks, one and two passes over the columns), 1 / 2 / 4 k-tiles per load
+chunk on plain rows, 3 / 4 on gathered taps (temporal, spatial, dilated, strided), FPROP and DGRAD, ragged last
+blocks, every epilogue (bias + residual + ReLU; residual + mask), bf16 and fp16.  Each case runs three times: a
+race or a stale register would show up as run-to-run differences.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import dev, q, rel_err, to_ncthw, to_nthwc, w_to_kernel
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from vlfb import hip
+    hip.lib()
+    return hip
+
+
+def _geom(k, s, p, d):
+    return dict(kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2], dt=d[0], dh=d[1], dw=d[2])
+
+
+ONE, ZERO = (1, 1, 1), (0, 0, 0)
+# name: (N, Cin, Cout, T, H, W, k, stride, pad, dil, dgrad too?)
+CASES = {
+    "ident_64_256": (1, 64, 256, 3, 19, 19, ONE, ONE, ZERO, ONE, True),          # (16,1) uk 1 | dgrad (4,2) uk 4
+    "ident_128_512_two_passes": (1, 128, 512, 2, 21, 21, ONE, ONE, ZERO, ONE, True),   # (16,1) uk 2, 2 passes | dgrad (8,1) uk 4, 2 chunks
+    "ident_192_128": (2, 192, 128, 2, 13, 13, ONE, ONE, ZERO, ONE, False),       # (8,1) uk 1, 3 chunks
+    "ident_128_64": (1, 128, 64, 3, 17, 17, ONE, ONE, ZERO, ONE, True),          # (4,2) uk 2 | dgrad (8,1) uk 1
+    "ident_64_64": (1, 64, 64, 2, 23, 23, ONE, ONE, ZERO, ONE, True),            # (4,2) uk 1
+    "ident_128_128": (1, 128, 128, 2, 18, 18, ONE, ONE, ZERO, ONE, True),        # (8,1) uk 2
+    "ident_256_256": (1, 256, 256, 1, 25, 25, ONE, ONE, ZERO, ONE, True),        # (16,1) uk 4
+    "temporal3_256_64": (1, 256, 64, 5, 15, 15, (3, 1, 1), ONE, (1, 0, 0), ONE, True),    # (4,2) uk 3 gather | dgrad (16,1) uk 3
+    "spatial3_64_64": (2, 64, 64, 2, 23, 23, (1, 3, 3), ONE, (0, 1, 1), ONE, True),       # (4,2) uk 3 gather, 9 taps
+    "temporal3_64_256": (1, 64, 256, 4, 14, 14, (3, 1, 1), ONE, (1, 0, 0), ONE, False),   # (16,1) uk 3 gather
+    "spatial3_dil2_64_128": (1, 64, 128, 2, 20, 20, (1, 3, 3), ONE, (0, 2, 2), (1, 2, 2), True),   # (8,1) uk 3 | dgrad (4,2) uk 3, 18 k-tiles
+    "strided_1tap_256_128": (1, 256, 128, 2, 30, 30, ONE, (1, 2, 2), ZERO, ONE, False),   # (8,1) uk 4 gather
+    "strided_1tap_256_64": (1, 256, 64, 2, 31, 31, ONE, (1, 2, 2), ZERO, ONE, False),     # (4,2) uk 4 gather
+    "strided_3x3_64_128": (1, 64, 128, 2, 29, 29, (1, 3, 3), (1, 2, 2), (0, 1, 1), ONE, False),      # (8,1) uk 3, stride 2
+    "strided_1tap_256_256": (1, 256, 256, 1, 33, 33, ONE, (1, 2, 2), ZERO, ONE, False),   # (16,1) uk 4 gather
+}
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_stream_is_bit_identical_to_tile128_and_matches_fp64(case, tdt):
+    hip = _hip()
+    hdt = hip.BF16 if tdt == torch.bfloat16 else hip.F16
+    tol = 1e-2 if tdt == torch.bfloat16 else 2e-3
+    if tdt == torch.float16 and case not in ("ident_64_256", "spatial3_64_64", "temporal3_256_64", "ident_128_512_two_passes"):
+        pytest.skip("fp16 instances are the same template: a subset is enough")
+    N, Cin, Cout, T, H, W, k, s, p, d, with_dgrad = CASES[case]
+    gen = torch.Generator().manual_seed(sum(map(ord, case)))
+    x = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    w = q(torch.randn(Cout, Cin, *k, generator=gen) / math.sqrt(Cin * k[0] * k[1] * k[2]), tdt)
+    To, Ho, Wo = [(a + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for a, kk, ss, pp, dd in zip((T, H, W), k, s, p, d)]
+    bias = torch.randn(Cout, generator=gen)
+    res = q(torch.randn(N, Cout, To, Ho, Wo, generator=gen), tdt)
+    A = to_nthwc(x).to(dev(), tdt)
+    Bw = w_to_kernel(w).to(dev(), tdt)
+    R = to_nthwc(res).to(dev(), tdt)
+    bg = bias.to(dev())
+    y_ref = torch.relu(F.conv3d(x.double(), w.double(), bias.double(), s, p, d) + res.double())
+    outs = {}
+    for algo in (hip.ALGO_TILE128, hip.ALGO_STREAM):
+        for rep in range(3 if algo == hip.ALGO_STREAM else 1):
+            O = torch.full((N, To, Ho, Wo, Cout), float("nan"), device=dev(), dtype=tdt)
+            desc = hip.conv_desc(mode=hip.FPROP, dtype=hdt, out_dtype=hdt, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
+                                 Ws=W, Cs=Cin, Cn=Cout, relu=1, bias_mode=hip.BIAS_COL, algo=algo, **_geom(k, s, p, d))
+            hip.conv_run(desc, A, Bw, None, O, bias=bg, R=R)
+            O2 = torch.full((N, To, Ho, Wo, Cout), float("nan"), device=dev(), dtype=tdt)     # plain: no epilogue operand, alpha != 1
+            desc = hip.conv_desc(mode=hip.FPROP, dtype=hdt, out_dtype=hdt, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
+                                 Ws=W, Cs=Cin, Cn=Cout, alpha=0.75, algo=algo, **_geom(k, s, p, d))
+            hip.conv_run(desc, A, Bw, None, O2)
+            torch.cuda.synchronize()
+            outs.setdefault(algo, []).append((O.clone(), O2.clone()))
+    ref, ref2 = outs[hip.ALGO_TILE128][0]
+    for O, O2 in outs[hip.ALGO_STREAM]:
+        assert torch.equal(O.view(torch.int16), ref.view(torch.int16)), "fprop: streaming kernel differs from the 128x128 kernel"
+        assert torch.equal(O2.view(torch.int16), ref2.view(torch.int16)), "fprop (alpha, no epilogue operands) differs"
+    assert rel_err(to_ncthw(ref.float()), y_ref) < tol
+    if not with_dgrad:
+        return
+    # ---- dgrad (unit stride) with residual-add + mask epilogue: rows = conv input positions, Cn = Cin ----------------
+    dy = q(torch.randn(N, Cout, To, Ho, Wo, generator=gen), tdt)
+    mask_src = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    add_src = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    G = to_nthwc(dy).to(dev(), tdt)
+    Wd = w.permute(1, 2, 3, 4, 0).contiguous().to(dev(), tdt)
+    Rm, Mm = to_nthwc(add_src).to(dev(), tdt), to_nthwc(mask_src).to(dev(), tdt)
+    got = {}
+    for algo in (hip.ALGO_TILE128, hip.ALGO_STREAM):
+        for rep in range(3 if algo == hip.ALGO_STREAM else 1):
+            DX = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt)
+            desc = hip.conv_desc(mode=hip.DGRAD, dtype=hdt, out_dtype=hdt, N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo,
+                                 Cs=Cout, Cn=Cin, algo=algo, **_geom(k, s, p, d))
+            hip.conv_run(desc, G, Wd, None, DX, R=Rm, mask=Mm)
+            torch.cuda.synchronize()
+            got.setdefault(algo, []).append(DX)
+    for DX in got[hip.ALGO_STREAM]:
+        assert torch.equal(DX.view(torch.int16), got[hip.ALGO_TILE128][0].view(torch.int16)), "dgrad differs"
+    xd = x.double().requires_grad_(True)
+    gx, = torch.autograd.grad(F.conv3d(xd, w.double(), None, s, p, d), xd, dy.double())
+    dx_ref = torch.where(mask_src.double() > 0, gx + add_src.double(), torch.zeros_like(gx))
+    assert rel_err(to_ncthw(got[hip.ALGO_STREAM][0].float()), dx_ref) < tol
+
+
+def test_stream_is_what_the_library_picks_for_a_res2_sized_layer():
+    """AUTO must route a many-position, small-weight layer (64 -> 256, 1x1x1, 8 x 16 x 56 x 56 = 401 k positions) to
+    the streaming kernel -- visible as bit-identity with TILE128 plus the launch not failing -- and must keep
+    rejecting what the kernel cannot run when it is asked for explicitly"""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(7)
+    M, Cin, Cout = 8 * 16 * 56 * 56, 64, 256
+    A = q(torch.randn(M, Cin, generator=gen), torch.bfloat16).to(dev(), torch.bfloat16)
+    Bw = q(torch.randn(Cout, Cin, generator=gen) / 8, torch.bfloat16).to(dev(), torch.bfloat16)
+    R = q(torch.randn(M, Cout, generator=gen), torch.bfloat16).to(dev(), torch.bfloat16)
+    outs = []
+    for algo in (hip.ALGO_TILE128, hip.ALGO_AUTO, hip.ALGO_STREAM):
+        O = torch.full((M, Cout), float("nan"), device=dev(), dtype=torch.bfloat16)
+        desc = hip.conv_desc(mode=hip.FPROP, dtype=hip.BF16, out_dtype=hip.BF16, N=1, Tr=1, Hr=1, Wr=M, Ts=1, Hs=1, Ws=M,
+                             Cs=Cin, Cn=Cout, relu=1, algo=algo)
+        hip.conv_run(desc, A, Bw, None, O, R=R)
+        torch.cuda.synchronize()
+        outs.append(O)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    ref = torch.relu(A.double().cpu() @ Bw.double().cpu().t() + R.double().cpu())
+    assert rel_err(outs[2].float(), ref) < 1e-2
+    t = torch.zeros(4096 * 2048, device=dev(), dtype=torch.bfloat16)
+    for bad in (dict(Cs=1024, Cn=256), dict(Cs=64, Cn=96), dict(Cs=96, Cn=64)):        # weights too large / odd widths
+        d = hip.conv_desc(mode=hip.FPROP, dtype=hip.BF16, out_dtype=hip.BF16, N=1, Tr=1, Hr=1, Wr=2048, Ts=1, Hs=1, Ws=2048,
+                          algo=hip.ALGO_STREAM, **bad)
+        with pytest.raises(hip.VlfbError):
+            hip.conv_run(d, t, t, None, t)

@@ -32,15 +32,15 @@ inline int check_launch(const char* what) {
 
 // ---- scalar conversions -------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-nearest-even
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-nearest-even, by the gfx950 converter (v_cvt_pk_bf16_f32: one instruction per PAIR; NaNs come
+// out quiet).  Finite values and infinities round exactly like the integer recipe u += 0x7fff + ((u >> 16) & 1).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // round-nearest-even
 

@@ -1016,6 +1016,8 @@ struct Plan {
   int nt8;        // NT: 256-row phase-pipelined kernel with this tile width (256 / 128), 0 = 128x128 kernel
   int nt8_bm;     //     rows per tile: 256 or 196
   int nt8_mode;   //     0 plain rows, 1 gathered FPROP, 2 gathered unit-stride DGRAD
+  int nts;        // NT: weight-resident streaming kernel (vlfb_gemm_s.hip); nts_mode as nt8_mode
+  int nts_mode;
   size_t stem_lds;
   dim3 grid;
   size_t lds;
@@ -1212,6 +1214,33 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       g.tiles_m = (int)((M + pl->nt8_bm - 1) / pl->nt8_bm);
     }
   }
+  pl->nts = 0;
+  pl->nts_mode = 0;
+  if (d->mode != VLFB_CONV_WGRAD && d->algo != VLFB_ALGO_TILE128 && d->algo != VLFB_ALGO_PIPE256) {
+    // weight-resident streaming kernel (vlfb_gemm_s.hip): the whole weight operand (<= ~150 KiB) lives in LDS,
+    // every wave streams its own 16 / 32-position blocks without workgroup barriers -- for the HBM-bound layers
+    const int mode = pl->ident ? 0 : (d->mode == VLFB_CONV_FPROP ? 1 : 2);
+    const bool gather_ok = pl->ident || (!d->pack_w && taps <= 32 &&
+                                         (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
+    const int uk = nts_chunk(mode, K);
+    const int ncp = d->Cn >= 256 ? 256 : d->Cn;                       // channels per pass
+    const bool shape_ok = (d->Cn == 64 || d->Cn == 128 || d->Cn == 256 || d->Cn == 512) && d->Cs % 64 == 0 && uk > 0 &&
+                          (d->Cn / ncp == 1 || K / 64 / (uk ? uk : 1) == 1);
+    const bool ok = is16(d->dtype) && d->out_dtype == d->dtype && batch == 1 && shape_ok && gather_ok &&
+                    g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldo % 8 == 0 && g.ldr % 8 == 0 &&
+                    (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
+                    (long long)d->Cn * K * 2 + d->Cn * 4 <= 156 * 1024 &&
+                    M * g.ldo * 2 < (1ll << 31) && M * g.ldr * 2 < (1ll << 31);
+    if (d->algo == VLFB_ALGO_STREAM)
+      VLFB_REQUIRE(ok, "conv: algo = STREAM needs bf16 / f16 in and out, batch 1, Cn in {64, 128, 256, 512}, Cs %% 64 == 0, a weight "
+                       "operand of at most 156 KiB (one k chunk if Cn = 512), 16-byte aligned rows and operands below 2 GiB");
+    // Library choice (measured at the 8-clip shapes, scratch/nts_probe.cpp and bench.py --detail): the 256-column
+    // layers of res2 (0.8 M positions: 2c / shortcut fprop 1.04-1.08x alone, the 3x1x1 dgrad with residual + mask
+    // 1.19x alone and 1.4x under the concurrent wgrad stream).  The 64-column variants are VALU-bound by the
+    // per-block row decode and lose to the tiled kernel, res3 (0.1 M positions) has 3 blocks per wave.
+    const bool want = d->algo == VLFB_ALGO_STREAM || (ok && M >= 400000 && d->Cn == 256);
+    if (ok && want) { pl->nts = 1; pl->nts_mode = mode; pl->nt8 = 0; }
+  }
   pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
   pl->pre = 0;
   pl->threads = kThreads;
@@ -1321,6 +1350,7 @@ int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
       else launch_tn_tr<T, OutT, false, false>(pl, s);
       return check_launch("conv wgrad (tr) kernel");
     }
+    if (d->mode != VLFB_CONV_WGRAD && pl.nts) return launch_nts(pl.gp, pl.nts_mode, d->dtype, s);
     if (d->mode != VLFB_CONV_WGRAD && pl.nt8)
       return launch_nt8(pl.gp, pl.nt8_bm, pl.nt8, pl.nt8_mode, d->dtype, sizeof(OutT) == 4,
                         (unsigned)(d->batch > 0 ? d->batch : 1), s);

@@ -43,6 +43,11 @@ int launch_nt8(const GP& gp, int bm, int bn, int mode, int dtype, bool out_f32, 
 // 256 x 256 phase-pipelined TN kernel (plain rows: wgrad of 1x1x1 convs, attention products); grid as planned
 int launch_tn8(const GP& gp, dim3 grid, int dtype, bool out_f32, hipStream_t s);
 
+// vlfb_gemm_s.hip: weight-resident streaming NT kernel (bf16 / f16 in and out, batch 1).  mode as launch_nt8;
+// nts_chunk = k-tiles per load chunk the kernel would use for this K (0: K not supported)
+int nts_chunk(int mode, long long K);
+int launch_nts(const GP& gp, int mode, int dtype, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;

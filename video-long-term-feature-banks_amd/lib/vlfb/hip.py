@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16 = 0, 1, 2
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
-ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256 = 0, 1, 2
+ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256, ALGO_STREAM = 0, 1, 2, 3
 ATTN_CAN_RUN, ATTN_FWD_FASTER, ATTN_BWD_FASTER = 1, 2, 4     # vlfb_attn_scores_supported flags
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
