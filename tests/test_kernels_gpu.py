@@ -276,6 +276,8 @@ POOLS = {
     "pool1": ((1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 11, 11)),   # resnet_video.py:190-196
     "pool2": ((2, 1, 1), (2, 1, 1), (0, 0, 0), (2, 4, 5, 5)),     # resnet_video.py:219-225
     "nlpool": ((1, 2, 2), (1, 2, 2), (0, 0, 0), (2, 2, 6, 6)),    # nonlocal_helper.py:48-54
+    "other_window": ((1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 7, 7)),   # not a compiled window shape: the generic backward kernel
+    "pool1_ragged": ((1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 2, 14, 10)),  # even extents: the last window column / row is cut
 }
 
 

@@ -1223,17 +1223,15 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     const bool gather_ok = pl->ident || (!d->pack_w && taps <= 32 &&
                                          (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
     const int uk = nts_chunk(mode, K);
-    const int ncp = d->Cn >= 256 ? 256 : d->Cn;                       // channels per pass
-    const bool shape_ok = (d->Cn == 64 || d->Cn == 128 || d->Cn == 256 || d->Cn == 512) && d->Cs % 64 == 0 && uk > 0 &&
-                          (d->Cn / ncp == 1 || K / 64 / (uk ? uk : 1) == 1);
+    const bool shape_ok = (d->Cn == 64 || d->Cn == 128 || d->Cn == 256) && d->Cs % 64 == 0 && uk > 0 && M < (1ll << 24);
     const bool ok = is16(d->dtype) && d->out_dtype == d->dtype && batch == 1 && shape_ok && gather_ok &&
                     g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldo % 8 == 0 && g.ldr % 8 == 0 &&
                     (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
                     (long long)d->Cn * K * 2 + d->Cn * 4 <= 156 * 1024 &&
                     M * g.ldo * 2 < (1ll << 31) && M * g.ldr * 2 < (1ll << 31);
     if (d->algo == VLFB_ALGO_STREAM)
-      VLFB_REQUIRE(ok, "conv: algo = STREAM needs bf16 / f16 in and out, batch 1, Cn in {64, 128, 256, 512}, Cs %% 64 == 0, a weight "
-                       "operand of at most 156 KiB (one k chunk if Cn = 512), 16-byte aligned rows and operands below 2 GiB");
+      VLFB_REQUIRE(ok, "conv: algo = STREAM needs bf16 / f16 in and out, batch 1, Cn in {64, 128, 256}, Cs %% 64 == 0, a weight "
+                       "operand of at most 156 KiB, fewer than 2^24 rows, 16-byte aligned rows and operands below 2 GiB");
     // Library choice (measured at the 8-clip shapes, scratch/nts_probe.cpp and bench.py --detail): the 256-column
     // layers of res2 (0.8 M positions: 2c / shortcut fprop 1.04-1.08x alone, the 3x1x1 dgrad with residual + mask
     // 1.19x alone and 1.4x under the concurrent wgrad stream).  The 64-column variants are VALU-bound by the

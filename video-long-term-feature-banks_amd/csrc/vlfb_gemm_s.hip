@@ -36,15 +36,14 @@ __device__ __forceinline__ void bufst16(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)voff, 0, 0);
 }
 
-// NF: 16-channel fragments per pass over the columns (a pass covers NF * 16 output channels);
+// NF: 16-channel fragments (NF * 16 = output channels: 64, 128 or 256);
 // MF: 16-position fragments per row block; UK: k-tiles (64 k) per load chunk; GATHER: conv taps (FPROP of
-// any stride, unit-stride DGRAD) instead of plain rows.
-template <typename T, int NF, int MF, int UK, bool GATHER>
-__global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgrad, const int lgN) {
+// any stride, unit-stride DGRAD) instead of plain rows; NW: waves per workgroup (8, or 16 where 128 VGPRs are enough).
+template <typename T, int NF, int MF, int UK, bool GATHER, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nts_kernel(const GP p, const int dgrad, const int lgN) {
   typedef typename V16<T>::V vec_t;
   constexpr int RB = 16 * MF;                    // positions per block
-  constexpr int NC = NF * 16;                    // channels per pass
-  constexpr int NQ = NF / 2;                     // 8-channel groups per lane and pass
+  constexpr int NQ = NF / 2;                     // 8-channel groups per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,13 +52,12 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
   const int N = p.Ncols;
   const int nkt = p.K >> 6;
   const int nchunk = nkt / UK;
-  const int npass = N / NC;
 
   // ---- the weight operand -> LDS, once per workgroup: [k-tile][permuted channel][128 B, chunk ^ (row & 7)] ----
   {
     const auto rsB = make_rsrc(p.B, p.b_bytes);
     const int total = nkt << (lgN + 3);          // 16-byte pieces
-    for (int base = wave * 64; base < total; base += 512) {
+    for (int base = wave * 64; base < total; base += NW * 64) {
       const int piece = base + lane;
       const int s = piece & 7, r = (piece >> 3) & (N - 1), kt = piece >> (lgN + 3);
       const int c = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
@@ -84,13 +82,25 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
   const int nblk = (p.M + RB - 1) / RB;
   const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3, nwx = gridDim.x >> 3;
   const int S = (nblk + 7) >> 3;
-  const int stride = nwx * 8;
+  const int stride = nwx * NW;
   const int blk0 = xcd * S;
-  int li = wx * 8 + wave;
+  int li = wx * NW + wave;
 
-  struct Rows { unsigned aoff[MF]; unsigned amask[MF]; };
-  struct Cur { int a, b, c, tap, ci; };
+  // per block row: byte offset of its first tap (wraps for padding rows) and, per filter dimension, one validity
+  // bit per tap index (a tap exists iff its three bits are set) -- kt + kh + kw compares per row, not kt * kh * kw
+  struct Rows { unsigned aoff[MF]; unsigned vt[MF], vh[MF], vw[MF]; };
+  struct Cur { int a, b, c, ci; };
   const int sgn = dgrad ? -1 : 1;
+  // row -> (n, t, h, w) by reciprocal multiplication (exact below 2^24 rows after the +-1 fix-up)
+  const int hw = p.Hr * p.Wr, thw = p.Tr * hw;
+  const float inv_thw = 1.0f / (float)thw, inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.Wr;
+  auto divmod = [](int x, int d, float inv, int& rem) {
+    int q = (int)((float)x * inv);
+    rem = x - q * d;
+    if (rem < 0) { --q; rem += d; }
+    else if (rem >= d) { ++q; rem -= d; }
+    return q;
+  };
 
   auto decode = [&](int blk, bool live, Rows& rw) {
 #pragma unroll
@@ -99,24 +109,27 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
       const bool ok = live && m < p.M;
       if (!GATHER) {
         rw.aoff[f] = ok ? (unsigned)(m * p.lda + g * 8) * 2u : kOOB;
-        rw.amask[f] = ok ? 1u : 0u;
+        rw.vt[f] = ok ? 1u : 0u;
+        rw.vh[f] = rw.vw[f] = 1u;
       } else {
-        RowC r = decode_row(p, ok ? m : 0);
-        if (!dgrad) { r.t = r.t * p.st - p.pt; r.h = r.h * p.sh - p.ph; r.w = r.w * p.sw - p.pw; }
-        else { r.t += p.pt; r.h += p.ph; r.w += p.pw; }
-        const int pix = ((r.n * p.Ts + r.t) * p.Hs + r.h) * p.Ws + r.w;
-        rw.aoff[f] = (unsigned)(pix * p.lda + g * 8) * 2u;          // wraps for padding rows (masked below)
-        unsigned mk = 0;
-        int tap = 0;
-        for (int a = 0; a < p.kt; ++a)
-          for (int b = 0; b < p.kh; ++b)
-            for (int c = 0; c < p.kw; ++c, ++tap) {
-              const bool v = (unsigned)(r.t + sgn * a * p.dt) < (unsigned)p.Ts &&
-                             (unsigned)(r.h + sgn * b * p.dh) < (unsigned)p.Hs &&
-                             (unsigned)(r.w + sgn * c * p.dw) < (unsigned)p.Ws;
-              mk |= (v ? 1u : 0u) << tap;
-            }
-        rw.amask[f] = ok ? mk : 0u;
+        int rem, rem2, w;
+        const int n = divmod(ok ? m : 0, thw, inv_thw, rem);
+        int t = divmod(rem, hw, inv_hw, rem2);
+        int h = divmod(rem2, p.Wr, inv_w, w);
+        if (!dgrad) { t = t * p.st - p.pt; h = h * p.sh - p.ph; w = w * p.sw - p.pw; }
+        else { t += p.pt; h += p.ph; w += p.pw; }
+        const int pix = ((n * p.Ts + t) * p.Hs + h) * p.Ws + w;
+        rw.aoff[f] = (unsigned)(pix * p.lda + g * 8) * 2u;          // wraps for padding rows (masked by the bits)
+        unsigned bt = 0, bh = 0, bw = 0;
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int a = 0; a < p.kt; ++a) bt |= ((unsigned)(t + sgn * a * p.dt) < (unsigned)p.Ts ? 1u : 0u) << a;
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int b = 0; b < p.kh; ++b) bh |= ((unsigned)(h + sgn * b * p.dh) < (unsigned)p.Hs ? 1u : 0u) << b;
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int c = 0; c < p.kw; ++c) bw |= ((unsigned)(w + sgn * c * p.dw) < (unsigned)p.Ws ? 1u : 0u) << c;
+        rw.vt[f] = ok ? bt : 0u;
+        rw.vh[f] = bh;
+        rw.vw[f] = bw;
       }
     }
   };
@@ -132,16 +145,24 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
       }
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
-        const bool ok = (rw.amask[f] >> (GATHER ? cu.tap : 0)) & 1u;
+        const bool ok = GATHER ? (((rw.vt[f] >> cu.a) & (rw.vh[f] >> cu.b) & (rw.vw[f] >> cu.c)) & 1u) != 0u : rw.vt[f] != 0u;
         const unsigned voff = ok ? rw.aoff[f] + dbyte : kOOB;
         dst[f][u][0] = __builtin_bit_cast(vec_t, bufld16(rsA, voff));
         dst[f][u][1] = __builtin_bit_cast(vec_t, bufld16(rsA, voff + 64u));
       }
-      cu.ci += 128;
-      if (GATHER && cu.ci >= p.Cs * 2) {
-        cu.ci = 0;
-        ++cu.tap;
-        if (++cu.c == p.kw) { cu.c = 0; if (++cu.b == p.kh) { cu.b = 0; ++cu.a; } }
+      // cursor advance by selects (a branch between the loads would make the compiler's wait counts pessimistic)
+      if (GATHER) {
+        const bool wc = cu.ci + 128 >= p.Cs * 2;
+        cu.ci = wc ? 0 : cu.ci + 128;
+        const int c1 = cu.c + (wc ? 1 : 0);
+        const bool wb = c1 == p.kw;
+        cu.c = wb ? 0 : c1;
+        const int b1 = cu.b + (wb ? 1 : 0);
+        const bool wa = b1 == p.kh;
+        cu.b = wa ? 0 : b1;
+        cu.a += wa ? 1 : 0;
+      } else {
+        cu.ci += 128;
       }
     }
   };
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
   const int ktile_bytes = N << 7;
 
   Rows rw_cur, rw_nxt;
-  Cur cu = {0, 0, 0, 0, 0};
+  Cur cu = {0, 0, 0, 0};
   vec_t cur[MF][UK][2], nxt[MF][UK][2];
   bool live = li < S && blk0 + li < nblk;
   decode(blk0 + li, live, rw_cur);
@@ -163,15 +184,15 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
     const int nli = li + stride;
     const bool nlive = nli < S && blk0 + nli < nblk;
     decode(blk0 + nli, nlive, rw_nxt);
-    for (int pass = 0; pass < npass; ++pass) {
-      // residual / mask rows of this block and pass: requested now, used after the MFMAs
+    {
+      // residual / mask rows of this block: requested now, used after the MFMAs
       // (always issued: an absent operand is read at the out-of-range offset, which returns zeros without a
       // memory access -- no branches around loads, so the compiler can count what is in flight)
       u32x4_v rreg[MF][NQ], mreg[MF][NQ];
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
         const int m = blk * RB + f * 16 + l15;
-        const unsigned ro = m < p.M ? (unsigned)(m * p.ldr + pass * NC + g * 8) * 2u : kOOB;
+        const unsigned ro = m < p.M ? (unsigned)(m * p.ldr + g * 8) * 2u : kOOB;
         const unsigned ror = hasR ? ro : kOOB, rom = hasM ? ro : kOOB;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rreg[f][q] = bufld16(rsR, ror + q * 64u);
@@ -183,22 +204,22 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
       for (int f = 0; f < MF; ++f)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[f][j] = f32x4_v{0.f, 0.f, 0.f, 0.f};
-      const char* wrow = smem + ((pass * NC + l15) << 7);
+      const char* wrow = smem + ((l15) << 7);
       for (int ch = 0; ch < nchunk; ++ch) {
         // The next chunk of this wave's stream goes in flight first: the next k-tiles of this block, or the
         // first ones of the wave's next block.  ONE load site, no branch around it (a second, conditional site
-        // makes the compiler drain the queue before re-using the registers): on the earlier passes of a
-        // two-pass layer (Cn = 512, one chunk) the loads are issued out of range -- zeros, no memory access.
+        // makes the compiler drain the queue before re-using the registers).
         {
           const bool same = ch + 1 < nchunk;
-          const bool real = pass == npass - 1;
           Rows sel;
 #pragma unroll
           for (int f = 0; f < MF; ++f) {
             sel.aoff[f] = same ? rw_cur.aoff[f] : rw_nxt.aoff[f];
-            sel.amask[f] = real ? (same ? rw_cur.amask[f] : rw_nxt.amask[f]) : 0u;
+            sel.vt[f] = same ? rw_cur.vt[f] : rw_nxt.vt[f];
+            sel.vh[f] = same ? rw_cur.vh[f] : rw_nxt.vh[f];
+            sel.vw[f] = same ? rw_cur.vw[f] : rw_nxt.vw[f];
           }
-          if (!same) cu = Cur{0, 0, 0, 0, 0};
+          if (!same) cu = Cur{0, 0, 0, 0};
           load_chunk(nxt, sel, cu);
         }
         // weight fragments: groups of four ds_read_b128, the next group requested before the MFMAs of this one
@@ -222,18 +243,16 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
 #pragma unroll
             for (int f = 0; f < MF; ++f) acc[f][jg * 4 + j] = V16<T>::mma(bq[gi & 1][j], cur[f][u][ks], acc[f][jg * 4 + j]);
         }
-        if (pass == npass - 1) {
 #pragma unroll
-          for (int f = 0; f < MF; ++f)
+        for (int f = 0; f < MF; ++f)
 #pragma unroll
-            for (int u = 0; u < UK; ++u) { cur[f][u][0] = nxt[f][u][0]; cur[f][u][1] = nxt[f][u][1]; }
-        }
+          for (int u = 0; u < UK; ++u) { cur[f][u][0] = nxt[f][u][0]; cur[f][u][1] = nxt[f][u][1]; }
       }
-      // ---- epilogue in registers: lane = position l15, channels pass*NC + q*32 + g*8 .. +7 ----------------
+      // ---- epilogue in registers: lane = position l15, channels q*32 + g*8 .. +7 -----------------------
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
         const int m = blk * RB + f * 16 + l15;
-        const unsigned oo = m < p.M ? (unsigned)(m * p.ldo + pass * NC + g * 8) * 2u : kOOB;
+        const unsigned oo = m < p.M ? (unsigned)(m * p.ldo + g * 8) * 2u : kOOB;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           float v[8];
@@ -242,8 +261,8 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e * 4 + r] = __fmul_rn(acc[f][2 * q + e][r], p.alpha);
           if (p.bias_mode == VLFB_BIAS_COL) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + ((pass * NC + q * 32 + g * 8) << 2));
-            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + ((pass * NC + q * 32 + g * 8 + 4) << 2));
+            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + ((q * 32 + g * 8) << 2));
+            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + ((q * 32 + g * 8 + 4) << 2));
             v[0] = __fadd_rn(v[0], b0.x); v[1] = __fadd_rn(v[1], b0.y); v[2] = __fadd_rn(v[2], b0.z); v[3] = __fadd_rn(v[3], b0.w);
             v[4] = __fadd_rn(v[4], b1.x); v[5] = __fadd_rn(v[5], b1.y); v[6] = __fadd_rn(v[6], b1.z); v[7] = __fadd_rn(v[7], b1.w);
           }
@@ -279,34 +298,34 @@ __global__ __launch_bounds__(512) void gemm_nts_kernel(const GP p, const int dgr
 }
 
 template <typename K>
-int launch_s(K kernel, const GP& gp, int dgrad, int lgN, unsigned nwg, size_t lds, hipStream_t s) {
+int launch_s(K kernel, const GP& gp, int dgrad, int lgN, unsigned nwg, int nw, size_t lds, hipStream_t s) {
   static bool configured = false;   // per template instance
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     configured = true;
   }
-  hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), lds, s, gp, dgrad, lgN);
+  hipLaunchKernelGGL(kernel, dim3(nwg), dim3(nw * 64), lds, s, gp, dgrad, lgN);
   return check_launch("conv kernel (weight-resident streaming)");
 }
 
-template <typename T, int NF, int MF>
+template <typename T, int NF, int MF, int NW>
 int launch_nts_shape(const GP& gp, int mode, int uk, int lgN, unsigned nwg, size_t lds, hipStream_t s) {
   const int dgrad = mode == 2;
   if (mode == 0) {
-    if (uk == 1) return launch_s(gemm_nts_kernel<T, NF, MF, 1, false>, gp, 0, lgN, nwg, lds, s);
-    if (uk == 2) return launch_s(gemm_nts_kernel<T, NF, MF, 2, false>, gp, 0, lgN, nwg, lds, s);
-    return launch_s(gemm_nts_kernel<T, NF, MF, 4, false>, gp, 0, lgN, nwg, lds, s);
+    if (uk == 1) return launch_s(gemm_nts_kernel<T, NF, MF, 1, false, NW>, gp, 0, lgN, nwg, NW, lds, s);
+    if (uk == 2) return launch_s(gemm_nts_kernel<T, NF, MF, 2, false, NW>, gp, 0, lgN, nwg, NW, lds, s);
+    return launch_s(gemm_nts_kernel<T, NF, MF, 4, false, NW>, gp, 0, lgN, nwg, NW, lds, s);
   }
-  if (uk == 3) return launch_s(gemm_nts_kernel<T, NF, MF, 3, true>, gp, dgrad, lgN, nwg, lds, s);
-  return launch_s(gemm_nts_kernel<T, NF, MF, 4, true>, gp, dgrad, lgN, nwg, lds, s);
+  if (uk == 3) return launch_s(gemm_nts_kernel<T, NF, MF, 3, true, NW>, gp, dgrad, lgN, nwg, NW, lds, s);
+  return launch_s(gemm_nts_kernel<T, NF, MF, 4, true, NW>, gp, dgrad, lgN, nwg, NW, lds, s);
 }
 
 template <typename T>
 int launch_nts_t(const GP& gp, int mode, int uk, int lgN, unsigned nwg, size_t lds, hipStream_t s) {
-  if (gp.Ncols == 64) return launch_nts_shape<T, 4, 2>(gp, mode, uk, lgN, nwg, lds, s);
-  if (gp.Ncols == 128) return launch_nts_shape<T, 8, 1>(gp, mode, uk, lgN, nwg, lds, s);
-  return launch_nts_shape<T, 16, 1>(gp, mode, uk, lgN, nwg, lds, s);
+  if (gp.Ncols == 64) return launch_nts_shape<T, 4, 1, 16>(gp, mode, uk, lgN, nwg, lds, s);
+  if (gp.Ncols == 128) return launch_nts_shape<T, 8, 1, 8>(gp, mode, uk, lgN, nwg, lds, s);
+  return launch_nts_shape<T, 16, 1, 8>(gp, mode, uk, lgN, nwg, lds, s);
 }
 
 }  // namespace
@@ -329,9 +348,9 @@ int launch_nts(const GP& gp, int mode, int dtype, hipStream_t s) {
   const int uk = nts_chunk(mode, gp.K);
   int lgN = 0;
   while ((1 << lgN) < gp.Ncols) ++lgN;
-  const int rb = gp.Ncols == 64 ? 32 : 16;
+  const int rb = 16, nw = gp.Ncols == 64 ? 16 : 8;
   const long long nblk = ((long long)gp.M + rb - 1) / rb;
-  long long nwg = (nblk + 7) / 8;                       // a workgroup's eight waves want a block each
+  long long nwg = (nblk + nw - 1) / nw;                 // every wave of a workgroup wants a block
   nwg = (nwg + 7) / 8 * 8;
   if (nwg > ncu) nwg = ncu;
   const size_t lds = (size_t)gp.Ncols * gp.K * 2 + (size_t)gp.Ncols * 4;

@@ -337,6 +337,150 @@ __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict
   }
 }
 
+// Max-pool backward for the window shapes the models use (pool1 1x3x3 / 1x2x2, pool2 2x1x1 / 2x1x1, the non-local
+// 1x2x2 / 1x2x2 pools), with the window geometry as compile-time constants: the generic kernel above spends its time
+// in 64-bit index divisions and data-dependent window loops (pool1 of the 8-clip step: 532 us for 0.57 GB of
+// traffic).  One workgroup per input row (n, t, h): the row decode is scalar, the candidate windows of a position
+// are at most ceil(k / s) per dimension and unroll completely, and the accumulation order (windows ascending in
+// t, h, w) is the one of the generic kernel, so both give identical bits.
+// 16 bytes of T as floats
+template <typename T>
+__device__ __forceinline__ void unpack_vec(const uint4& t, float (&v)[Vec16<T>::N]) {
+  if (sizeof(T) == 4) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2 % Vec16<T>::N] = __uint_as_float(t.z); v[3 % Vec16<T>::N] = __uint_as_float(t.w);
+  } else {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[(2 * i) % Vec16<T>::N] = Elem<T>::lo(w[i]);
+      v[(2 * i + 1) % Vec16<T>::N] = Elem<T>::hi(w[i]);
+    }
+  }
+}
+
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, bool YMASK>
+__global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                                T* dx, const T* add, const T* __restrict__ mask, PoolP p,
+                                                                const T* __restrict__ ymask) {
+  constexpr int V = Vec16<T>::N;
+  constexpr int CT = (KT + ST - 1) / ST, CH = (KH + SH - 1) / SH, CW = (KW + SW - 1) / SW;
+  const int cchunks = p.C / V;
+  const int row = blockIdx.x;                       // (n * Ti + ti) * Hi + hi
+  const int hi = row % p.Hi;
+  const int r2 = row / p.Hi;
+  const int ti = r2 % p.Ti;
+  const int n = r2 / p.Ti;
+  const int items = p.Wi * cchunks;
+  const int to_hi = (ti + p.pt) / ST, ho_hi = (hi + p.ph) / SH;
+  for (int it = threadIdx.x; it < items; it += 128) {
+    // item -> (w, channel chunk), w running through one residue class mod SW after the other
+    const int wj = it / cchunks, cc = it - wj * cchunks;
+    int wi = wj;
+    if (SW > 1) {
+      // classes 0 .. SW-1 hold ceil / floor (Wi / SW) positions; walk them in order
+      int cls = 0, base = 0;
+#pragma unroll
+      for (int q = 0; q < SW - 1; ++q) {
+        const int cnt = (p.Wi - q + SW - 1) / SW;
+        if (wj >= base + cnt) { base += cnt; cls = q + 1; }
+      }
+      wi = (wj - base) * SW + cls;
+    }
+    const int wo_hi = (wi + p.pw) / SW;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    // Candidate windows in t and h are workgroup-uniform: those that do not exist are skipped by scalar branches.
+    // The w candidates of a position are all loaded, unconditionally and before any of them is used (a window that
+    // does not exist reads window 0 and is compared against a tap no arg-max holds): the loads of a position are
+    // in flight together instead of one round trip after the other.
+#pragma unroll
+    for (int jt = CT - 1; jt >= 0; --jt) {
+      const int to = to_hi - jt, a = ti + p.pt - to * ST;
+      if (to < 0 || to >= p.To || a >= KT) continue;
+#pragma unroll
+      for (int jh = CH - 1; jh >= 0; --jh) {
+        const int ho = ho_hi - jh, b = hi + p.ph - ho * SH;
+        if (ho < 0 || ho >= p.Ho || b >= KH) continue;
+        const int orow = ((n * p.To + to) * p.Ho + ho) * p.Wo;
+        uint4 gq[CW], yq[CW];
+        uint2 aq[CW];
+        int tapq[CW];
+#pragma unroll
+        for (int jw = 0; jw < CW; ++jw) {
+          const int wo = wo_hi - (CW - 1 - jw), c = wi + p.pw - wo * SW;
+          const bool ok = wo >= 0 && wo < p.Wo && c < KW;
+          const long long o = ok ? (long long)(orow + wo) * p.C + cc * V : (long long)(cc * V);
+          tapq[jw] = ok ? (a * KH + b) * KW + c : 255;
+          if (sizeof(T) == 2) {
+            gq[jw] = *reinterpret_cast<const uint4*>(dy + o);
+            if (YMASK) yq[jw] = *reinterpret_cast<const uint4*>(ymask + o);
+            aq[jw] = *reinterpret_cast<const uint2*>(argmax + o);
+          } else {
+            gq[jw] = *reinterpret_cast<const uint4*>(dy + o);
+            if (YMASK) yq[jw] = *reinterpret_cast<const uint4*>(ymask + o);
+            aq[jw] = make_uint2(*reinterpret_cast<const uint32_t*>(argmax + o), 0u);
+          }
+        }
+#pragma unroll
+        for (int jw = 0; jw < CW; ++jw) {
+          float g[V];
+          unpack_vec<T>(gq[jw], g);
+          if (YMASK) {
+            float yv[V];
+            unpack_vec<T>(yq[jw], yv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            const int sel = (int)(((k < 4 ? aq[jw].x : aq[jw].y) >> (8 * (k & 3))) & 0xff);
+            acc[k] += sel == tapq[jw] ? g[k] : 0.f;
+          }
+        }
+      }
+    }
+    const long long off = ((long long)row * p.Wi + wi) * p.C + cc * V;
+    if (add) {
+      float a2[V];
+      Vec16<T>::load(add + off, a2);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += a2[k];
+    }
+    if (mask) {
+      float mk[V];
+      Vec16<T>::load(mask + off, mk);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] = mk[k] > 0.f ? acc[k] : 0.f;
+    }
+    Vec16<T>::store(dx + off, acc);
+  }
+}
+
+// launches the fixed-shape kernel when the window is one of the compiled shapes (one-byte arg-max); false = use the generic one
+template <typename T>
+bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax, void* dx, const void* add, const void* mask,
+                              const void* ymask, hipStream_t s) {
+  const long long rows = (long long)p.N * p.Ti * p.Hi;
+  if (rows >= (1ll << 31) || (long long)p.N * p.To * p.Ho * p.Wo >= (1ll << 31)) return false;
+  const dim3 grid((unsigned)rows), block(128);
+#define VLFB_POOL_FIXED(KT_, KH_, KW_, ST_, SH_, SW_)                                                                      \
+  if (p.kt == KT_ && p.kh == KH_ && p.kw == KW_ && p.st == ST_ && p.sh == SH_ && p.sw == SW_) {                           \
+    if (ymask)                                                                                                           \
+      hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, true>), grid, block, 0, s,           \
+                         (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p, (const T*)ymask); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, false>), grid, block, 0, s,          \
+                         (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p, (const T*)ymask); \
+    return true;                                                                                                         \
+  }
+  VLFB_POOL_FIXED(1, 3, 3, 1, 2, 2)
+  VLFB_POOL_FIXED(2, 1, 1, 2, 1, 1)
+  VLFB_POOL_FIXED(1, 2, 2, 1, 2, 2)
+#undef VLFB_POOL_FIXED
+  return false;
+}
+
 template <typename T>
 __global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolP p) {
   constexpr int V = Vec16<T>::N;
@@ -811,6 +955,12 @@ extern "C" int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const v
   const bool wide = vlfb_pool_argmax_bytes(d) == 2;
   int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
   hipStream_t s = (hipStream_t)stream;
+  if (!wide) {
+    bool done;
+    if (d->dtype == VLFB_F32) done = launch_maxpool_bwd_fixed<float>(p, dy, argmax, dx, add, mask, nullptr, s);
+    else VLFB_WITH_T16(d->dtype, done = launch_maxpool_bwd_fixed<T16>(p, dy, argmax, dx, add, mask, nullptr, s));
+    if (done) return check_launch("maxpool_bwd (fixed window)");
+  }
   if (d->dtype == VLFB_F32 && !wide)
     hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint8_t*)argmax, (float*)dx, (const float*)add, (const float*)mask, p, 1.f);
   else if (d->dtype == VLFB_F32)
@@ -831,6 +981,12 @@ extern "C" int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, co
   const bool wide = vlfb_pool_argmax_bytes(d) == 2;
   int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / v), 256);
   hipStream_t s = (hipStream_t)stream;
+  if (!wide) {
+    bool done;
+    if (d->dtype == VLFB_F32) done = launch_maxpool_bwd_fixed<float>(p, dy, argmax, dx, nullptr, nullptr, y, s);
+    else VLFB_WITH_T16(d->dtype, done = launch_maxpool_bwd_fixed<T16>(p, dy, argmax, dx, nullptr, nullptr, y, s));
+    if (done) return check_launch("maxpool_relu_bwd (fixed window)");
+  }
   if (d->dtype == VLFB_F32 && !wide)
     hipLaunchKernelGGL((pool_bwd_kernel<float, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const float*)dy, (const uint8_t*)argmax, (float*)dx, (const float*)nullptr, (const float*)nullptr, p, 1.f, (const float*)y);
   else if (d->dtype == VLFB_F32)
