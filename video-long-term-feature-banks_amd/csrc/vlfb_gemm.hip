@@ -1203,14 +1203,17 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
                       (ok && ((d->Cn == 512 && K >= 1024) ||
                               (batch > 1 && K >= 768 && d->Cn >= 256 && d->Cn <= 512 && d->out_dtype == d->dtype)));
     if (ok && want) {
-      const int pad256 = (d->Cn + 255) / 256 * 256, pad128 = (d->Cn + 127) / 128 * 128;
-      pl->nt8 = pad256 <= pad128 ? 256 : 128;
+      // tile shape: 256 / 196 rows (196 = two wave rows of 98: 7 of 8 fragment rows useful) x 256 / 128 columns,
+      // whichever needs the fewest MFMA slots over whole rounds of 256 workgroups (one per CU)
+      long long best = -1;
+      for (int bn = 256; bn >= 128; bn -= 128)
+        for (int bm = 256; bm >= 196; bm -= 60) {
+          const long long tn = (d->Cn + bn - 1) / bn, tm = (M + bm - 1) / bm;
+          const long long cost = (tn * tm * batch + 255) / 256 * (bm == 196 ? 7 : 8) * (bn / 128);
+          if (best < 0 || cost < best) { best = cost; pl->nt8 = bn; pl->nt8_bm = bm; }
+        }
       pl->nt8_mode = pl->ident ? 0 : (d->mode == VLFB_CONV_FPROP ? 1 : 2);
       g.tiles_n = (d->Cn + pl->nt8 - 1) / pl->nt8;
-      // rows per tile: 256, or 196 (7 of 8 fragment rows useful) when that fills whole rounds of 256 CUs better
-      const long long t256 = (M + 255) / 256 * g.tiles_n * batch, t196 = (M + 195) / 196 * g.tiles_n * batch;
-      const long long c256 = (t256 + 255) / 256 * 8, c196 = (t196 + 255) / 256 * 7;
-      pl->nt8_bm = c196 < c256 ? 196 : 256;
       g.tiles_m = (int)((M + pl->nt8_bm - 1) / pl->nt8_bm);
     }
   }

@@ -13,27 +13,32 @@ Backend-agnostic on purpose: the CPU tests drive the same class over `gloo`.
 import torch.distributed as td
 
 
+def make_buckets(segments, bucket_bytes, esize=4):
+    """cut [(offset, count, ready_step)] (flat order, ready_step non-decreasing) into [(start, end, ready_step)]
+    buckets of at least `bucket_bytes` (the last one may be smaller)"""
+    buckets = []
+    start, end, ready = None, 0, -1
+    for off, cnt, step in segments:
+        if start is None:
+            start = off
+        end = max(end, off + cnt)
+        ready = max(ready, step)
+        if (end - start) * esize >= bucket_bytes:
+            buckets.append((start, end, ready))
+            start = None
+    if start is not None:
+        buckets.append((start, end, ready))
+    return buckets
+
+
 class GradComm(object):
-    def __init__(self, flat_grad, segments, bucket_bytes=32 << 20, group=None):
+    def __init__(self, flat_grad, segments, bucket_bytes=32 << 20, group=None, buckets=None):
         """segments: [(offset, count, ready_step)] in flat order; ready_step = index of the backward
-        step after which that segment's gradient is final (non-decreasing)."""
+        step after which that segment's gradient is final (non-decreasing).  `buckets` overrides the cut
+        (the engine's per-bucket solver uses the same buckets)."""
         self.flat = flat_grad
         self.group = group
-        self.buckets = []          # (start, end, ready_step)
-        start = None
-        end = 0
-        ready = -1
-        esize = flat_grad.element_size()
-        for off, cnt, step in segments:
-            if start is None:
-                start = off
-            end = max(end, off + cnt)
-            ready = max(ready, step)
-            if (end - start) * esize >= bucket_bytes:
-                self.buckets.append((start, end, ready))
-                start = None
-        if start is not None:
-            self.buckets.append((start, end, ready))
+        self.buckets = list(buckets) if buckets is not None else make_buckets(segments, bucket_bytes, flat_grad.element_size())
         self._next = 0
         self._works = []
 
@@ -46,12 +51,14 @@ class GradComm(object):
         return self._next < len(self.buckets) and self.buckets[self._next][2] <= step_index
 
     def after_step(self, step_index):
-        """call after backward step `step_index` has been enqueued"""
+        """call after backward step `step_index` has been enqueued; returns the reductions issued by this call"""
+        issued = []
         while self._next < len(self.buckets) and self.buckets[self._next][2] <= step_index:
             s, e, _ = self.buckets[self._next]
-            self._works.append(td.all_reduce(self.flat[s:e], op=td.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+            issued.append(td.all_reduce(self.flat[s:e], op=td.ReduceOp.SUM, group=self.group, async_op=True))
             self._next += 1
+        self._works.extend(issued)
+        return issued
 
     def wait(self):
         """flush buckets not yet issued, then make the current stream wait for every reduction"""

@@ -1196,6 +1196,11 @@ class Engine(object):
         self.lr = float(model.current_lr)
         self.comm = None
         self.side = None
+        self.solver_stream = None      # all-reduce hand-off + per-bucket solver (third HIP stream)
+        self.solver_dirty = False
+        self._eager_lr = None          # learning rate of the step whose buckets are solved during backward
+        self._eager_next = 0
+        self._eager_done = False
         self.side_dirty = False
         model.engine = self
 
@@ -1229,6 +1234,9 @@ class Engine(object):
         if self.side is not None and self.side_dirty:
             torch.cuda.current_stream().wait_stream(self.side)
             self.side_dirty = False
+        if self.solver_stream is not None and self.solver_dirty:
+            torch.cuda.current_stream().wait_stream(self.solver_stream)
+            self.solver_dirty = False
 
     # ---- bookkeeping used by steps ------------------------------------------------------------
     def is_trainable(self, name):
@@ -1285,6 +1293,9 @@ class Engine(object):
             self.refresh_operands(all_params=True)
             if self.train and self.use_side_stream:
                 self.side = torch.cuda.Stream(device=self.device)
+                self.solver_stream = torch.cuda.Stream(device=self.device)
+        if self.train:
+            self._plan_solver_buckets()
         return self
 
     def _plan_params(self):
@@ -1492,31 +1503,32 @@ class Engine(object):
             off, cnt, shape = self.train_layout[name]
             self.flat_mom[off:off + cnt].view(shape).copy_(self._to_kernel_layout(name, arr).to(self.device))
 
+    def _wprep_table(self, convs):
+        """device table for vlfb_weight_prep_batched over these conv steps: (tensor, items, tiles) or None"""
+        items, tile = [], 0
+        for st in convs:
+            cout, taps, cin = st.out.shape[1], st.taps(), st.Cin_k
+            it = hip.WPrepItem()
+            it.w = hip.ptr(self.param_tensor(st.wname))
+            it.scale = hip.ptr(self.param_tensor(st.sname)) if st.sname else None
+            it.w_fprop = hip.ptr(st.w_f)
+            it.w_dgrad = hip.ptr(st.w_d) if st.w_d is not None else None
+            it.cout, it.taps, it.cin, it.tile_begin = cout, taps, cin, tile
+            tile += taps * ((cout + 31) // 32) * ((cin + 31) // 32)
+            items.append(it)
+        if not items:
+            return None
+        arr = (hip.WPrepItem * len(items))(*items)
+        raw = bytes(memoryview(arr))
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        return (dev, len(items), tile)
+
     def _build_wprep_tables(self):
         """device tables for vlfb_weight_prep_batched: all convs / only those with trainable weights"""
-        import ctypes as C_
         self._wprep = {}
         for key in ("all", "trainable"):
-            items, tile = [], 0
-            for st in self.steps:
-                if not isinstance(st, ConvStep) or (key == "trainable" and not self.is_trainable(st.wname)):
-                    continue
-                cout, taps, cin = st.out.shape[1], st.taps(), st.Cin_k
-                it = hip.WPrepItem()
-                it.w = hip.ptr(self.param_tensor(st.wname))
-                it.scale = hip.ptr(self.param_tensor(st.sname)) if st.sname else None
-                it.w_fprop = hip.ptr(st.w_f)
-                it.w_dgrad = hip.ptr(st.w_d) if st.w_d is not None else None
-                it.cout, it.taps, it.cin, it.tile_begin = cout, taps, cin, tile
-                tile += taps * ((cout + 31) // 32) * ((cin + 31) // 32)
-                items.append(it)
-            if not items:
-                self._wprep[key] = None
-                continue
-            arr = (hip.WPrepItem * len(items))(*items)
-            raw = bytes(memoryview(arr))
-            dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-            self._wprep[key] = (dev, len(items), tile)
+            self._wprep[key] = self._wprep_table([st for st in self.steps if isinstance(st, ConvStep) and
+                                                  (key == "all" or self.is_trainable(st.wname))])
 
     def refresh_operands(self, all_params=False):
         """rebuild the MFMA operand copies (one batched launch) and the effective biases"""
@@ -1621,28 +1633,94 @@ class Engine(object):
                 b.slot.reset()
         if self.comm is not None:
             self.comm.begin()
+        eager = self._eager_lr is not None
+        self._eager_next = 0
+        buckets = self.sol_buckets
         for i, st in enumerate(self.bwd_steps):
             st.bwd()
-            if self.comm is not None and self.comm.due(i):
-                self._issue_buckets(i)
+            if (self.comm is not None and self.comm.due(i)) or \
+                    (eager and self._eager_next < len(buckets) and buckets[self._eager_next]["ready"] <= i):
+                self._bucket_ready(i)
+        if eager and self._eager_next < len(buckets):
+            self._bucket_ready(1 << 60)
+        self._eager_done = eager
         self.join_side_stream()
 
-    def _issue_buckets(self, i):
-        """all-reduce the buckets that became final with backward step i WITHOUT stalling the dgrad chain:
-        their gradients were produced on the side stream (wgrads, bias column sums) or, for the classifier,
-        on the main stream.  The reduction is issued with the SIDE stream current, after the side stream has
-        been made to wait for the main stream's position: ProcessGroupNCCL orders the collective behind the
-        stream that is current at the call, so the bucket waits for exactly its producers and the main
-        stream keeps running dgrads (it only joins the side stream once, at the end of backward)."""
-        if self.side is None:
-            self.comm.after_step(i)
+    def _bucket_ready(self, i):
+        """The buckets that became final with backward step i: all-reduce them and, in a train_step() (the
+        learning rate of the step is known), run the solver and the operand refresh for them right away --
+        WITHOUT stalling the dgrad chain or the parameter-gradient stream.  Their gradients were produced on
+        the side stream (wgrads, bias column sums) or, for the classifier, on the main stream, so a third
+        stream waits for both positions; ProcessGroupNCCL orders the collective behind the stream that is
+        current at the call, and the solver kernels of the bucket follow the collective on that stream.  The
+        main stream joins it once, at the end of backward (the forward of the next step reads the refreshed
+        operand copies).  Safe because nothing later in backward reads a parameter of a finished bucket: the
+        dgrad of a layer is enqueued (main stream) before the event this hand-off waits for."""
+        eager = self._eager_lr is not None
+        if self.side is None:                       # single-stream development mode
+            works = self.comm.after_step(i) if self.comm is not None else []
+            if eager:
+                for w in works:
+                    w.wait()
+                self._solve_ready_buckets(i)
             return
         ev = torch.cuda.Event()
         ev.record()
         self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            self.comm.after_step(i)
+        ev2 = torch.cuda.Event()
+        ev2.record(self.side)
+        sol = self.solver_stream
+        sol.wait_event(ev)
+        sol.wait_event(ev2)
+        with torch.cuda.stream(sol):
+            works = self.comm.after_step(i) if self.comm is not None else []
+            if eager:
+                for w in works:
+                    w.wait()
+                self._solve_ready_buckets(i)
         self.side_dirty = True
+        self.solver_dirty = True
+
+    def _solve_ready_buckets(self, i):
+        while self._eager_next < len(self.sol_buckets) and self.sol_buckets[self._eager_next]["ready"] <= i:
+            self._solve_bucket(self.sol_buckets[self._eager_next], self._eager_lr)
+            self._eager_next += 1
+
+    def _solve_bucket(self, b, lr):
+        """WeightedSum + MomentumSGDUpdate (model_builder_video.py:348-389) and the MFMA operand refresh for the
+        parameters of one bucket, on the current stream"""
+        sol = cfg.SOLVER
+        S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
+        for off, end, wd in b["wd"]:
+            hip.call("vlfb_sgd_update", hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off,
+                     hip.ptr(self.flat_mom) + 4 * off, end - off, lr / S, wd * S, float(sol.MOMENTUM),
+                     int(bool(sol.NESTEROV)))
+        if b["wprep"] is not None:
+            dev, n, tiles = b["wprep"]
+            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.code)
+        for st in b["bias_steps"]:
+            st.refresh_bias()
+
+    def _plan_solver_buckets(self, bucket_mb=32):
+        """buckets of the flat parameter buffer in backward-completion order (the all-reduce buckets), each with
+        its weight-decay ranges, the batched operand-refresh table of its conv weights and its effective biases"""
+        from vlfb.comm import make_buckets
+        index = {id(st): i for i, st in enumerate(self.bwd_steps)}
+        segs = []
+        for n in self.train_order:
+            off, cnt, _ = self.train_layout[n]
+            segs.append((off, cnt, index[id(self.param_step[n])]))
+        self._bucket_mb = int(bucket_mb)
+        self.sol_buckets = []
+        for start, end, ready in make_buckets(segs, int(bucket_mb) << 20, 4):
+            names = [n for n in self.train_order if start <= self.train_layout[n][0] < end]
+            wd = [[max(o, start), min(e, end), w] for o, e, w in self.wd_ranges if max(o, start) < min(e, end)]
+            convs = [st for st in self.steps if isinstance(st, ConvStep) and st.wname in names]
+            bias_steps = [st for st in self.steps if isinstance(st, ConvStep) and st.eff_bias is not None and
+                          any(p in names for p in st.params)]
+            self.sol_buckets.append({"start": start, "end": end, "ready": ready, "wd": wd, "names": names,
+                                     "wprep": None if self.dry_run else self._wprep_table(convs),
+                                     "bias_steps": bias_steps})
 
     def set_lr(self, lr):
         self.lr = float(lr)
@@ -1662,12 +1740,10 @@ class Engine(object):
         td.broadcast(self.flat_param, 0)
         td.broadcast(self.flat_frozen, 0)
         self.refresh_operands(all_params=True)
-        index = {id(st): i for i, st in enumerate(self.bwd_steps)}
-        segments = []
-        for n in self.train_order:
-            off, cnt, _ = self.train_layout[n]
-            segments.append((off, cnt, index[id(self.param_step[n])]))
-        self.comm = GradComm(self.flat_grad, segments, int(bucket_mb) << 20)
+        if int(bucket_mb) != self._bucket_mb:
+            self._plan_solver_buckets(bucket_mb)
+        self.comm = GradComm(self.flat_grad, None, int(bucket_mb) << 20,
+                             buckets=[(b["start"], b["end"], b["ready"]) for b in self.sol_buckets])
 
     def recent_losses(self):
         """losses since the last call (device ring of the loss step; a single host sync)"""
@@ -1686,6 +1762,14 @@ class Engine(object):
             self.lr = float(lr)
         if self.comm is not None:
             self.comm.wait()
+        if self._eager_done:
+            # train_step(): every bucket was solved and refreshed during backward, as soon as it was final
+            assert self._eager_next == len(self.sol_buckets)
+            self._eager_done = False
+            self._pstate[0] += 1
+            self._operand_version = self._pstate[0]
+            self.iteration += 1
+            return
         sol = cfg.SOLVER
         S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
         for off, end, wd in self.wd_ranges:       # one launch unless a trainable '_bn' parameter exists
@@ -1696,7 +1780,21 @@ class Engine(object):
         self.refresh_operands()
         self.iteration += 1
 
+    # True: train_step() solves every gradient bucket during backward, as soon as it is final (the learning rate
+    # of the step is known before backward starts), on the third stream; False: one solver pass after backward.
+    # Bit-identical (tests/test_eager_solver_gpu.py).  Measured on one MI355X at 8 clips: 425.8 vs 427.3 clips/s --
+    # the solver's 0.9 GB of traffic then competes with the HBM-bound res2 / res3 backward instead of running
+    # alone after it, which costs as much as the hidden tail saves -- so it is off unless a multi-GPU run wants the
+    # solver of a bucket to follow its all-reduce directly.
+    EAGER_SOLVER = False
+
     def train_step(self, lr=None):
         self.forward()
-        self.backward()
-        self.sgd_step(lr)
+        if lr is not None:
+            self.lr = float(lr)
+        self._eager_lr = self.lr if self.EAGER_SOLVER else None
+        try:
+            self.backward()
+        finally:
+            self._eager_lr = None
+        self.sgd_step()
