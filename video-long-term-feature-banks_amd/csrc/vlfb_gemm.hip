@@ -624,6 +624,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
 // LDS rows are RS = 2*B bytes (one position); the 32-byte segment index is XOR-ed with a key of
 // the row so that the 8 rows touched by a 32-lane half of a tr-read fall on 8 different 32-byte
 // bank segments (the DMA destination is lane-linear, so the XOR is applied on the SOURCE chunk).
+// The DMAs are issued through bufglds16_hidden: with the builtin, hipcc put s_waitcnt vmcnt(0) in front of the
+// transposed reads of every k-tile, i.e. it waited for the NEXT tile's DMA right after issuing it.
 // =============================================================================================
 template <typename T, typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
@@ -711,11 +713,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
     const int kb = kbeg + kt * BK;
     const unsigned pstep = (unsigned)(kt * BK) * (unsigned)p.ldp * 2u;
 #pragma unroll
-    for (int i = 0; i < PI; ++i) bufglds16(rsP, poff[i], pstep, pt + i * (NTHR * 16));
+    for (int i = 0; i < PI; ++i) bufglds16_hidden(rsP, poff[i], pstep, pt + i * (NTHR * 16));
     if (IDENT) {
       const unsigned qstep = (unsigned)(kt * BK) * (unsigned)p.lda * 2u;
 #pragma unroll
-      for (int i = 0; i < QI; ++i) bufglds16(rsQ, qoff[i], qstep, qt + i * (NTHR * 16));
+      for (int i = 0; i < QI; ++i) bufglds16_hidden(rsQ, qoff[i], qstep, qt + i * (NTHR * 16));
     } else {
 #pragma unroll
       for (int i = 0; i < QI; ++i) {
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
           off = ok ? (unsigned)((qcur[i].base + ws) * p.lda + qtap.ci) * 2u : kOOB;
         }
         qrow_jump(p, qcur[i], jump, qtap);
-        bufglds16(rsQ, off, 0, qt + i * (NTHR * 16));
+        bufglds16_hidden(rsQ, off, 0, qt + i * (NTHR * 16));
       }
     }
   };
@@ -868,13 +870,13 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
         const int tin = t * p.st - p.pt + ra[i], hin = h * p.sh - p.ph + rb[i];
         const bool ok = (unsigned)tin < (unsigned)p.Ts && (unsigned)hin < (unsigned)p.Hs;
         const unsigned off = ok ? (unsigned)(((n * p.Ts + tin) * p.Hs + hin) * rbytes + rj[i]) : kOOB;
-        bufglds16(rsX, off, 0, base + (i * 512 + wave_u * 64) * 16);
+        bufglds16_hidden(rsX, off, 0, base + (i * 512 + wave_u * 64) * 16);
       }
     }
     const unsigned gstep = (unsigned)(tile * p.Wr) * (unsigned)p.ldp * 2u;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      if (gok[i]) bufglds16(rsG, gvoff[i], gstep, base + poff_lds + (i * 512 + wave_u * 64) * 16);
+      if (gok[i]) bufglds16_hidden(rsG, gvoff[i], gstep, base + poff_lds + (i * 512 + wave_u * 64) * 16);
   };
 
   f32x4_v acc[kStemCT][4];
@@ -1012,6 +1014,7 @@ struct Plan {
   int threads;    // workgroup size (NT: 256 or 512)
   int ut;         // NT: taps span whole k-tiles (and DGRAD has unit stride): scalar tap cursor
   int stem;       // WGRAD: packed-stem kernel (whole output rows per workgroup, raw input rows in LDS)
+  int rows;       // WGRAD: whole-row kernel for thin 64 -> 64 channel convs (vlfb_wgrad_rows.hip)
   int tn8;        // WGRAD: 256 x 256 phase-pipelined kernel (plain rows)
   int nt8;        // NT: 256-row phase-pipelined kernel with this tile width (256 / 128), 0 = 128x128 kernel
   int nt8_bm;     //     rows per tile: 256 or 196
@@ -1086,6 +1089,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->tn8 = 0;
   pl->tn_tr = 0;
   pl->stem = 0;
+  pl->rows = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
     pl->bm = 128;
     pl->bn = d->Cn > 64 ? 128 : 64;
@@ -1135,7 +1139,28 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         pl->stem_lds = (size_t)(2 * stage);
       }
     }
-    if (!pl->stem) {
+    // whole-row kernel (vlfb_wgrad_rows.hip): 64 -> 64 channels, unit stride, same-size output, rows of <= 64
+    // positions (res2 3x3 / 3x1x1): every operand byte is read once, taps are LDS row offsets
+    if (!pl->stem && pl->tn_tr && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && d->Cs == 64 && d->Cn == 64 &&
+        d->st == 1 && d->sh == 1 && d->sw == 1 && d->dt == 1 && d->dh == 1 && d->dw == 1 && d->Tr == d->Ts &&
+        d->Hr == d->Hs && d->Wr == d->Ws && d->Wr % 8 == 0 && d->Ws + d->kw - 1 <= 64 && d->pw < d->kw &&
+        wgrad_rows_ct(K) > 0 && d->kt * d->kh == 3 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && g.lda == 64 && g.ldp == 64) {
+      const long long tiles_total = (long long)d->N * d->Tr * d->Hr;
+      if (tiles_total >= 2) {
+        const long long wgs = tiles_total < 256 ? tiles_total : 256;            // one 128 KiB workgroup per CU
+        const long long tpw = (tiles_total + wgs - 1) / wgs;
+        const int splits = (int)((tiles_total + tpw - 1) / tpw);
+        g.tiles_m = (int)tiles_total;
+        g.tiles_n = 1;
+        g.kper = (int)tpw;
+        g.splits = splits;
+        pl->splits = splits;
+        pl->ws_elems = (long long)splits * d->Cn * K;
+        pl->rows = 1;
+        pl->stem_lds = (size_t)2 * ((size_t)d->kt * d->kh * (d->Ws + d->kw - 1) * 128 + (size_t)d->Wr * 128) + 1024;
+      }
+    }
+    if (!pl->stem && !pl->rows) {
       g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
       g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
       const int bk = 128 / es;
@@ -1273,7 +1298,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->pre = g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
   } else {
     pl->lds = (size_t)2 * (pl->bm + pl->bn) * 128;
-    if (pl->stem) { pl->lds = pl->stem_lds; pl->threads = 512; }
+    if (pl->stem || pl->rows) { pl->lds = pl->stem_lds; pl->threads = 512; }
   }
   return VLFB_OK;
 }
@@ -1344,6 +1369,7 @@ int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
       hipLaunchKernelGGL(stem_wgrad_kernel<T>, pl.grid, dim3(512), pl.lds, s, pl.gp);
       return check_launch("conv wgrad (stem) kernel");
     }
+    if (d->mode == VLFB_CONV_WGRAD && pl.rows) return launch_wgrad_rows(pl.gp, pl.splits, pl.lds, d->dtype, s);
     if (d->mode == VLFB_CONV_WGRAD && pl.tn8) return launch_tn8(pl.gp, pl.grid, d->dtype, sizeof(OutT) == 4, s);
     if (d->mode == VLFB_CONV_WGRAD && pl.tn_tr) {
       if (pl.ident) launch_tn_tr<T, OutT, true, false>(pl, s);

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const GP p) {
     char* dst = smem + buf * BUFSZ + h * HT + wave * 1024;
     const unsigned step = (unsigned)(kt * 64) * (unsigned)p.ldp * 2u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) bufglds16(rsP, live ? poff[h][i] : kOOB, step, dst + i * 8192);
+    for (int i = 0; i < 2; ++i) bufglds16_hidden(rsP, live ? poff[h][i] : kOOB, step, dst + i * 8192);
     pkt[h] = kt + 1;
   };
   auto stage_q = [&](int h, int buf) {
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const GP p) {
     char* dst = smem + buf * BUFSZ + (2 + h) * HT + wave * 1024;
     const unsigned step = (unsigned)(kt * 64) * (unsigned)p.lda * 2u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) bufglds16(rsQ, live ? qoff[h][i] : kOOB, step, dst + i * 8192);
+    for (int i = 0; i < 2; ++i) bufglds16_hidden(rsQ, live ? qoff[h][i] : kOOB, step, dst + i * 8192);
     qkt[h] = kt + 1;
   };
 

@@ -48,6 +48,11 @@ int launch_tn8(const GP& gp, dim3 grid, int dtype, bool out_f32, hipStream_t s);
 int nts_chunk(int mode, long long K);
 int launch_nts(const GP& gp, int mode, int dtype, hipStream_t s);
 
+// vlfb_wgrad_rows.hip: whole-row WGRAD of thin 64 -> 64 channel convs (gp.tiles_m = output rows, gp.kper = rows per
+// workgroup, gp.ws = slabs); wgrad_rows_ct = column tiles per wave for K gathered columns (0: K not supported)
+int wgrad_rows_ct(long long K);
+int launch_wgrad_rows(const GP& gp, int splits, size_t lds, int dtype, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
@@ -152,6 +157,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, un
 __device__ __forceinline__ void bufglds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
                                            (int)voff, (int)soff, 0, 0);
+}
+// The same DMA, HIDDEN from the compiler (inline asm).  hipcc orders every later LDS read whose address it cannot
+// prove distinct -- in practice every ds_read_b64_tr_b16 -- behind ALL pending LDS DMAs of the builtin above by
+// emitting s_waitcnt vmcnt(0) in front of it, which drains a multi-stage ring on every k-step (found in the .s of the
+// transposed-read kernels; the plain ds_read_b128 loops of the NT kernels are not affected).  With the DMA in asm the
+// compiler counts nothing, so completion is the kernel's job: counted `s_waitcnt vmcnt(N)` + `s_barrier` before the
+// slot is read, exactly as those kernels already do.  lds_wave_base must be wave-uniform; M0 is written and consumed
+// inside the statement (the compiler re-loads M0 before its own uses).
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void bufglds16_hidden(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ void bufglds16_hidden(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, const char* lds_wave_base) {
+  bufglds16_hidden(rsrc, voff, soff, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(lds_wave_base)));
 }
 
 // Branch-free predicated loads: the load always executes (from offset 0 of the operand when the
