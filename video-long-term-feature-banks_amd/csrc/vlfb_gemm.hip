@@ -1160,6 +1160,25 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         pl->stem_lds = (size_t)2 * ((size_t)d->kt * d->kh * (d->Ws + d->kw - 1) * 128 + (size_t)d->Wr * 128) + 1024;
       }
     }
+    if (!pl->stem && !pl->rows && pl->tn_tr && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && d->Cs == 256 &&
+        d->Cn == 64 && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->dt == 1 &&
+        d->Tr == d->Ts && d->Hr == d->Hs && d->Wr == d->Ws && d->ph == 0 && d->pw == 0 && d->pt < 3 && d->Wr % 8 == 0 &&
+        d->Wr <= 64 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && g.lda == 256 && g.ldp == 64) {
+      const long long tiles_total = (long long)d->N * d->Ts * d->Hs;
+      if (tiles_total >= 2) {
+        const long long wgs = tiles_total < 256 ? tiles_total : 256;
+        const long long tpw = (tiles_total + wgs - 1) / wgs;
+        const int splits = (int)((tiles_total + tpw - 1) / tpw);
+        g.tiles_m = (int)tiles_total;
+        g.tiles_n = 1;
+        g.kper = (int)tpw;
+        g.splits = splits;
+        pl->splits = splits;
+        pl->ws_elems = (long long)splits * d->Cn * K;
+        pl->rows = 2;
+        pl->stem_lds = 0;
+      }
+    }
     if (!pl->stem && !pl->rows) {
       g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
       g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
@@ -1369,6 +1388,7 @@ int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
       hipLaunchKernelGGL(stem_wgrad_kernel<T>, pl.grid, dim3(512), pl.lds, s, pl.gp);
       return check_launch("conv wgrad (stem) kernel");
     }
+    if (d->mode == VLFB_CONV_WGRAD && pl.rows == 2) return launch_wgrad_rows_fat(pl.gp, pl.splits, d->dtype, s);
     if (d->mode == VLFB_CONV_WGRAD && pl.rows) return launch_wgrad_rows(pl.gp, pl.splits, pl.lds, d->dtype, s);
     if (d->mode == VLFB_CONV_WGRAD && pl.tn8) return launch_tn8(pl.gp, pl.grid, d->dtype, sizeof(OutT) == 4, s);
     if (d->mode == VLFB_CONV_WGRAD && pl.tn_tr) {

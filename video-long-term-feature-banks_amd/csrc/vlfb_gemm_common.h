@@ -52,6 +52,8 @@ int launch_nts(const GP& gp, int mode, int dtype, hipStream_t s);
 // workgroup, gp.ws = slabs); wgrad_rows_ct = column tiles per wave for K gathered columns (0: K not supported)
 int wgrad_rows_ct(long long K);
 int launch_wgrad_rows(const GP& gp, int splits, size_t lds, int dtype, hipStream_t s);
+// fat-input variant: 256 -> 64 channels, 3x1x1 (the gradient rows are shifted, the 512-byte input rows read once)
+int launch_wgrad_rows_fat(const GP& gp, int splits, int dtype, hipStream_t s);
 
 namespace {
 

@@ -195,6 +195,144 @@ __global__ __launch_bounds__(NW * 64) void wgrad_rows_kernel(const GP p) {
   }
 }
 
+// =============================================================================================
+// The same idea for the 3x1x1 convs with a FAT input (res2 branch2a: 256 -> 64 channels):
+//   dW[co][a][ci] = sum_pos G[pos][co] * X[pos + (a - pt) * H * W][ci]
+//                 = sum_pos' X[pos'][ci] * G[pos' - (a - pt) * H * W][co]
+// -- shift the THIN operand.  A workgroup walks input rows (n, t, h): the 512-byte-per-position X row is staged once
+// (NG = Cs / 64 channel groups of [64 positions][128 B]) next to the kt gradient rows of the frames t - (a - pt)
+// (rows of frames that do not exist are requested out of range: zeros).  Wave w owns input channels
+// [32 w, 32 w + 32): two 16-channel tiles x kt taps x all 64 output channels = 6 x 4 accumulator fragments.  X is read
+// from HBM exactly once, the gradient rows kt times out of L1 / L2 (the generic kernel reads X once per 128-column
+// tile of the gradient -- 6 times -- and was at 2.3 TB/s of algorithmic bytes).
+// =============================================================================================
+template <typename T, int NG, int KT>
+__global__ __launch_bounds__(512) void wgrad_rows_fat_kernel(const GP p) {
+  typedef typename V16<T>::V vec_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(NG == 4, "8 waves x 32 channels");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4, pl = lane & 15;
+  constexpr int slotb = 64 * 128;                  // one staged [64 positions][128 B] piece
+  constexpr int goff_lds = NG * slotb;             // gradient rows behind the X groups
+  constexpr int stage = (NG + KT) * slotb;
+  constexpr int NS = 2;
+  const int split = blockIdx.x;
+  const int tiles_total = p.tiles_m, tpw = p.kper;
+  const int tile_beg = split * tpw;
+  const int tile_end = min(tiles_total, tile_beg + tpw);
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(p.P, p.b_bytes);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+  const int prow = tid >> 3, slot = tid & 7;
+  const int pc = (((slot >> 1) ^ tr_key<128>(prow)) << 1) | (slot & 1);
+  const bool row_ok = prow < p.Wr;
+  const unsigned xvoff = (unsigned)(prow * p.lda + pc * 8) * 2u;      // + group * 128 + row base
+  const unsigned gvoff = (unsigned)(prow * p.ldp + pc * 8) * 2u;
+  const int frame = p.Hs * p.Ws;                                       // positions per frame
+
+  // every wave issues exactly NG + KT DMA instructions per row
+  auto load_tile = [&](int tile, int buf) {
+    const bool tile_ok = tile < tile_end;
+    const int h = tile % p.Hs;
+    const int nt = tile / p.Hs;
+    const int t = nt % p.Ts, n = nt / p.Ts;
+    const unsigned base = lds0 + buf * stage + wave * 1024;
+    const unsigned xbase = (unsigned)(tile * p.Ws) * (unsigned)p.lda * 2u;
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+      bufglds16_hidden(rsX, (tile_ok && row_ok) ? xbase + xvoff + c * 128u : kOOB, 0u, base + c * slotb);
+#pragma unroll
+    for (int a = 0; a < KT; ++a) {
+      const int tg = t - (a - p.pt);                                   // frame of the gradient row tap a pairs with
+      const bool ok = tile_ok && row_ok && (unsigned)tg < (unsigned)p.Tr;
+      const unsigned gbase = (unsigned)(((n * p.Tr + tg) * p.Hr + h) * p.Wr) * (unsigned)p.ldp * 2u;
+      bufglds16_hidden(rsG, ok ? gbase + gvoff : kOOB, 0u, base + goff_lds + a * slotb);
+    }
+  };
+  (void)frame;
+
+  f32x4_v acc[2 * KT][4];
+#pragma unroll
+  for (int j = 0; j < 2 * KT; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses, once per lane: the gradient fragments of tap a are the ones of tap 0 + a * slotb
+  constexpr int KS = 2;
+  int poff[KS][4][2], qoff[KS][2][2];
+  const int cg = wave >> 1;                                            // channel group of this wave's 32 channels
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int r0 = ks * 32 + 8 * g + (pl >> 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      poff[ks][i][0] = goff_lds + r0 * 128 + ((i ^ tr_key<128>(r0)) << 5) + ((pl & 3) << 3);
+      poff[ks][i][1] = goff_lds + (r0 + 4) * 128 + ((i ^ tr_key<128>(r0 + 4)) << 5) + ((pl & 3) << 3);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int seg = ((wave & 1) << 1) | e;
+      qoff[ks][e][0] = cg * slotb + r0 * 128 + ((seg ^ tr_key<128>(r0)) << 5) + ((pl & 3) << 3);
+      qoff[ks][e][1] = cg * slotb + (r0 + 4) * 128 + ((seg ^ tr_key<128>(r0 + 4)) << 5) + ((pl & 3) << 3);
+    }
+  }
+  auto tr8 = [](const char* a0, const char* a1) {
+    union { struct { s16x4_v a, b; } s; vec_t v; } u;
+    u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)a0);
+    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)a1);
+    return u.v;
+  };
+
+  load_tile(tile_beg, 0);
+  int buf = 0;
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    load_tile(tile + 1, buf ^ 1);
+    const char* rows = smem + buf * stage;
+    // positions past the row end were staged as zeros on both sides: no masks
+    vec_t qf[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) qf[ks][e] = tr8(rows + qoff[ks][e][0], rows + qoff[ks][e][1]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      vec_t pf[KT][4];
+#pragma unroll
+      for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[a][i] = tr8(rows + a * slotb + poff[ks][i][0], rows + a * slotb + poff[ks][i][1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[a * 2 + e][i] = V16<T>::mma(qf[ks][e], pf[a][i], acc[a * 2 + e][i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    buf ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-fill DMAs of the tail
+
+  // ---- slab: ws[split][co][a * Cs + ci], lane holds 4 consecutive ci of row co --------------------------------
+  float* slab = p.ws + (long long)split * ((long long)p.Ncols * p.ldo);
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = i * 16 + l15;
+        const int col = a * p.Cs + (wave * 2 + e) * 16 + g * 4;
+        *reinterpret_cast<float4*>(slab + (long long)co * p.ldo + col) =
+            make_float4(acc[a * 2 + e][i][0], acc[a * 2 + e][i][1], acc[a * 2 + e][i][2], acc[a * 2 + e][i][3]);
+      }
+}
+
 template <typename K>
 void launch_rows(K kernel, const GP& gp, unsigned splits, unsigned threads, size_t lds, hipStream_t s) {
   static bool configured = false;   // per template instance
@@ -221,6 +359,13 @@ int wgrad_rows_ct(long long K) {
   const long long ncts = K / 16;
   if (K % 64 || ncts < 1) return 0;
   return ncts <= 16 ? 2 : ncts <= 40 ? 5 : 0;
+}
+
+int launch_wgrad_rows_fat(const GP& gp, int splits, int dtype, hipStream_t s) {
+  constexpr size_t kLds = 2 * (4 + 3) * 64 * 128;       // 2 rows x (4 X groups + 3 gradient rows) x 8 KiB
+  if (dtype == VLFB_F16) launch_rows(wgrad_rows_fat_kernel<f16_t, 4, 3>, gp, (unsigned)splits, 512, kLds, s);
+  else launch_rows(wgrad_rows_fat_kernel<bf16_t, 4, 3>, gp, (unsigned)splits, 512, kLds, s);
+  return check_launch("conv wgrad (whole rows, fat input) kernel");
 }
 
 int launch_wgrad_rows(const GP& gp, int splits, size_t lds, int dtype, hipStream_t s) {
