@@ -54,6 +54,9 @@ def parse():
                     help="extra cfg overrides, e.g. --set MODEL.FREEZE_BACKBONE False (SURVEY 8d C3 'unfrozen')")
     ap.add_argument("--single-stream", action="store_true",
                     help="development: parameter-gradient kernels on the main stream too (uncontended per-launch times for --detail)")
+    ap.add_argument("--solver", default="after", choices=["after", "eager", "tail"],
+                    help="after: one solver pass after backward | eager: per gradient bucket during backward | tail: the "
+                         "finished buckets beside the last wgrad of backward (Engine.EAGER_SOLVER)")
     ap.add_argument("--detail", default="", help="write the per-launch GEMM table of the profiled step to this file")
     return ap.parse_args()
 
@@ -110,6 +113,7 @@ def main():
                                 "TRAIN.VIDEO_LENGTH", args.frames, "TRAIN.CROP_SIZE", args.crop] + list(args.set))
     model = ModelBuilder(train=True, split="train", name="bench")
     model.build_model(suffix="_train")
+    Engine.EAGER_SOLVER = {"after": False, "eager": True, "tail": "tail"}[args.solver]
     eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED, side_stream=not args.single_stream)
     rois = args.rois_per_clip if args.rois_per_clip > 0 else synth.rois_per_clip_draw(clips, seed=cfg.RNG_SEED + rank)
     batch = synth.inputs(cfg, clips, rois, seed=cfg.RNG_SEED + rank, crop=args.crop, frames=args.frames)

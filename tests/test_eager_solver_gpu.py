@@ -17,7 +17,7 @@ def _engine(eager, dtype):
     from vlfb.engine import Engine
     from vlfb import synth
     load_preset("ava_r50_lfb_nl", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64])
-    model = ModelBuilder(train=True, split="train", name="eager%d" % int(eager))
+    model = ModelBuilder(train=True, split="train", name="eager_%s" % eager)
     model.build_model(suffix="_train")
     eng = Engine(model, dtype, device="cuda:0", base_seed=3)
     eng.EAGER_SOLVER = eager
@@ -31,10 +31,12 @@ def _engine(eager, dtype):
     return eng
 
 
+@pytest.mark.parametrize("mode", [True, "tail"], ids=["eager", "tail"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_bucketwise_solver_is_bit_identical_to_the_solver_pass_after_backward(dtype):
+def test_bucketwise_solver_is_bit_identical_to_the_solver_pass_after_backward(dtype, mode):
+    """mode True: every bucket as soon as it is final; "tail": the finished buckets together, beside the last wgrad"""
     from vlfb.engine import ConvStep
-    a, b = _engine(True, dtype), _engine(False, dtype)
+    a, b = _engine(mode, dtype), _engine(False, dtype)
     assert len(a.sol_buckets) > 3
     covered = sorted((x["start"], x["end"]) for x in a.sol_buckets)
     assert covered[0][0] == 0 and all(covered[i][1] <= covered[i + 1][0] for i in range(len(covered) - 1))

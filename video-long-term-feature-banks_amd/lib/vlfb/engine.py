@@ -1639,7 +1639,8 @@ class Engine(object):
         for i, st in enumerate(self.bwd_steps):
             st.bwd()
             if (self.comm is not None and self.comm.due(i)) or \
-                    (eager and self._eager_next < len(buckets) and buckets[self._eager_next]["ready"] <= i):
+                    (eager and self._eager_next < len(buckets) and buckets[self._eager_next]["ready"] <= i and
+                     (self.EAGER_SOLVER != "tail" or i >= len(self.bwd_steps) - 2)):
                 self._bucket_ready(i)
         if eager and self._eager_next < len(buckets):
             self._bucket_ready(1 << 60)
@@ -1682,6 +1683,8 @@ class Engine(object):
         self.solver_dirty = True
 
     def _solve_ready_buckets(self, i):
+        if self.EAGER_SOLVER == "tail" and i < len(self.bwd_steps) - 2:
+            return        # "tail": the finished buckets are solved together beside the last (MFMA-bound) stem wgrad
         while self._eager_next < len(self.sol_buckets) and self.sol_buckets[self._eager_next]["ready"] <= i:
             self._solve_bucket(self.sol_buckets[self._eager_next], self._eager_lr)
             self._eager_next += 1
@@ -1785,7 +1788,8 @@ class Engine(object):
     # Bit-identical (tests/test_eager_solver_gpu.py).  Measured on one MI355X at 8 clips: 425.8 vs 427.3 clips/s --
     # the solver's 0.9 GB of traffic then competes with the HBM-bound res2 / res3 backward instead of running
     # alone after it, which costs as much as the hidden tail saves -- so it is off unless a multi-GPU run wants the
-    # solver of a bucket to follow its all-reduce directly.
+    # solver of a bucket to follow its all-reduce directly.  "tail" = solve the finished buckets together beside the
+    # last wgrad of backward (the MFMA-bound stem wgrad leaves HBM idle): 440.5 vs 440.4 clips/s, no gain either.
     EAGER_SOLVER = False
 
     def train_step(self, lr=None):
