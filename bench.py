@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--solver", default="after", choices=["after", "eager", "tail"],
                     help="after: one solver pass after backward | eager: per gradient bucket during backward | tail: the "
                          "finished buckets beside the last wgrad of backward (Engine.EAGER_SOLVER)")
+    ap.add_argument("--no-forward-branches", action="store_true",
+                    help="development: every forward step on the main stream (Engine.FORWARD_BRANCHES = False)")
     ap.add_argument("--detail", default="", help="write the per-launch GEMM table of the profiled step to this file")
     return ap.parse_args()
 
@@ -113,6 +115,7 @@ def main():
                                 "TRAIN.VIDEO_LENGTH", args.frames, "TRAIN.CROP_SIZE", args.crop] + list(args.set))
     model = ModelBuilder(train=True, split="train", name="bench")
     model.build_model(suffix="_train")
+    Engine.FORWARD_BRANCHES = not args.no_forward_branches
     Engine.EAGER_SOLVER = {"after": False, "eager": True, "tail": "tail"}[args.solver]
     eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED, side_stream=not args.single_stream)
     rois = args.rois_per_clip if args.rois_per_clip > 0 else synth.rois_per_clip_draw(clips, seed=cfg.RNG_SEED + rank)

@@ -1296,6 +1296,7 @@ class Engine(object):
                 self.solver_stream = torch.cuda.Stream(device=self.device)
         if self.train:
             self._plan_solver_buckets()
+        self._plan_forward_branches()
         return self
 
     def _plan_params(self):
@@ -1623,8 +1624,76 @@ class Engine(object):
         if self._operand_version != self._pstate[0]:
             # parameters were changed through another engine that shares them (the train net's solver)
             self.refresh_operands(all_params=True)
-        for st in self.steps:
-            st.fwd()
+        if self.side is None or not self.FORWARD_BRANCHES or not self._fwd_side:
+            for st in self.steps:
+                st.fwd()
+            return
+        # The parameter-gradient stream is idle during forward: the projection shortcut of a stage's first block and
+        # the pooled phi / g branch of a non-local block run on it, beside the bottleneck chain / the theta conv they
+        # are independent of (20-150 us launches that leave most of the chip idle on their own).  Only the edges that
+        # cross streams carry an event.
+        main = torch.cuda.current_stream()
+        done = {}
+        for i, st in enumerate(self.steps):
+            on_side = i in self._fwd_side
+            stream = self.side if on_side else main
+            for j in self._fwd_wait[i]:
+                stream.wait_event(done[j])
+            if on_side:
+                with torch.cuda.stream(self.side):
+                    st.fwd()
+            else:
+                st.fwd()
+            if i in self._fwd_signal:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                done[i] = ev
+
+    # independent forward branches on the second stream (Engine.forward)
+    FORWARD_BRANCHES = True
+
+    def _plan_forward_branches(self):
+        """which forward steps run on the second stream, and which cross-stream edges need an event"""
+        steps = self.steps
+        side = set()
+        writer = {}                                   # id(root blob) -> index of the step that wrote it last
+        writers_at = []                               # per step: {id(root): writer index} of its reads
+        for i, st in enumerate(steps):
+            reads = [b.root for b in st.inputs]
+            if isinstance(st, ConvStep) and st.residual is not None:
+                reads.append(st.residual.root)
+            writers_at.append({id(r): writer[id(r)] for r in reads if id(r) in writer})
+            for b in st.outputs:
+                writer[id(b.root)] = i
+        readers = {}
+        for i, w in enumerate(writers_at):
+            for j in set(w.values()):
+                readers.setdefault(j, []).append(i)
+        for i, st in enumerate(steps):
+            # (a) projection shortcut: a conv whose output is only the residual operand of a later conv, and whose input
+            #     feeds another chain as well
+            if isinstance(st, ConvStep) and not st.stem and st.residual is None:
+                cons = readers.get(i, [])
+                if len(cons) == 1 and isinstance(steps[cons[0]], ConvStep) and steps[cons[0]].residual is not None and \
+                        steps[cons[0]].residual.root is st.out.root and steps[cons[0]].x.root is not st.out.root:
+                    side.add(i)
+            # (b) non-local block: the max-pool and the phi / g convs it feeds (theta stays on the main stream)
+            if isinstance(st, AttentionStep):
+                prods = [writers_at[i].get(id(b.root)) for b in st.inputs]
+                if all(p is not None and isinstance(steps[p], ConvStep) for p in prods):
+                    for p in prods[1:]:
+                        src = writers_at[p].get(id(steps[p].x.root))
+                        if src is not None and isinstance(steps[src], PoolStep) and \
+                                all(isinstance(steps[c], ConvStep) for c in readers.get(src, [])):
+                            side.add(p)
+                            side.add(src)
+        self._fwd_side = side
+        self._fwd_wait = []
+        self._fwd_signal = set()
+        for i in range(len(steps)):
+            waits = sorted(j for j in set(writers_at[i].values()) if (j in side) != (i in side))
+            self._fwd_wait.append(waits)
+            self._fwd_signal.update(waits)
 
     def backward(self):
         assert self.train, "backward() on a forward-only engine"
