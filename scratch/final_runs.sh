@@ -27,3 +27,7 @@ rm -rf $O/pmc_fetch $O/pmc_write
 VLFB_PARITY_DIR=$R/$O timeout 900 python -m pytest tests/test_model_gpu.py -q -k "full_size" > $O/parity_fullsize.log 2>&1
 tail -3 $O/parity_fullsize.log
 ls $O
+python bench.py --steps 30 --no-cpu-baseline --no-fp32-line --detail $O/per_launch_two_stream.txt > /dev/null 2>&1
+python bench.py --steps 30 --no-cpu-baseline --no-fp32-line --single-stream --detail $O/per_launch_single_stream.txt > /dev/null 2>&1
+python scratch/timeline2.py $O/prof $O/timeline_step.txt > /dev/null 2>&1
+rm -rf $O/prof
