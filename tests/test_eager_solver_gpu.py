@@ -61,3 +61,21 @@ def test_bucketwise_solver_is_bit_identical_to_the_solver_pass_after_backward(dt
             assert torch.equal(sa.eff_bias, sb.eff_bias)
     la, lb = a.recent_losses(), b.recent_losses()
     assert la == lb and len(la) == 3
+
+
+def test_forward_branches_on_the_second_stream_change_no_bit():
+    """Engine.forward runs the projection shortcuts and the pool -> phi / g branches of the non-local blocks on the
+    parameter-gradient stream (events on the edges that cross streams).  Same kernels, same data: activations, loss
+    and the parameters after two steps are bit-identical to the one-stream order."""
+    a, b = _engine(False, "bf16"), _engine(False, "bf16")
+    b.FORWARD_BRANCHES = False
+    assert len(a._fwd_side) >= 3 * 5 + 2 and all(a._fwd_wait[i] for i in a._fwd_side if a.steps[i].name().startswith("maxpool"))
+    for it in range(2):
+        a.train_step(0.02)
+        b.train_step(0.02)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat_param, b.flat_param) and torch.equal(a.flat_mom, b.flat_mom)
+    assert a.recent_losses() == b.recent_losses()
+    for name in ("nonlocal_conv3_1_sum", "res5_2_branch2c_bn", "res2_0_branch2c_bn"):
+        ta, tb = a.env[name].root.tensor, b.env[name].root.tensor
+        assert torch.equal(ta.view(torch.int16), tb.view(torch.int16)), name
