@@ -59,6 +59,9 @@ def parse():
                          "finished buckets beside the last wgrad of backward (Engine.EAGER_SOLVER)")
     ap.add_argument("--no-forward-branches", action="store_true",
                     help="development: every forward step on the main stream (Engine.FORWARD_BRANCHES = False)")
+    ap.add_argument("--graph", default="off", choices=["off", "step", "forward"],
+                    help="development: replay the single-GPU step (or its forward pass) as one captured HIP graph "
+                         "(Engine.STEP_GRAPH; measured slower than the two-stream enqueue, see engine.py)")
     ap.add_argument("--detail", default="", help="write the per-launch GEMM table of the profiled step to this file")
     return ap.parse_args()
 
@@ -116,6 +119,7 @@ def main():
     model = ModelBuilder(train=True, split="train", name="bench")
     model.build_model(suffix="_train")
     Engine.FORWARD_BRANCHES = not args.no_forward_branches
+    Engine.STEP_GRAPH = {"off": False, "step": True, "forward": "forward"}[args.graph]
     Engine.EAGER_SOLVER = {"after": False, "eager": True, "tail": "tail"}[args.solver]
     eng = Engine(model, args.dtype, device=device, base_seed=cfg.RNG_SEED, side_stream=not args.single_stream)
     rois = args.rois_per_clip if args.rois_per_clip > 0 else synth.rois_per_clip_draw(clips, seed=cfg.RNG_SEED + rank)
@@ -138,7 +142,8 @@ def main():
         if i == args.steps - 1:
             # HIP-event brackets around every GEMM launch of the last timed step, each on the stream the
             # launch goes to, in the normal two-stream schedule: the durations are the ones the step pays
-            # (and the ones a rocprofv3 kernel trace of this command reports)
+            # (and the ones a rocprofv3 kernel trace of this command reports).  Events cannot sit inside a
+            # replayed graph, so this one step is enqueued launch by launch -- inside the timed region.
             hip.PROFILE = []
         eng.train_step(lr)
     torch.cuda.synchronize()

@@ -269,6 +269,10 @@ int vlfb_layernorm_bwd(const void* dy, const void* y, const float* rstd, void* d
  * data is stored [(r*inner + k)*ch + c] (channels-last). */
 int vlfb_dropout_fwd(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows, int64_t inner,
                      int64_t ch, float ratio, uint64_t seed, vlfb_stream_t stream);
+/* the same with the seed read from device memory at run time: a step captured in a HIP graph replays
+ * the same launch packet every iteration, so per-iteration values cannot be kernel arguments */
+int vlfb_dropout_fwd_dev(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows, int64_t inner,
+                         int64_t ch, float ratio, const uint64_t* seed_dev, vlfb_stream_t stream);
 int vlfb_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dtype, int64_t n,
                      float ratio, vlfb_stream_t stream);
 
@@ -330,6 +334,12 @@ int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const 
  * ------------------------------------------------------------------------------------------ */
 int vlfb_sgd_update(float* p, float* g, float* m, int64_t n, float lr, float wd, float mu,
                     int nesterov, vlfb_stream_t stream);
+/* learning rate read from device memory (captured steps, see vlfb_dropout_fwd_dev) */
+int vlfb_sgd_update_dev(float* p, float* g, float* m, int64_t n, const float* lr_dev, float wd, float mu,
+                        int nesterov, vlfb_stream_t stream);
+/* dst[i] = values[i], i < n <= 8, in stream order; the values are copied into the launch packet before the
+ * call returns (per-iteration scalars of a captured step: learning rate bits, dropout seeds) */
+int vlfb_store_scalars(uint64_t* dst, int n, const uint64_t* values, vlfb_stream_t stream);
 int vlfb_scale_inplace(float* x, int64_t n, float s, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -95,7 +95,9 @@ __host__ __device__ __forceinline__ float dropout_uniform(uint64_t seed, uint64_
 template <typename T>
 __global__ void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                    uint8_t* __restrict__ mask, long long rows, long long inner,
-                                   long long ch, float ratio, unsigned long long seed) {
+                                   long long ch, float ratio, unsigned long long seed,
+                                   const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) seed = *seed_dev;     // captured step: the per-iteration seed lives in device memory
   const long long total = rows * inner * ch;
   const float keep_scale = 1.0f / (1.0f - ratio);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -448,7 +450,9 @@ __global__ void fbo_rowfix_kernel(float* __restrict__ s, const float* __restrict
 
 // ---- solver -------------------------------------------------------------------------------------
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                           long long n, float lr, float wd, float mu, int nesterov) {
+                           long long n, float lr, float wd, float mu, int nesterov,
+                           const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;           // captured step: the learning rate of the iteration lives in device memory
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float pi = p[i];
@@ -502,19 +506,31 @@ extern "C" int vlfb_layernorm_bwd(const void* dy, const void* y, const float* rs
   else return set_error(VLFB_ERR_ARG, "layernorm_bwd: bad dtype");
   return check_launch("layernorm_bwd");
 }
-extern "C" int vlfb_dropout_fwd(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows,
-                                int64_t inner, int64_t ch, float ratio, uint64_t seed,
-                                vlfb_stream_t stream) {
+static int dropout_fwd_any(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows, int64_t inner,
+                           int64_t ch, float ratio, uint64_t seed, const uint64_t* seed_dev,
+                           vlfb_stream_t stream) {
   VLFB_REQUIRE(x && y && mask && rows > 0 && inner > 0 && ch > 0, "dropout_fwd: bad args");
   VLFB_REQUIRE(ratio >= 0.f && ratio < 1.f, "dropout_fwd: ratio must be in [0,1)");
   int grid = grid_for(rows * inner * ch, 256);
   hipStream_t s = (hipStream_t)stream;
+  const unsigned long long* sd = (const unsigned long long*)seed_dev;
   if (dtype == VLFB_F32)
-    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed);
+    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed, sd);
   else if (is16(dtype))
-    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(dropout_fwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed));
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(dropout_fwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)x, (T16*)y, mask, (long long)rows, (long long)inner, (long long)ch, ratio, (unsigned long long)seed, sd));
   else return set_error(VLFB_ERR_ARG, "dropout_fwd: bad dtype");
   return check_launch("dropout_fwd");
+}
+extern "C" int vlfb_dropout_fwd(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows,
+                                int64_t inner, int64_t ch, float ratio, uint64_t seed,
+                                vlfb_stream_t stream) {
+  return dropout_fwd_any(x, y, mask, dtype, rows, inner, ch, ratio, seed, nullptr, stream);
+}
+extern "C" int vlfb_dropout_fwd_dev(const void* x, void* y, uint8_t* mask, int dtype, int64_t rows,
+                                    int64_t inner, int64_t ch, float ratio, const uint64_t* seed_dev,
+                                    vlfb_stream_t stream) {
+  VLFB_REQUIRE(seed_dev, "dropout_fwd_dev: null seed pointer");
+  return dropout_fwd_any(x, y, mask, dtype, rows, inner, ch, ratio, 0, seed_dev, stream);
 }
 extern "C" int vlfb_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dtype, int64_t n,
                                 float ratio, vlfb_stream_t stream) {
@@ -660,8 +676,31 @@ extern "C" int vlfb_sgd_update(float* p, float* g, float* m, int64_t n, float lr
                                int nesterov, vlfb_stream_t stream) {
   VLFB_REQUIRE(p && g && m && n > 0, "sgd_update: bad args");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                     (long long)n, lr, wd, mu, nesterov);
+                     (long long)n, lr, wd, mu, nesterov, (const float*)nullptr);
   return check_launch("sgd_update");
+}
+extern "C" int vlfb_sgd_update_dev(float* p, float* g, float* m, int64_t n, const float* lr_dev, float wd,
+                                   float mu, int nesterov, vlfb_stream_t stream) {
+  VLFB_REQUIRE(p && g && m && n > 0 && lr_dev, "sgd_update_dev: bad args");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     (long long)n, 0.f, wd, mu, nesterov, lr_dev);
+  return check_launch("sgd_update_dev");
+}
+// per-iteration scalars of a captured step (learning rate, dropout seeds): the values travel in the launch
+// packet, so the host may overwrite its copy at once, and land in device memory in stream order
+struct StepScalars { unsigned long long v[8]; };
+namespace vlfb { namespace {
+__global__ void store_scalars_kernel(unsigned long long* dst, int n, StepScalars s) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = s.v[threadIdx.x];
+}
+} }
+extern "C" int vlfb_store_scalars(uint64_t* dst, int n, const uint64_t* values, vlfb_stream_t stream) {
+  VLFB_REQUIRE(dst && values && n > 0 && n <= 8, "store_scalars: 1..8 values");
+  StepScalars s;
+  for (int i = 0; i < 8; ++i) s.v[i] = i < n ? values[i] : 0ull;
+  hipLaunchKernelGGL(store_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     (unsigned long long*)dst, n, s);
+  return check_launch("store_scalars");
 }
 extern "C" int vlfb_scale_inplace(float* x, int64_t n, float sc, vlfb_stream_t stream) {
   VLFB_REQUIRE(x && n > 0, "scale_inplace: bad args");

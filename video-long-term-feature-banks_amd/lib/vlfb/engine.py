@@ -20,6 +20,7 @@ group only.
 import ctypes as C
 import logging
 import math
+import struct
 from collections import OrderedDict
 
 import numpy as np
@@ -546,6 +547,10 @@ class DropoutStep(Step):
         self.inner = self.x.numel // (self.rows * self.ch)
 
     def fwd(self):
+        if self.eng._dev_scalars:      # captured step: the seed of the iteration is read from device memory
+            hip.call("vlfb_dropout_fwd_dev", self.x.ptr(), self.out.ptr(), hip.ptr(self.mask), self.eng.code,
+                     self.rows, self.inner, self.ch, self.ratio, hip.ptr(self.eng._scalars_dev) + 8 * self.seed_slot)
+            return
         seed = dropout_seed(self.eng.base_seed, self.out.name, self.eng.iteration, self.eng.replica)
         hip.call("vlfb_dropout_fwd", self.x.ptr(), self.out.ptr(), hip.ptr(self.mask), self.eng.code, self.rows,
                  self.inner, self.ch, self.ratio, seed)
@@ -718,6 +723,10 @@ class LossStep(Step):
                  self.scale)
         if self.dlogits is not None and self.eng.loss_scale != 1.0:
             hip.call("vlfb_scale_inplace", hip.ptr(self.dlogits), self.dlogits.numel(), self.eng.loss_scale)
+        if not self.eng._dev_scalars:  # (a captured step pushes after the replay: the ring position is host state)
+            self.ring_push()
+
+    def ring_push(self):
         if self.ring is not None:
             self.ring.narrow(0, self.ring_pos % LOSS_RING, 1).copy_(self.loss.root.tensor.narrow(0, 0, 1), non_blocking=True)
             self.ring_pos += 1
@@ -1202,6 +1211,12 @@ class Engine(object):
         self._eager_next = 0
         self._eager_done = False
         self.side_dirty = False
+        self._dev_scalars = False      # True while a step is being captured: per-iteration scalars come from memory
+        self._scalars_dev = None
+        self._graph = None
+        self._graph_key = None
+        self._graph_stream = None
+        self._eager_steps = 0
         model.engine = self
 
     # ---- side stream for parameter gradients ---------------------------------------------------
@@ -1297,6 +1312,11 @@ class Engine(object):
         if self.train:
             self._plan_solver_buckets()
         self._plan_forward_branches()
+        self._drop_steps = [st for st in self.steps if isinstance(st, DropoutStep)]
+        for k, st in enumerate(self._drop_steps):
+            st.seed_slot = 1 + k
+        if not self.dry_run:
+            self._scalars_dev = torch.zeros(1 + len(self._drop_steps), device=self.device, dtype=torch.int64)
         return self
 
     def _plan_params(self):
@@ -1764,14 +1784,23 @@ class Engine(object):
         sol = cfg.SOLVER
         S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
         for off, end, wd in b["wd"]:
-            hip.call("vlfb_sgd_update", hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off,
-                     hip.ptr(self.flat_mom) + 4 * off, end - off, lr / S, wd * S, float(sol.MOMENTUM),
-                     int(bool(sol.NESTEROV)))
+            self._sgd_launch(off, end, wd, lr)
         if b["wprep"] is not None:
             dev, n, tiles = b["wprep"]
             hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.code)
         for st in b["bias_steps"]:
             st.refresh_bias()
+
+    def _sgd_launch(self, off, end, wd, lr):
+        sol = cfg.SOLVER
+        S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
+        args = (hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off, hip.ptr(self.flat_mom) + 4 * off,
+                end - off)
+        if self._dev_scalars:                     # captured step: lr/S is slot 0 of the step scalars
+            hip.call("vlfb_sgd_update_dev", *args, hip.ptr(self._scalars_dev), wd * S, float(sol.MOMENTUM),
+                     int(bool(sol.NESTEROV)))
+        else:
+            hip.call("vlfb_sgd_update", *args, lr / S, wd * S, float(sol.MOMENTUM), int(bool(sol.NESTEROV)))
 
     def _plan_solver_buckets(self, bucket_mb=32):
         """buckets of the flat parameter buffer in backward-completion order (the all-reduce buckets), each with
@@ -1845,9 +1874,7 @@ class Engine(object):
         sol = cfg.SOLVER
         S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
         for off, end, wd in self.wd_ranges:       # one launch unless a trainable '_bn' parameter exists
-            hip.call("vlfb_sgd_update", hip.ptr(self.flat_param) + 4 * off, hip.ptr(self.flat_grad) + 4 * off,
-                     hip.ptr(self.flat_mom) + 4 * off, end - off, self.lr / S, wd * S, float(sol.MOMENTUM),
-                     int(bool(sol.NESTEROV)))
+            self._sgd_launch(off, end, wd, self.lr)
         self._pstate[0] += 1
         self.refresh_operands()
         self.iteration += 1
@@ -1861,13 +1888,89 @@ class Engine(object):
     # last wgrad of backward (the MFMA-bound stem wgrad leaves HBM idle): 440.5 vs 440.4 clips/s, no gain either.
     EAGER_SOLVER = False
 
+    # True: from its second call on, train_step() replays the whole step (forward, backward on both streams,
+    # solver, operand refresh) as ONE captured HIP graph; "forward": only the forward pass.  Nothing in the step
+    # depends on the host -- shapes, plans and buffers are fixed at plan() -- except the learning rate and the dropout
+    # seeds, which the captured kernels read from device memory (vlfb_store_scalars writes them in stream order before
+    # each replay).  Bit-identical to the stream path (tests/test_step_graph_gpu.py).
+    # OFF by default, because it measures slower on this runtime (ROCm 7.2, one MI355X, 8 clips, same box):
+    #   streams 18.80 ms | whole-step graph 20.27 ms | forward-only graph 18.84 ms
+    #   one stream only: streams 20.62 ms | graph 20.60 ms
+    # A chain of empty kernels dispatches in 1.7 us per node from a graph against 4.5 us from a stream
+    # (scratch/graph_probe.py), but behind real kernels the command processor already hides the dispatch of the next
+    # packet, so the one-stream step gains nothing; and the graph executor runs the forked branches (wgrads beside
+    # the dgrad chain) almost serially, which loses what the second stream buys.  The host is not the limit either:
+    # enqueuing a step takes ~6 ms of the 18.8 ms it runs.  Data-parallel steps (collectives inside backward) and
+    # profiled steps (hip.PROFILE) always use the stream path.
+    STEP_GRAPH = False
+
     def train_step(self, lr=None):
-        self.forward()
         if lr is not None:
             self.lr = float(lr)
+        if self.STEP_GRAPH and self.comm is None and hip.PROFILE is None and self._eager_steps >= 1 and \
+                not self.dry_run:
+            if self.STEP_GRAPH == "forward":
+                self._graph_replay("forward")
+                self._backward_and_solve()
+                return
+            return self._graph_replay("step")
+        self._train_step_streams()
+        self._eager_steps += 1
+
+    def _backward_and_solve(self):
         self._eager_lr = self.lr if self.EAGER_SOLVER else None
         try:
             self.backward()
         finally:
             self._eager_lr = None
         self.sgd_step()
+
+    def _train_step_streams(self):
+        self.forward()
+        self._backward_and_solve()
+
+    def _store_step_scalars(self):
+        """learning rate (fp32 bits, already divided by the loss scale) and the dropout seeds of this iteration"""
+        vals = [struct.unpack("<I", struct.pack("<f", self.lr / self.loss_scale))[0]]
+        vals += [dropout_seed(self.base_seed, st.out.name, self.iteration, self.replica) for st in self._drop_steps]
+        for c in range(0, len(vals), 8):
+            chunk = vals[c:c + 8]
+            arr = (C.c_uint64 * len(chunk))(*chunk)
+            hip.call("vlfb_store_scalars", hip.ptr(self._scalars_dev) + 8 * c, len(chunk), arr)
+
+    def _capture_step(self, key, scope):
+        losses = [st for st in self.steps if isinstance(st, LossStep)]
+        saved = (self.iteration, self._pstate[0], self._operand_version, [st.ring_pos for st in losses])
+        if self._graph_stream is None:
+            self._graph_stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self._dev_scalars = True
+        try:
+            with torch.cuda.graph(graph, stream=self._graph_stream):
+                if scope == "forward":
+                    self.forward()
+                else:
+                    self._train_step_streams()
+        finally:
+            self._dev_scalars = False
+        # capturing enqueues nothing: undo the host-side bookkeeping of the pass
+        self.iteration, self._pstate[0], self._operand_version = saved[0], saved[1], saved[2]
+        for st, pos in zip(losses, saved[3]):
+            st.ring_pos = pos
+        self._graph, self._graph_key, self._graph_losses = graph, key, losses
+
+    def _graph_replay(self, scope):
+        if self._operand_version != self._pstate[0]:
+            self.refresh_operands(all_params=True)
+        key = (scope, self.EAGER_SOLVER, self.FORWARD_BRANCHES)
+        if self._graph is None or self._graph_key != key:
+            self._capture_step(key, scope)
+        self._store_step_scalars()
+        self._graph.replay()
+        for st in self._graph_losses:
+            st.ring_push()
+        if scope == "step":
+            self._pstate[0] += 1
+            self._operand_version = self._pstate[0]
+            self.iteration += 1

@@ -115,6 +115,7 @@ _SIGS = {
     "vlfb_layernorm_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _P]),
     "vlfb_dropout_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, _I64, C.c_float, C.c_uint64, _P]),
+    "vlfb_dropout_fwd_dev": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, _I64, C.c_float, _P, _P]),
     "vlfb_dropout_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, C.c_float, _P]),
     "vlfb_fc_fwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _I64, _I64, _I64, _P]),
     "vlfb_fc_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, _P]),
@@ -128,6 +129,8 @@ _SIGS = {
     "vlfb_fbo_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64,
                                     C.c_float, _P]),
     "vlfb_sgd_update": (C.c_int, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+    "vlfb_sgd_update_dev": (C.c_int, [_P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_int, _P]),
+    "vlfb_store_scalars": (C.c_int, [_P, C.c_int, _P, _P]),
     "vlfb_scale_inplace": (C.c_int, [_P, _I64, C.c_float, _P]),
     "vlfb_clip_preprocess": (C.c_int, [C.POINTER(ClipDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vlfb_lfb_bank_bytes": (_I64, [C.POINTER(LfbDesc)]),
