@@ -278,6 +278,8 @@ POOLS = {
     "nlpool": ((1, 2, 2), (1, 2, 2), (0, 0, 0), (2, 2, 6, 6)),    # nonlocal_helper.py:48-54
     "other_window": ((1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 7, 7)),   # not a compiled window shape: the generic backward kernel
     "pool1_ragged": ((1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 2, 14, 10)),  # even extents: the last window column / row is cut
+    "pool1_bands": ((1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 3, 29, 23)),   # five bands of six input rows, the last one cut
+    "pool1_nopad": ((1, 3, 3), (1, 2, 2), (0, 0, 0), (1, 2, 15, 13)),   # pads 0 as resnet_video.py:190-196 writes them
 }
 
 
@@ -303,6 +305,9 @@ def test_maxpool_fwd_bwd(name, dtype):
     (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
     add = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
     DX = torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype)
+    # no residual operand, no mask (pool1 windows: the band kernel with the pooled rows staged in LDS)
+    hip.call("vlfb_maxpool_bwd", C.byref(d), gp(to_nthwc(dy), dtype), hip.ptr(AM), hip.ptr(DX), None, None)
+    assert rel_err(to_ncthw(DX.float()), gx) < TOL[dtype]
     hip.call("vlfb_maxpool_bwd", C.byref(d), gp(to_nthwc(dy), dtype), hip.ptr(AM), hip.ptr(DX),
              gp(to_nthwc(add), dtype), hip.ptr(X))
     ref = torch.where(x.double() > 0, gx + add.double(), torch.zeros_like(gx))

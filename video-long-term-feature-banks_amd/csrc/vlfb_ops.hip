@@ -457,6 +457,123 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
   }
 }
 
+// pool1 (1x3x3 windows, stride 1x2x2): overlapping windows, so the row kernel above reads every pooled row for up to
+// three input rows (PMC: 762 MB fetched for 257 MB of pooled gradient / arg-max / pooled output at 8 clips).  Here a
+// workgroup owns a band of 2R input rows of one frame: the R + 2 pooled rows the band can touch are staged in LDS once
+// -- the gradient already masked by the pooled output's sign, the arg-max bytes beside it -- and every input position
+// then sums its (at most 2 x 2) candidate windows out of LDS, in the order of the kernels above (windows ascending in h,
+// then w), so the bits are the same.  Pooled rows are read (R + 2) / R times per 2R input rows instead of 3 times per 2.
+template <typename T, bool YMASK>
+__global__ __launch_bounds__(256) void maxpool_bwd_band_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                               T* dx, const T* add, const T* __restrict__ mask, PoolP p,
+                                                               const T* __restrict__ ymask, int R, int bands) {
+  constexpr int V = Vec16<T>::N;                      // elements per 16 bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
+  const int cch = p.C / V;
+  const int NR = R + 2;
+  const int rowv = p.Wo * cch;                        // 16-byte vectors per pooled row
+  uint4* g_l = reinterpret_cast<uint4*>(band_lds);
+  unsigned char* t_l = band_lds + (size_t)NR * rowv * 16;
+  const int band = blockIdx.x % bands, frame = blockIdx.x / bands;       // frame = n * Ti + ti  (kt = st = 1, pt = 0)
+  const int h0 = band * 2 * R;
+  const int hb = (h0 + p.ph) / 2 - 1;                 // first pooled row staged
+  for (int i = threadIdx.x; i < NR * rowv; i += 256) {
+    const int r = i / rowv, ho = hb + r;
+    uint4 g = make_uint4(0u, 0u, 0u, 0u);
+    uint2 tp = make_uint2(0xffffffffu, 0xffffffffu);
+    if (ho >= 0 && ho < p.Ho) {
+      const long long o = ((long long)(frame * p.Ho + ho) * rowv + (i - r * rowv)) * V;
+      g = *reinterpret_cast<const uint4*>(dy + o);
+      tp = V == 8 ? *reinterpret_cast<const uint2*>(argmax + o) : make_uint2(*reinterpret_cast<const uint32_t*>(argmax + o), 0u);
+      if (YMASK) {
+        const uint4 yq = *reinterpret_cast<const uint4*>(ymask + o);
+        float yv[V];
+        unpack_vec<T>(yq, yv);
+        uint32_t w[4] = {g.x, g.y, g.z, g.w};
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = yv[k % V] > 0.f ? w[k] : 0u;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            w[k] = (yv[(2 * k) % V] > 0.f ? (w[k] & 0xffffu) : 0u) | (yv[(2 * k + 1) % V] > 0.f ? (w[k] & 0xffff0000u) : 0u);
+        }
+        g = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    g_l[i] = g;
+    if (V == 8) *reinterpret_cast<uint2*>(t_l + (size_t)i * 8) = tp;
+    else *reinterpret_cast<uint32_t*>(t_l + (size_t)i * 4) = tp.x;
+  }
+  __syncthreads();
+  const int rows = min(2 * R, p.Hi - h0);
+  const int rowi = p.Wi * cch;                        // items per input row
+  for (int it = threadIdx.x; it < rows * rowi; it += 256) {
+    const int hr = it / rowi, rem = it - hr * rowi;
+    const int wi = rem / cch, cc = rem - wi * cch;
+    const int hi = h0 + hr;
+    const int ho_hi = (hi + p.ph) / 2, wo_hi = (wi + p.pw) / 2;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int jh = 1; jh >= 0; --jh) {
+      const int ho = ho_hi - jh, b = hi + p.ph - ho * 2;
+      const bool okh = ho >= 0 && ho < p.Ho && b < 3;
+      const int lr = okh ? ho - hb : 0;
+#pragma unroll
+      for (int jw = 1; jw >= 0; --jw) {
+        const int wo = wo_hi - jw, c = wi + p.pw - wo * 2;
+        const bool ok = okh && wo >= 0 && wo < p.Wo && c < 3;
+        const int idx = ok ? (lr * p.Wo + wo) * cch + cc : cc;
+        const int tap = ok ? b * 3 + c : 255;
+        const uint4 gq = g_l[idx];
+        uint2 aq;
+        if (V == 8) aq = *reinterpret_cast<const uint2*>(t_l + (size_t)idx * 8);
+        else aq = make_uint2(*reinterpret_cast<const uint32_t*>(t_l + (size_t)idx * 4), 0u);
+        // keep the elements whose arg-max byte equals this tap, on the packed words: bytes of (arg-max ^ tap) that
+        // are zero -> 0xff, widened to the element width by a byte permute, AND-ed onto the gradient bits (a dropped
+        // element adds +0.0f exactly like the select of the kernels above)
+        const uint32_t tapw = (uint32_t)tap * 0x01010101u;
+        uint32_t fullb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t t = (q ? aq.y : aq.x) ^ tapw;
+          const uint32_t nz = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;     // 0x80 where the byte differs
+          fullb[q] = ((nz ^ 0x80808080u) >> 7) * 0xffu;                                   // 0xff where it matches
+        }
+        uint32_t w[4] = {gq.x, gq.y, gq.z, gq.w};
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] &= __builtin_amdgcn_perm(fullb[0], fullb[0], 0x01010101u * (uint32_t)k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            w[k] &= __builtin_amdgcn_perm(fullb[k >> 1], fullb[k >> 1], (k & 1) ? 0x03030202u : 0x01010000u);
+        }
+        float g[V];
+        unpack_vec<T>(make_uint4(w[0], w[1], w[2], w[3]), g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += g[k];
+      }
+    }
+    const long long off = (((long long)frame * p.Hi + hi) * p.Wi + wi) * p.C + cc * V;
+    if (add) {
+      float a2[V];
+      Vec16<T>::load(add + off, a2);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += a2[k];
+    }
+    if (mask) {
+      float mk[V];
+      Vec16<T>::load(mask + off, mk);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] = mk[k] > 0.f ? acc[k] : 0.f;
+    }
+    Vec16<T>::store(dx + off, acc);
+  }
+}
+
 // launches the fixed-shape kernel when the window is one of the compiled shapes (one-byte arg-max); false = use the generic one
 template <typename T>
 bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax, void* dx, const void* add, const void* mask,
@@ -464,6 +581,29 @@ bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax
   const long long rows = (long long)p.N * p.Ti * p.Hi;
   if (rows >= (1ll << 31) || (long long)p.N * p.To * p.Ho * p.Wo >= (1ll << 31)) return false;
   const dim3 grid((unsigned)rows), block(128);
+  // (with a residual operand and a ReLU mask streamed beside it the row kernel is the faster one: 271 vs 357 us)
+  if (p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 2 && p.sw == 2 && p.pt == 0 && p.To == p.Ti && !add &&
+      !mask) {
+    // band kernel: as many input-row pairs per workgroup as 64 KB of LDS hold pooled rows for (R + 2 rows staged)
+    const long long row_bytes = (long long)p.Wo * p.C * (sizeof(T) + 1);
+    // R = 3: measured 226 us at R = 2 and 3, 259 us at R = 4 (two 64 KB workgroups per CU leave the load and the store
+    // phases of a CU unbalanced) against 285 us for the row kernel, pool1 of the 8-clip step in isolation
+    const int R = (int)std::min<long long>(3, 65536 / row_bytes - 2);
+    if (R >= 2) {
+      const int bands = (p.Hi + 2 * R - 1) / (2 * R);
+      const long long wgs = (long long)p.N * p.Ti * bands;
+      const size_t lds = (size_t)(R + 2) * row_bytes;
+      if (wgs < (1ll << 31)) {
+        if (ymask)
+          hipLaunchKernelGGL((maxpool_bwd_band_kernel<T, true>), dim3((unsigned)wgs), dim3(256), lds, s, (const T*)dy,
+                             (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p, (const T*)ymask, R, bands);
+        else
+          hipLaunchKernelGGL((maxpool_bwd_band_kernel<T, false>), dim3((unsigned)wgs), dim3(256), lds, s, (const T*)dy,
+                             (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p, (const T*)ymask, R, bands);
+        return true;
+      }
+    }
+  }
 #define VLFB_POOL_FIXED(KT_, KH_, KW_, ST_, SH_, SW_)                                                                      \
   if (p.kt == KT_ && p.kh == KH_ && p.kw == KW_ && p.st == ST_ && p.sh == SH_ && p.sw == SW_) {                           \
     if (ymask)                                                                                                           \
