@@ -55,6 +55,10 @@ int launch_wgrad_rows(const GP& gp, int splits, size_t lds, int dtype, hipStream
 // fat-input variant: 256 -> 64 channels, 3x1x1 (the gradient rows are shifted, the 512-byte input rows read once)
 int launch_wgrad_rows_fat(const GP& gp, int splits, int dtype, hipStream_t s);
 
+// vlfb_stem.hip: direct-convolution FPROP of the packed stem (whole output rows per wave, raw input rows in LDS)
+bool stem_fprop_ok(const GP& gp, int pack_w, int dtype, int out_dtype, long long batch);
+int launch_stem_fprop(const GP& gp, int dtype, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
