@@ -59,6 +59,7 @@ struct Case {
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
   const char* only = argc > 2 ? argv[2] : nullptr;
+  const int second_algo = argc > 3 ? atoi(argv[3]) : 3;      // 3 = STREAM, 0 = AUTO (whatever the library picks)
   std::vector<Case> cases = {
     // res2 (8 clips: 32 x 56 x 56 per clip)
     {"res2 2c 64->256 +R relu", 0, 8, 32, 56, 56, 32, 56, 56, 64, 256, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 7},
@@ -134,7 +135,7 @@ int main(int argc, char** argv) {
     float t[3] = {0, 0, 0};
     bool ok256 = true;
     for (int algo = 1; algo <= 2; ++algo) {
-      d.algo = algo == 1 ? 1 : 3;
+      d.algo = algo == 1 ? 1 : second_algo;
       char* O = algo == 1 ? O1 : O2;
       if (wg) {
         const long long need = vlfb_conv_workspace_bytes(&d);

@@ -1020,6 +1020,7 @@ struct Plan {
   int nt8_bm;     //     rows per tile: 256 or 196
   int nt8_mode;   //     0 plain rows, 1 gathered FPROP, 2 gathered unit-stride DGRAD
   int nts;        // NT: weight-resident streaming kernel (vlfb_gemm_s.hip); nts_mode as nt8_mode
+  int rows64;     // FPROP / unit-stride DGRAD of 1x3x3 64 -> 64 convs: direct-convolution kernel (vlfb_conv_rows.hip)
   int stemf;      // FPROP of the packed stem: direct-convolution kernel (vlfb_stem.hip) when the call has no residual / mask
   int nts_mode;
   size_t stem_lds;
@@ -1291,6 +1292,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->stemf = d->mode == VLFB_CONV_FPROP && pl->packw && d->algo == VLFB_ALGO_AUTO &&
               (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
               stem_fprop_ok(g, d->pack_w, d->dtype, d->out_dtype, batch);
+  pl->rows64 = d->mode != VLFB_CONV_WGRAD && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO &&
+               (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
+               conv_rows64_ok(g, d->mode, d->dtype, d->out_dtype, batch);
   pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
   pl->pre = 0;
   pl->threads = kThreads;
@@ -1403,6 +1407,7 @@ int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
       return check_launch("conv wgrad (tr) kernel");
     }
     if (d->mode == VLFB_CONV_FPROP && pl.stemf && !pl.gp.R && !pl.gp.Mask) return launch_stem_fprop(pl.gp, d->dtype, s);
+    if (d->mode != VLFB_CONV_WGRAD && pl.rows64) return launch_conv_rows64(pl.gp, d->mode, d->dtype, s);
     if (d->mode != VLFB_CONV_WGRAD && pl.nts) return launch_nts(pl.gp, pl.nts_mode, d->dtype, s);
     if (d->mode != VLFB_CONV_WGRAD && pl.nt8)
       return launch_nt8(pl.gp, pl.nt8_bm, pl.nt8, pl.nt8_mode, d->dtype, sizeof(OutT) == 4,

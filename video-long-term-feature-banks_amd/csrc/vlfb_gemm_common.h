@@ -59,6 +59,11 @@ int launch_wgrad_rows_fat(const GP& gp, int splits, int dtype, hipStream_t s);
 bool stem_fprop_ok(const GP& gp, int pack_w, int dtype, int out_dtype, long long batch);
 int launch_stem_fprop(const GP& gp, int dtype, hipStream_t s);
 
+// vlfb_conv_rows.hip: direct-convolution FPROP / unit-stride DGRAD of 1x3x3 convs with 64 -> 64 channels (weights
+// resident in LDS, input rows rolling through a ring); mode = VLFB_CONV_FPROP | VLFB_CONV_DGRAD
+bool conv_rows64_ok(const GP& gp, int mode, int dtype, int out_dtype, long long batch);
+int launch_conv_rows64(const GP& gp, int mode, int dtype, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
