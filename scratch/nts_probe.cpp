@@ -79,6 +79,11 @@ int main(int argc, char** argv) {
     {"res3_0 2b 3x3 s2 128->128", 0, 8, 16, 28, 28, 16, 56, 56, 128, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1, 1, 1, 6},
     // res4 (16 x 14 x 14): weights that still fit
     {"res4 2c dgrad 1024->256 (no)", 1, 8, 16, 14, 14, 16, 14, 14, 1024, 256, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 8},
+    // stride-2 dgrads (rows = conv input positions)
+    {"s2 res3_0 2b 3x3 dgrad mask", 1, 8, 16, 56, 56, 16, 28, 28, 128, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1, 1, 1, 8},
+    {"s2 res3_0 b1 dgrad 512->256 +R", 1, 8, 16, 56, 56, 16, 28, 28, 512, 256, 1, 1, 1, 1, 2, 2, 0, 0, 0, 1, 1, 1},
+    {"s2 res4_0 2b 3x3 dgrad mask", 1, 8, 16, 28, 28, 16, 14, 14, 256, 256, 1, 3, 3, 1, 2, 2, 0, 1, 1, 1, 1, 8},
+    {"s2 res4_0 b1 dgrad 1024->512 +R", 1, 8, 16, 28, 28, 16, 14, 14, 1024, 512, 1, 1, 1, 1, 2, 2, 0, 0, 0, 1, 1, 1},
     {"nl3 g/phi 512->256 pooled", 0, 8, 16, 14, 14, 16, 14, 14, 512, 128, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 4},
   };
   hipStream_t s;

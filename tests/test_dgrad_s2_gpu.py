@@ -1,0 +1,63 @@
+"""DGRAD of the (1, 2, 2)-strided 1x3x3 convolutions (res3_0 / res4_0 branch2b, resnet_helper.py:35-119).  An input position only meets the taps of its own (h, w) parity, so the tiled kernel
+enumerates its rows parity class by parity class and a tile walks only the taps of its class (csrc/vlfb_gemm.hip,
+GP::s2) instead of multiplying structural zeros.  The taps that remain are walked in the order of the full walk, so
+the result must be BIT-IDENTICAL to the plain enumeration (algo = TILE128), for every epilogue (residual, mask,
+both, alpha), bf16 / fp16 / fp32, and match fp64 autograd."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import dev, q, rel_err, to_ncthw, to_nthwc
+
+pytestmark = pytest.mark.gpu
+
+# name: (N, Cin, Cout, T, H, W, k, pad)      (stride (1, 2, 2) always; H, W even)
+CASES = {
+    "conv3x3": (2, 128, 128, 2, 12, 20, (1, 3, 3), (0, 1, 1)),
+    "conv1x3": (1, 128, 64, 3, 10, 14, (1, 1, 3), (0, 0, 1)),            # one strided dimension with a single tap row
+    "conv3x3_64": (1, 64, 64, 1, 34, 18, (1, 3, 3), (0, 1, 1)),          # several row tiles per class
+    "temporal_3x3x3": (1, 64, 128, 4, 8, 8, (3, 3, 3), (1, 1, 1)),       # a temporal extent beside the strided dims
+}
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_class_major_strided_dgrad_is_bit_identical_and_matches_fp64(case, tdt):
+    from vlfb import hip
+    hip.lib()
+    hdt = hip.dtype_code(tdt)
+    tol = {torch.bfloat16: 1e-2, torch.float16: 2e-3, torch.float32: 2e-5}[tdt]
+    N, Cin, Cout, T, H, W, k, p = CASES[case]
+    s, d = (1, 2, 2), (1, 1, 1)
+    gen = torch.Generator().manual_seed(sum(map(ord, case)))
+    x = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    w = q(torch.randn(Cout, Cin, *k, generator=gen) / math.sqrt(Cin * k[0] * k[1] * k[2]), tdt)
+    To, Ho, Wo = [(a + 2 * pp - (kk - 1) - 1) // ss + 1 for a, kk, ss, pp in zip((T, H, W), k, s, p)]
+    dy = q(torch.randn(N, Cout, To, Ho, Wo, generator=gen), tdt)
+    mask_src = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    add_src = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    G = to_nthwc(dy).to(dev(), tdt)
+    Wd = w.permute(1, 2, 3, 4, 0).contiguous().to(dev(), tdt)
+    Rm, Mm = to_nthwc(add_src).to(dev(), tdt), to_nthwc(mask_src).to(dev(), tdt)
+    geom = dict(kt=k[0], kh=k[1], kw=k[2], st=1, sh=2, sw=2, pt=p[0], ph=p[1], pw=p[2], dt=1, dh=1, dw=1)
+    view = torch.int16 if tdt != torch.float32 else torch.int32
+    got = {}
+    for algo in (hip.ALGO_TILE128, hip.ALGO_AUTO):
+        outs = []
+        for kw in (dict(R=Rm, mask=Mm), dict(R=Rm), dict(mask=Mm), dict()):
+            DX = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt)
+            desc = hip.conv_desc(mode=hip.DGRAD, dtype=hdt, out_dtype=hdt, N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo,
+                                 Cs=Cout, Cn=Cin, alpha=0.5 if not kw else 1.0, algo=algo, **geom)
+            hip.conv_run(desc, G, Wd, None, DX, **kw)
+            torch.cuda.synchronize()
+            outs.append(DX)
+        got[algo] = outs
+    for a, b in zip(got[hip.ALGO_AUTO], got[hip.ALGO_TILE128]):
+        assert not torch.isnan(a.float()).any()
+        assert torch.equal(a.view(view), b.view(view))
+    xd = x.double().requires_grad_(True)
+    gx, = torch.autograd.grad(F.conv3d(xd, w.double(), None, s, p, d), xd, dy.double())
+    assert rel_err(to_ncthw(got[hip.ALGO_AUTO][0].float()), torch.where(mask_src.double() > 0, gx + add_src.double(), torch.zeros_like(gx))) < tol
+    assert rel_err(to_ncthw(got[hip.ALGO_AUTO][3].float()), 0.5 * gx) < tol

@@ -35,6 +35,11 @@ struct GP {
   unsigned a_bytes, b_bytes;   // NT: extent of one batch element of A / B (buffer descriptors)
   int vec_epi;        // NT: LDS-staged, fully coalesced epilogue is legal for this problem
   int epi;            // NT: the fp32 tile is staged through LDS in this many passes (1 or 2)
+  // NT DGRAD with stride (1, 2, 2): rows are enumerated parity class by parity class ((h & 1, w & 1), each class in
+  // (n, t, h / 2, w / 2) order), so a tile holds one class and only walks the taps that class can reach
+  int s2;             // 1: class-major rows
+  int s2_mq;          // rows per class (M / 4)
+  int s2_tpc;         // row tiles per class
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered
