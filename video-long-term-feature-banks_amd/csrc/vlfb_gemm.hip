@@ -1175,7 +1175,8 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // Measured at 8 clips (scratch/nts_probe.cpp): res3_0 2b 161 -> 110 us, res4_0 2b 156 -> 95 us.  NOT for the 1x1x1
     // shortcuts, where one class would do the whole GEMM and the other three only the epilogue: their residual /
     // output rows are then visited as 256-byte pieces of four different passes over the tensor instead of one
-    // stream (198 -> 248 us, 153 -> 175 us), and those launches are bound by exactly that traffic.
+    // stream (198 -> 248 us, 153 -> 175 us).  Classes over h only (odd lines epilogue-only, as whole contiguous lines) are
+    // no better (246 / 167 us): a tile without a k-loop has nothing to hide its residual loads behind.
     if (d->mode == VLFB_CONV_DGRAD && d->algo == VLFB_ALGO_AUTO && !pl->ident && !pl->packw && batch == 1 && d->kh * d->kw > 1 &&
         d->st == 1 && d->sh == 2 && d->sw == 2 && d->dt == 1 && d->dh == 1 && d->dw == 1 && d->Hr % 2 == 0 &&
         d->Wr % 2 == 0 && ((long long)d->Cs * es) % 128 == 0 && d->bias_mode == VLFB_BIAS_NONE) {
