@@ -16,16 +16,21 @@ from gpu_util import dev, q, rel_err, to_ncthw, to_nthwc, w_to_kernel
 
 pytestmark = pytest.mark.gpu
 
-K, S, P, D = (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)
-GEOM = dict(kt=1, kh=3, kw=3, st=1, sh=1, sw=1, pt=0, ph=1, pw=1, dt=1, dh=1, dw=1)
-# name: (N, T, H, W)
+S, D = (1, 1, 1), (1, 1, 1)
+SPATIAL = ((1, 3, 3), (0, 1, 1))       # res2 branch2b
+TEMPORAL = ((3, 1, 1), (1, 0, 0))      # res2_0 branch2a: the same walk with t in the role of h
+# name: (N, T, H, W, (kernel, pad))
 CASES = {
-    "res2_row": (1, 2, 9, 56),          # 56-wide rows (three and a half fragments), cut last step
-    "widest": (1, 1, 6, 62),            # the widest row the 64-pixel pitch holds
-    "narrow": (2, 3, 4, 7),             # less than one fragment per row, exactly one step per frame
-    "tall": (1, 1, 23, 14),             # six steps: the ring wraps twice
-    "one_row": (3, 2, 1, 20),           # frames of a single row
-    "many_frames": (2, 150, 5, 16),     # 300 frames: several frames per workgroup
+    "res2_row": (1, 2, 9, 56, SPATIAL),          # 56-wide rows (three and a half fragments), cut last step
+    "widest": (1, 1, 6, 62, SPATIAL),            # the widest row the 64-pixel pitch holds
+    "narrow": (2, 3, 4, 7, SPATIAL),             # less than one fragment per row, exactly one step per frame
+    "tall": (1, 1, 23, 14, SPATIAL),             # six steps: the ring wraps twice
+    "one_row": (3, 2, 1, 20, SPATIAL),           # frames of a single row
+    "many_frames": (2, 150, 5, 16, SPATIAL),     # 300 frames: several frames per workgroup
+    "temporal_res2_row": (1, 9, 3, 56, TEMPORAL),      # t walks, cut last step
+    "temporal_long": (2, 23, 2, 14, TEMPORAL),         # six steps along t
+    "temporal_many_slabs": (3, 5, 110, 16, TEMPORAL),  # 330 (n, h) slabs: several per workgroup
+    "temporal_single_frame": (1, 1, 4, 20, TEMPORAL),  # T = 1: both temporal neighbours are padding
 }
 
 
@@ -36,13 +41,14 @@ def test_direct_rows_kernel_is_bit_identical_to_tile128_and_matches_fp64(case, t
     hip.lib()
     hdt = hip.BF16 if tdt == torch.bfloat16 else hip.F16
     tol = 1e-2 if tdt == torch.bfloat16 else 2e-3
-    if tdt == torch.float16 and case not in ("res2_row", "tall"):
+    if tdt == torch.float16 and case not in ("res2_row", "tall", "temporal_long"):
         pytest.skip("fp16 instances are the same template: a subset is enough")
-    N, T, H, W = CASES[case]
+    N, T, H, W, (K, P) = CASES[case]
+    GEOM = dict(kt=K[0], kh=K[1], kw=K[2], st=1, sh=1, sw=1, pt=P[0], ph=P[1], pw=P[2], dt=1, dh=1, dw=1)
     C = 64
     gen = torch.Generator().manual_seed(sum(map(ord, case)))
     x = q(torch.randn(N, C, T, H, W, generator=gen), tdt)
-    w = q(torch.randn(C, C, *K, generator=gen) / math.sqrt(C * 9), tdt)
+    w = q(torch.randn(C, C, *K, generator=gen) / math.sqrt(C * K[0] * K[1] * K[2]), tdt)
     bias = torch.randn(C, generator=gen)
     res = q(torch.randn(N, C, T, H, W, generator=gen), tdt)
     A = to_nthwc(x).to(dev(), tdt)

@@ -29,12 +29,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_r;
 constexpr int kRowsStep = 4;          // output rows per step
 constexpr int kRing = 10;             // input-row slots: 6 live + 4 arriving
 constexpr int kRowPitch = 8192;       // 64 pixels x 128 B
-constexpr int kWBytes = 18 * 4096;    // 18 k-steps x 64 channels x 64 B
 
-template <typename T, bool DG>
+// TM = false: 1x3x3 (frames = (n, t), rows = h, taps reach rows h - 1 .. h + 1 and pixels w - 1 .. w + 1).
+// TM = true: 3x1x1 (res2_0 branch2a): the same walk with the roles turned -- "frames" = (n, h), "rows" = t, the three
+// taps reach rows t - 1 .. t + 1 of the same pixel; consecutive rows are a whole frame apart in memory.
+template <typename T, bool DG, bool TM>
 __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int nframes, const int fpw) {
   typedef typename V16<T>::V vec_t;
   constexpr int MT = 4;
+  constexpr int NKS = TM ? 6 : 18;      // k-steps: taps x 2 halves of the 64 input channels
+  constexpr int kWBytes = NKS * 4096;   // NKS k-steps x 64 channels x 64 B
+  const int nrow = TM ? p.Tr : p.Hr;    // rows a frame has (source and output: same-size convs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
   {
     const unsigned wbase = lds_addr_of(smem);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {                       // 18 * 256 pieces / 512 threads
+    for (int i = 0; i < NKS / 2; ++i) {                 // NKS * 256 pieces / 512 threads
       const int id = tid + 512 * i;
       const int chunk = id & 3, r = (id >> 2) & 63, ks = id >> 8;
       const int c = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
@@ -73,8 +78,10 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
   const unsigned ring_base = lds_addr_of(ring);
   const int rowbytes = p.Ws * p.lda * 2;                // one source row
   auto load_row = [&](int frame, int i) {               // input row i of the frame (any integer) -> slot (i + 1) % 10
-    const bool ok = dpx && (unsigned)i < (unsigned)p.Hs && frame < nframes;
-    const unsigned off = ok ? (unsigned)((frame * p.Hs + i) * rowbytes) + dsrc : kOOB;
+    const bool ok = dpx && (unsigned)i < (unsigned)nrow && frame < nframes;
+    // spatial: row i of frame (n, t) = line (n * T + t) * H + i; temporal: row t = i of "frame" (n, h) = line (n * T + i) * H + h
+    const int line = TM ? ((frame / p.Hs) * p.Ts + i) * p.Hs + frame % p.Hs : frame * p.Hs + i;
+    const unsigned off = ok ? (unsigned)(line * rowbytes) + dsrc : kOOB;
     const int slot = (i + 1 + kRing) % kRing;
     bufglds16_hidden(rsX, off, 0u, (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_base + slot * kRowPitch + wave * 1024)));
   };
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
   // weights: fragment j of this wave's channel half = LDS rows wq*32 + j*16 + l15
   const int w_lane = (wq * 32 + l15) * 64 + ((g ^ ((0 - (l15 >> 2)) & 3)) << 4);
 
-  const int steps = (p.Hr + kRowsStep - 1) / kRowsStep;
+  const int steps = (nrow + kRowsStep - 1) / kRowsStep;
   const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int f_beg = wg * fpw, f_end = min(nframes, f_beg + fpw);
 
@@ -100,12 +107,12 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
       // residual / mask rows of this wave's outputs: requested now, used after the MFMAs (an absent operand is read
       // at the out-of-range offset: zeros, no memory access, no branch around the loads)
       const int h = h0 + wr;
-      const int row0 = (frame * p.Hr + h) * p.Wr;
+      const int row0 = (TM ? ((frame / p.Hr) * p.Tr + h) * p.Hr + frame % p.Hr : frame * p.Hr + h) * p.Wr;
       u32x4_r rq[MT], mq[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int w = m * 16 + l15;
-        const unsigned ro = (w < p.Wr && h < p.Hr) ? (unsigned)((row0 + w) * p.ldr + wq * 32 + g * 8) * 2u : kOOB;
+        const unsigned ro = (w < p.Wr && h < nrow) ? (unsigned)((row0 + w) * p.ldr + wq * 32 + g * 8) * 2u : kOOB;
         rq[m] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)(hasR ? ro : kOOB), 0, 0);
         mq[m] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (int)(hasM ? ro : kOOB), 0, 0);
       }
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
       // k-step ks = tap * 2 + half, tap = b * 3 + c: input row h0 + wr + (DG ? 1 - b : b - 1), pixel slot w + (DG ? 2 - c : c)
       vec_t wf[2][2], af[2][MT];
       auto read_step = [&](int ks, vec_t (&w)[2], vec_t (&x)[MT]) {
-        const int tap = ks >> 1, hf = ks & 1, b = tap / 3, c = tap - b * 3;
-        const int ib = DG ? 2 - b : b, ic = DG ? 2 - c : c;
+        const int tap = ks >> 1, hf = ks & 1, b = TM ? tap : tap / 3, c = TM ? 1 : tap - b * 3;
+        const int ib = DG ? 2 - b : b, ic = TM ? 1 : (DG ? 2 - c : c);
         const int slot = (h0 + wr + ib) % kRing;          // row h0 + wr + ib - 1  ->  slot (row + 1) % 10
         const char* row = ring + slot * kRowPitch;
 #pragma unroll
@@ -133,21 +140,22 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
       };
       read_step(0, wf[0], af[0]);
 #pragma unroll
-      for (int ks = 0; ks < 18; ++ks) {
-        if (ks + 1 < 18) read_step(ks + 1, wf[(ks + 1) & 1], af[(ks + 1) & 1]);
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) read_step(ks + 1, wf[(ks + 1) & 1], af[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[m][j] = V16<T>::mma(wf[ks & 1][j], af[ks & 1][m], acc[m][j]);
         __builtin_amdgcn_sched_barrier(0);
-        // the four rows of the next step, one per fourth k-step
-        if (more && (ks & 3) == 1 && ks < 16) load_row(frame, h0 + 5 + (ks >> 2));
+        // the four rows of the next step, spread over the k-steps
+        if (TM) { if (more && ks < 4) load_row(frame, h0 + 5 + ks); }
+        else if (more && (ks & 3) == 1 && ks < 16) load_row(frame, h0 + 5 + (ks >> 2));
         __builtin_amdgcn_sched_barrier(0);
       }
 
       // ---- epilogue in registers: lane = position m*16 + l15 of row h, channels wq*32 + g*8 .. +7 -----------------
-      if (h < p.Hr) {
+      if (h < nrow) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int w = m * 16 + l15;
@@ -191,9 +199,9 @@ __global__ __launch_bounds__(512) void conv_rows64_kernel(const GP p, const int 
 }
 
 template <typename K>
-int launch_rows64(K kernel, const GP& gp, int nframes, int fpw, unsigned nwg, hipStream_t s) {
+int launch_rows64(K kernel, const GP& gp, int nks, int nframes, int fpw, unsigned nwg, hipStream_t s) {
   static bool configured = false;   // per template instance
-  const size_t lds = kWBytes + kRing * kRowPitch + 256;
+  const size_t lds = (size_t)nks * 4096 + kRing * kRowPitch + 256;
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     configured = true;
@@ -208,8 +216,11 @@ int launch_rows64(K kernel, const GP& gp, int nframes, int fpw, unsigned nwg, hi
 bool conv_rows64_ok(const GP& gp, int mode, int dtype, int out_dtype, long long batch) {
   if (!(dtype == VLFB_BF16 || dtype == VLFB_F16) || out_dtype != dtype || batch != 1) return false;
   if (mode != VLFB_CONV_FPROP && mode != VLFB_CONV_DGRAD) return false;
-  if (gp.Cs != 64 || gp.Ncols != 64 || gp.kt != 1 || gp.kh != 3 || gp.kw != 3 || gp.K != 576) return false;
-  if (gp.st != 1 || gp.sh != 1 || gp.sw != 1 || gp.dt != 1 || gp.dh != 1 || gp.dw != 1 || gp.pt != 0 || gp.ph != 1 || gp.pw != 1) return false;
+  if (gp.Cs != 64 || gp.Ncols != 64) return false;
+  const bool spatial = gp.kt == 1 && gp.kh == 3 && gp.kw == 3 && gp.K == 576 && gp.pt == 0 && gp.ph == 1 && gp.pw == 1;
+  const bool temporal = gp.kt == 3 && gp.kh == 1 && gp.kw == 1 && gp.K == 192 && gp.pt == 1 && gp.ph == 0 && gp.pw == 0;
+  if (!spatial && !temporal) return false;
+  if (gp.st != 1 || gp.sh != 1 || gp.sw != 1 || gp.dt != 1 || gp.dh != 1 || gp.dw != 1) return false;
   if (gp.Ts != gp.Tr || gp.Hs != gp.Hr || gp.Ws != gp.Wr || gp.Wr > 62 || gp.Hr < 1) return false;
   if (gp.lda % 8 || gp.ldb % 8 || gp.ldo % 8 || gp.ldr % 8) return false;
   if ((long long)gp.M * gp.ldo * 2 >= (1ll << 31) || (long long)gp.M * gp.ldr * 2 >= (1ll << 31) ||
@@ -225,16 +236,20 @@ int launch_conv_rows64(const GP& gp, int mode, int dtype, hipStream_t s) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     ncu = n / 8 * 8;
   }
-  const int nframes = gp.M / (gp.Hr * gp.Wr);            // (n, t) frames
+  const bool tm = gp.kt == 3;
+  const int nframes = tm ? gp.M / (gp.Tr * gp.Wr) : gp.M / (gp.Hr * gp.Wr);      // (n, h) slabs | (n, t) frames
   long long nwg = ((long long)nframes + 7) / 8 * 8;
   if (nwg > ncu) nwg = ncu;
   const int fpw = (int)((nframes + nwg - 1) / nwg);
   const bool dg = mode == VLFB_CONV_DGRAD;
-  if (dtype == VLFB_F16)
-    return dg ? launch_rows64(conv_rows64_kernel<f16_t, true>, gp, nframes, fpw, (unsigned)nwg, s)
-              : launch_rows64(conv_rows64_kernel<f16_t, false>, gp, nframes, fpw, (unsigned)nwg, s);
-  return dg ? launch_rows64(conv_rows64_kernel<bf16_t, true>, gp, nframes, fpw, (unsigned)nwg, s)
-            : launch_rows64(conv_rows64_kernel<bf16_t, false>, gp, nframes, fpw, (unsigned)nwg, s);
+#define VLFB_ROWS64(T_, DG_, TM_) launch_rows64(conv_rows64_kernel<T_, DG_, TM_>, gp, TM_ ? 6 : 18, nframes, fpw, (unsigned)nwg, s)
+  if (dtype == VLFB_F16) {
+    if (tm) return dg ? VLFB_ROWS64(f16_t, true, true) : VLFB_ROWS64(f16_t, false, true);
+    return dg ? VLFB_ROWS64(f16_t, true, false) : VLFB_ROWS64(f16_t, false, false);
+  }
+  if (tm) return dg ? VLFB_ROWS64(bf16_t, true, true) : VLFB_ROWS64(bf16_t, false, true);
+  return dg ? VLFB_ROWS64(bf16_t, true, false) : VLFB_ROWS64(bf16_t, false, false);
+#undef VLFB_ROWS64
 }
 
 }  // namespace vlfb
