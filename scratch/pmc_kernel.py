@@ -10,7 +10,7 @@ for root in sys.argv[1:]:
             a[0] += 1
             a[1] += v
 for name, cs in acc.items():
-    if 'gemm' not in name and 'wgrad_rows' not in name and 'pool' not in name:
+    if not any(k in name for k in ('gemm', 'wgrad_rows', 'pool', 'stem_', 'conv_rows64')):
         continue
     short = re.sub(r'\(anonymous namespace\)::|vlfb::', '', name).replace('unsigned short', 'bf16')[:110]
     print(short)
