@@ -1,5 +1,7 @@
 #!/bin/bash
 # SQ / TCC counter passes over an arbitrary command: scratch/pmc_cmd.sh "<command>" <out.txt>   (run from the repo root)
+# CAUTION: never finished on `scratch/stem_probe 8 32 224` within 280 s at the end of round 2 (the call was killed by the budget
+# clamp, nothing came back) -- unverified which pass stalls; try it on a one-kernel command with its own short `timeout` first.
 R=$(pwd); C=$1; O=$2
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcp
