@@ -31,6 +31,19 @@ extern "C" {
 typedef void* vlfb_stream_t;
 
 enum { VLFB_F32 = 0, VLFB_BF16 = 1, VLFB_F16 = 2 };
+/* Weight-operand format of the split-bf16 path (vlfb_conv_desc.math != 0; accepted by vlfb_weight_prep* only): the
+ * FPROP copy is THREE bf16 planes [3][Cout][taps][Cin] (h = bf16(w), m = bf16(w - h), l = bf16(w - h - m)), the DGRAD
+ * copy TWO planes [2][Cin][taps][Cout] (h, m). */
+enum { VLFB_SPLIT = 3 };
+/* vlfb_conv_desc.math: how the contraction is evaluated when dtype == VLFB_F32.
+ *   VLFB_MATH_NATIVE  v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 vector rate)
+ *   VLFB_MATH_BF16X6  operands expanded into three bf16 terms each, six bf16 MFMAs per product (hh hm mh mm hl lh):
+ *                     fp32-grade results at 1/6 of the bf16 matrix rate (forward products of the parity path)
+ *   VLFB_MATH_BF16X3  two terms each, three MFMAs (hh hm mh): ~2^-17 per product (backward products)
+ * With math != 0 the B operand of FPROP / DGRAD launches is pre-split: bf16 planes (3 for BF16X6, 2 for BF16X3)
+ * `b_pstride` elements apart, each laid out as the fp32 B operand would be (vlfb_weight_prep* with VLFB_SPLIT,
+ * vlfb_split_planes); A, P, R, Mask and O stay fp32. */
+enum { VLFB_MATH_NATIVE = 0, VLFB_MATH_BF16X3 = 3, VLFB_MATH_BF16X6 = 6 };
 
 enum {
   VLFB_OK = 0,
@@ -123,6 +136,8 @@ typedef struct vlfb_conv_desc {
                          problem is not eligible), 3 = weight-resident streaming kernel (FPROP / DGRAD of
                          HBM-bound layers whose weight operand fits LDS; error if not eligible).  All
                          families give bit-identical results. */
+  int32_t math;       /* VLFB_MATH_* (dtype VLFB_F32 only) */
+  int64_t b_pstride;  /* math != 0, FPROP / DGRAD: elements between the bf16 term planes of B (0 = batch * Cn * ldb) */
 } vlfb_conv_desc;
 
 /* fills the desc with zeros and safe defaults (1x1x1, stride 1, alpha 1, batch 1) */
@@ -162,6 +177,11 @@ int vlfb_transpose2d(const void* src, void* dst, int dtype, int64_t batch, int64
 int vlfb_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int64_t rows,
                 int64_t cols, vlfb_stream_t stream);
 int vlfb_zero_f32(float* p, int64_t n, vlfb_stream_t stream);
+/* fp32 [batch][rows][cols] -> `nplanes` (2 | 3) bf16 term planes [plane][batch][rows][cols] (transpose = 0) or
+ * [plane][batch][cols][rows] (transpose = 1): the B operands of split-bf16 launches that are activations (the
+ * attention products, nonlocal_helper.py:94-121) */
+int vlfb_split_planes(const float* src, void* dst, int nplanes, int64_t batch, int64_t rows, int64_t cols,
+                      int transpose, vlfb_stream_t stream);
 /* Weight preparation: fp32 master W[Cout][taps][Cin] (kernel K-order) and the frozen affine
  * scale s[Cout] (may be NULL = 1) -> operand copies in `dtype`:
  *   w_fprop[Cout][taps][Cin] = W*s          (B operand of FPROP)

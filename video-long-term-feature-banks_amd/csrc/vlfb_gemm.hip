@@ -1090,6 +1090,8 @@ struct Plan {
   int rows64;     // FPROP / unit-stride DGRAD of 1x3x3 64 -> 64 convs: direct-convolution kernel (vlfb_conv_rows.hip)
   int stemf;      // FPROP of the packed stem: direct-convolution kernel (vlfb_stem.hip) when the call has no residual / mask
   int nts_mode;
+  int sp;         // split-bf16 math (vlfb_gemm_split.hip): bf16 terms per operand (2 | 3), 0 = native MFMA of the dtype
+  int sp_kind;    //   NT: 0 plain rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem
   size_t stem_lds;
   dim3 grid;
   size_t lds;
@@ -1102,6 +1104,12 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   VLFB_REQUIRE(dtype_ok(d->dtype), "conv: bad dtype %d", d->dtype);
   VLFB_REQUIRE(d->out_dtype == VLFB_F32 || d->out_dtype == d->dtype, "conv: bad out_dtype");
   VLFB_REQUIRE(d->mode >= 0 && d->mode <= 2, "conv: bad mode %d", d->mode);
+  VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || d->math == VLFB_MATH_BF16X3 || d->math == VLFB_MATH_BF16X6, "conv: bad math %d", d->math);
+  VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || (d->dtype == VLFB_F32 && d->out_dtype == VLFB_F32),
+               "conv: split-bf16 math needs fp32 operands and an fp32 output");
+  VLFB_REQUIRE(d->math != VLFB_MATH_BF16X6 || d->mode != VLFB_CONV_WGRAD, "conv: WGRAD has no BF16X6 form (use BF16X3)");
+  pl->sp = d->math == VLFB_MATH_BF16X6 ? 3 : d->math == VLFB_MATH_BF16X3 ? 2 : 0;
+  pl->sp_kind = 0;
   const int es = d->dtype == VLFB_F32 ? 4 : 2;
   const int epc = 16 / es;
   const int batch = d->batch > 0 ? d->batch : 1;
@@ -1177,7 +1185,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // output rows are then visited as 256-byte pieces of four different passes over the tensor instead of one
     // stream (198 -> 248 us, 153 -> 175 us).  Classes over h only (odd lines epilogue-only, as whole contiguous lines) are
     // no better (246 / 167 us): a tile without a k-loop has nothing to hide its residual loads behind.
-    if (d->mode == VLFB_CONV_DGRAD && d->algo == VLFB_ALGO_AUTO && !pl->ident && !pl->packw && batch == 1 && d->kh * d->kw > 1 &&
+    if (d->mode == VLFB_CONV_DGRAD && d->algo == VLFB_ALGO_AUTO && !pl->sp && !pl->ident && !pl->packw && batch == 1 && d->kh * d->kw > 1 &&
         d->st == 1 && d->sh == 2 && d->sw == 2 && d->dt == 1 && d->dh == 1 && d->dw == 1 && d->Hr % 2 == 0 &&
         d->Wr % 2 == 0 && ((long long)d->Cs * es) % 128 == 0 && d->bias_mode == VLFB_BIAS_NONE) {
       g.s2 = 1;
@@ -1278,7 +1286,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         // the main stream: rounds of 256 (one workgroup per CU, half the slab traffic) measured best
         // end to end (336 vs 331 clips/s at 512, 323 at 128).
         const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
-        const long long slots = 256;
+        // (split-bf16 math: one 4-wave workgroup per CU leaves every SIMD with a single wave, whose staging and MFMA
+        // phases then run back to back; two per CU -- 2 x 64 KiB of LDS -- overlap them)
+        const long long slots = pl->sp ? 512 : 256;
         long long maxs = (M + 8 * bk - 1) / (8 * bk);
         const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
         if (maxs > slab_cap) maxs = slab_cap;
@@ -1391,7 +1401,15 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // extents behind the buffer descriptors of the DMA kernels (one batch element)
     const long long a_rows = pl->ident ? M : (long long)d->N * d->Ts * d->Hs * d->Ws;
     const long long a_bytes = a_rows * (pl->packw ? 4 : g.lda) * es;
-    const long long b_bytes = d->mode == VLFB_CONV_WGRAD ? M * g.ldp * es : (long long)d->Cn * g.ldb * es;
+    long long b_bytes = d->mode == VLFB_CONV_WGRAD ? M * g.ldp * es : (long long)d->Cn * g.ldb * es;
+    if (pl->sp && d->mode != VLFB_CONV_WGRAD) {
+      // the weight operand is pl->sp bf16 planes b_ps elements apart; one descriptor spans all of them
+      g.b_ps = d->b_pstride > 0 ? d->b_pstride : (long long)batch * (batch > 1 ? d->b_bstride : (long long)d->Cn * g.ldb);
+      VLFB_REQUIRE(K % 8 == 0 && g.ldb % 8 == 0 && g.b_ps % 8 == 0 && d->b_bstride % 8 == 0,
+                   "conv: split-bf16 math needs K, ldb and the plane / batch strides of B in multiples of 8");
+      VLFB_REQUIRE(g.vec_epi, "conv: split-bf16 math needs 16-byte aligned output rows (Cn, ldo, ldr multiples of 4)");
+      b_bytes = ((long long)(pl->sp - 1) * g.b_ps + (long long)d->Cn * g.ldb) * 2;
+    }
     VLFB_REQUIRE(a_bytes < (1ll << 31) && b_bytes < (1ll << 31),
                  "conv: an operand of %lld / %lld bytes exceeds the 2 GiB a buffer descriptor addresses; split the batch",
                  a_bytes, b_bytes);
@@ -1409,6 +1427,14 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     g.epi = (int)((tile + pl->lds - 1) / pl->lds);
     if (g.epi > 2) { pl->lds = tile / 2; g.epi = 2; }
     pl->pre = g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
+    if (pl->sp) {
+      pl->sp_kind = pl->ident ? 0 : pl->packw ? 3 : d->mode == VLFB_CONV_FPROP ? 1 : 2;
+      pl->threads = kThreads;
+      pl->pre = 0;
+      const size_t sbuf = (size_t)128 * 128 + (size_t)pl->sp * pl->bn * 64;
+      pl->lds = 2 * sbuf;
+      if (pl->lds < (size_t)128 * pl->bn * 4) pl->lds = (size_t)128 * pl->bn * 4;
+    }
   } else {
     pl->lds = (size_t)2 * (pl->bm + pl->bn) * 128;
     if (pl->stem || pl->rows) { pl->lds = pl->stem_lds; pl->threads = 512; }
@@ -1571,7 +1597,10 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   g.ws = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
-  if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
+  if (pl.sp) {
+    rc = d->mode == VLFB_CONV_WGRAD ? launch_tn_split(g, pl.bm, pl.bn, pl.ident, pl.packw, pl.grid, pl.lds, s)
+                                    : launch_nt_split(g, pl.sp, pl.bn, pl.sp_kind, pl.ut != 0, pl.grid, pl.lds, s);
+  } else if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
   else if (d->dtype == VLFB_F16) rc = d->out_dtype == VLFB_F32 ? dispatch<f16_t, float>(d, pl, s) : dispatch<f16_t, f16_t>(d, pl, s);
   else rc = d->out_dtype == VLFB_F32 ? dispatch<bf16_t, float>(d, pl, s) : dispatch<bf16_t, bf16_t>(d, pl, s);
   if (rc != VLFB_OK) return rc;

@@ -40,6 +40,8 @@ struct GP {
   int s2;             // 1: class-major rows
   int s2_mq;          // rows per class (M / 4)
   int s2_tpc;         // row tiles per class
+  // split-bf16 math (vlfb_gemm_split.hip): element stride between the bf16 term planes of the weight operand
+  long long b_ps;
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered
@@ -68,6 +70,11 @@ int launch_stem_fprop(const GP& gp, int dtype, hipStream_t s);
 // resident in LDS, input rows rolling through a ring); mode = VLFB_CONV_FPROP | VLFB_CONV_DGRAD
 bool conv_rows64_ok(const GP& gp, int mode, int dtype, int out_dtype, long long batch);
 int launch_conv_rows64(const GP& gp, int mode, int dtype, hipStream_t s);
+
+// vlfb_gemm_split.hip: split-bf16 math on fp32 storage.  NT: npl = bf16 terms per operand (2 | 3), bn = 128 | 64, kind 0 plain
+// rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem FPROP; ut = scalar tap cursor.  TN: 2 terms, tiles 128 | 64.
+int launch_nt_split(const GP& gp, int npl, int bn, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s);
+int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 grid, size_t lds, hipStream_t s);
 
 namespace {
 

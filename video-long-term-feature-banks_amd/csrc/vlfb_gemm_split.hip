@@ -1,0 +1,708 @@
+// Split-bf16 implicit GEMM on the bf16 matrix cores with fp32 STORAGE (gfx950): the parity-grade path.
+//
+// The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VECTOR rate, 1/16 of the bf16 matrix rate.  Here every
+// fp32 operand value x is expanded into bf16 terms  x = h + m (+ l),  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+// (round-to-nearest-even, the differences are exact in fp32), and a product is the sum of the bf16 products whose
+// weight is above the fp32 rounding level, accumulated by v_mfma_f32_16x16x32_bf16 in fp32:
+//   math 6 ("bf16x6", 3 terms per operand, 24+ significand bits):  hh + hm + mh + mm + hl + lh   -- the FORWARD convs
+//       and attention products: a forward error above ~2^-21 flips enough ReLU / max-pool decisions to push parameter
+//       gradients past 1e-3 (scratch/emu_split.py: 16-bit forward operands -> conv1_w gradient off by 1e-2);
+//   math 3 ("bf16x3", 2 terms per operand, 16 bits):  hh + hm + mh  (error ~2^-17 per product, random sign) -- dgrad,
+//       wgrad and the backward attention products, where nothing is thresholded (gradients 3e-5 off, same experiment).
+// Small terms are issued first; 16 independent accumulators sit between two MFMAs on the same one.
+//
+// NT kernel (FPROP / DGRAD / batched NT GEMM): the activation operand is read as fp32 (buffer_load ... lds DMA, the
+// gathers of vlfb_gemm.hip: identity rows, scalar-tap cursor, per-lane tap decode, packed stem) and split when a
+// wave loads its fragments (10 VALU per value pair for three terms, hidden under 96 MFMAs per k-tile and wave); the
+// WEIGHT operand arrives PRE-SPLIT as NPL bf16 planes [plane][n][K] (vlfb_weight_prep* with dtype VLFB_SPLIT,
+// vlfb_split_planes for the attention operands), so it costs no VALU in the loop at all.
+// TN kernel (WGRAD, contract-over-positions products): both operands are activations with the contraction index as
+// the slow dimension; the register-staged transposing stager of the fp32 kernel splits each 4x4 block once on its
+// way into LDS ([channel][32 positions] rows = 64 bytes of h | 64 bytes of m), the MFMA loop reads bf16 fragments.
+//
+// LDS bank maps (ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... of
+// MI355X_MICROARCH.md): fp32 activation rows of 128 bytes are read as chunk pairs (2g, 2g+1): key128 below; bf16 plane
+// rows of 64 bytes as chunk g: key64.  Both conflict-free for those groups (worked out in DESIGN.md 3.1f).
+#include "vlfb_gemm_common.h"
+#include <type_traits>
+
+namespace vlfb {
+namespace {
+
+__device__ __forceinline__ int key128(int row) {
+  const int e = (row >> 1) & 7;
+  return e ^ (((e + 2) >> 1) & 2);
+}
+__device__ __forceinline__ int key64(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // 0, 3, 2, 1 per four rows
+
+// fp32 pair -> packed bf16 pair of the leading term, and the exact remainders
+__device__ __forceinline__ uint32_t peel(float& a, float& b) {
+  const uint32_t hp = pack_bf2(a, b);
+  a -= __uint_as_float(hp << 16);
+  b -= __uint_as_float(hp & 0xffff0000u);
+  return hp;
+}
+__device__ __forceinline__ uint32_t word_sel(const uint4& v, int i) {
+  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+template <int NPL>
+struct Terms { bf16x8_v t[NPL]; };
+
+template <int NPL>
+__device__ __forceinline__ Terms<NPL> split_frag(const float4 lo, const float4 hi) {
+  float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t w[NPL][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int pl = 0; pl < NPL - 1; ++pl) w[pl][i] = peel(x[2 * i], x[2 * i + 1]);
+    w[NPL - 1][i] = pack_bf2(x[2 * i], x[2 * i + 1]);
+  }
+  Terms<NPL> r;
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) {
+    const uint4 v = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+    r.t[pl] = __builtin_bit_cast(bf16x8_v, v);
+  }
+  return r;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (indices usable in `if constexpr`)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_impl(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+__device__ __forceinline__ f32x4_v mma_bf16(bf16x8_v a, bf16x8_v b, f32x4_v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// =============================================================================================
+// NT: O[m][n] = sum_k X[m][k] * W[n][k];  X fp32 (gathered), W = NPL bf16 planes, O / R / Mask fp32
+// =============================================================================================
+template <int NPL, int BN, bool IDENT, bool DGRAD, bool PACKW, bool UT>
+__global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
+  static_assert(!UT || (!IDENT && !PACKW), "UT is for gathered, unpacked operands");
+  typedef float T;
+  constexpr int BM = 128, NTHR = 256, NWN = 2;
+  constexpr int EPC = 4;                          // fp32 elements per 16-byte chunk of the activation operand
+  constexpr int RPPS_A = NTHR / 8, A_IT = BM / RPPS_A;       // 32 rows per pass, 4 passes
+  constexpr int RPPS_B = NTHR / 4, B_ITP = BN / RPPS_B;      // 64 rows per pass; 2 | 1 passes per plane
+  constexpr int WM = BM / 2, WN = BN / NWN;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
+  constexpr int BUF = A_BYTES + NPL * BP_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+
+  const char* Ab = p.A + (long long)z * p.a_bs * 4;
+  const char* Bb = p.B + (long long)z * p.b_bs * 2;
+
+  // ---- staging assignment: activation tile (128-byte fp32 rows), weight plane tiles (64-byte bf16 rows) ----
+  const int cc = tid & 7, r0 = tid >> 3;
+  const int ccg = cc ^ key128(r0);                 // global 16-byte chunk column this lane fetches (rows r0 + 32 i share the key)
+  const int cb = tid & 3, rb0 = tid >> 2;
+  const int cbg = cb ^ key64(rb0);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  RowC arow[A_IT];
+  bool aok[A_IT];
+  int upix[UT ? A_IT : 1];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + r0 + RPPS_A * i;
+    aok[i] = m < p.M;
+    if (!IDENT) arow[i] = decode_row(p, aok[i] ? m : 0);
+    if (UT) {
+      RowC& r = arow[i];
+      if (!DGRAD) { r.t = r.t * p.st - p.pt; r.h = r.h * p.sh - p.ph; r.w = r.w * p.sw - p.pw; }
+      else { r.t += p.pt; r.h += p.ph; r.w += p.pw; }
+      upix[i] = ((r.n * p.Ts + r.t) * p.Hs + r.h) * p.Ws + r.w;
+    }
+  }
+  unsigned boff[B_ITP], aoff[(IDENT || UT) ? A_IT : 1];
+#pragma unroll
+  for (int i = 0; i < B_ITP; ++i) {
+    const int n = n0 + rb0 + RPPS_B * i;
+    boff[i] = n < p.Ncols ? (unsigned)(n * p.ldb + cbg * 8) * 2u : kOOB;
+  }
+  if (IDENT || UT) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int m = m0 + r0 + RPPS_A * i;
+      if (IDENT) aoff[i] = aok[i] ? (unsigned)(m * p.lda + ccg * EPC) * 4u : kOOB;
+      else aoff[i] = (unsigned)(upix[i] * p.lda + ccg * EPC) * 4u;
+    }
+  }
+  const unsigned plane_bytes = (unsigned)p.b_ps * 2u;
+  int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;       // UT: scalar tap cursor of the next tile to fetch
+
+  const int ktiles = (p.K + 31) >> 5;
+
+  // The DMA of a k-tile is split into its address phase (prep_tile: per-lane offsets of the ND pieces, tap cursor)
+  // and ND issue slots (issue_piece) that the k-loop places between MFMAs.
+  constexpr int ND = A_IT + NPL * B_ITP;
+  unsigned dvo[ND], dso[ND];                       // voffset / soffset of every piece of the tile being fetched
+  auto prep_tile = [&](int kt) {
+    const int kc = kt * 8 + ccg;                   // global fp32 chunk index along K
+    TapC tap;
+    if (IDENT || UT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
+    else tap = decode_tap<T, PACKW>(p, kc);
+    const bool kok = kc * EPC < p.K;
+    const unsigned kbyte = (unsigned)kt * 128u;
+    if (UT) {
+      const int sgn = DGRAD ? -1 : 1;
+      const int da = sgn * u_a * p.dt, db = sgn * u_b * p.dh, dc = sgn * u_c * p.dw;
+      const unsigned dbyte = (unsigned)(((da * p.Hs + db) * p.Ws + dc) * p.lda + u_ci) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = aok[i] && (unsigned)(arow[i].t + da) < (unsigned)p.Ts &&
+                        (unsigned)(arow[i].h + db) < (unsigned)p.Hs && (unsigned)(arow[i].w + dc) < (unsigned)p.Ws;
+        dvo[i] = ok ? aoff[i] + dbyte : kOOB;
+        dso[i] = 0;
+      }
+      // branch-free cursor advance (scalar selects): the k-loop body has to stay one basic block
+      u_ci += 32;
+      const int w0 = u_ci >= p.Cs;
+      u_ci = w0 ? 0 : u_ci;
+      u_c += w0;
+      const int w1 = u_c == p.kw;
+      u_c = w1 ? 0 : u_c;
+      u_b += w1;
+      const int w2 = u_b == p.kh;
+      u_b = w2 ? 0 : u_b;
+      u_a += w2;
+    } else if (IDENT) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) { dvo[i] = kok ? aoff[i] : kOOB; dso[i] = kbyte; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        unsigned off;
+        if (PACKW) {
+          const int ts = arow[i].t * p.st - p.pt + tap.a * p.dt;
+          const int hs = arow[i].h * p.sh - p.ph + tap.b * p.dh;
+          const bool ok = aok[i] && tap.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+          const int w0 = arow[i].w * p.sw - p.pw + tap.c;
+          const int pix = ((arow[i].n * p.Ts + ts) * p.Hs + hs) * p.Ws + w0;
+          off = ok ? (unsigned)pix * 16u : kOOB;
+        } else {
+          bool ok;
+          const long long e = src_offset<DGRAD>(p, arow[i], tap, ok);
+          off = (ok && aok[i] && tap.ok) ? (unsigned)e * 4u : kOOB;
+        }
+        dvo[i] = off;
+        dso[i] = 0;
+      }
+    }
+    // weight planes: 32 k = 64 bytes per row and plane
+    const bool kokb = (kt * 4 + cbg) * 8 < p.K;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int i = 0; i < B_ITP; ++i) {
+        dvo[A_IT + pl * B_ITP + i] = kokb ? boff[i] : kOOB;
+        dso[A_IT + pl * B_ITP + i] = (unsigned)kt * 64u + (unsigned)pl * plane_bytes;
+      }
+  };
+  // past the last tile the fetch still runs (one basic block, see the k-loop) but through descriptors of ZERO
+  // records: every lane is out of range and the copies zero-fill a buffer nobody reads -- a scalar select, no lane work
+  auto issue_piece = [&](int d, int buf, bool live) {
+    char* base = smem + buf * BUF + wave_u * 1024;
+    if (d < A_IT) bufglds16(make_rsrc(Ab, live ? p.a_bytes : 0u), dvo[d], dso[d], base + d * (RPPS_A * 128));
+    else bufglds16(make_rsrc(Bb, live ? p.b_bytes : 0u), dvo[d], dso[d],
+                   base + A_BYTES + ((d - A_IT) / B_ITP) * BP_BYTES + ((d - A_IT) % B_ITP) * (RPPS_B * 64));
+  };
+
+  f32x4_v acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  if (ktiles > 0) {
+    prep_tile(0);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) issue_piece(d, 0, true);
+  }
+  // MFMA sequence of a k-tile: weight plane a x activation term b, every weight plane against the LEADING activation
+  // term first -- those MFMAs need one v_cvt_pk_bf16_f32 per value pair and nothing else; the further activation terms
+  // are peeled (5 VALU per pair and term) in the shadow of the MFMAs that precede their first use, and the ND DMA
+  // pieces of the next tile are spread over the whole sequence.  Largest products first: the accumulator already holds
+  // the sum of the earlier k-tiles, the order inside a tile does not matter for the rounding.
+  constexpr int NTERM = NPL == 3 ? 6 : 3;
+  constexpr int TA[6] = {0, 1, NPL == 3 ? 2 : 0, 0, 1, 0};
+  constexpr int TB[6] = {0, 0, NPL == 3 ? 0 : 1, 1, 1, 2};
+  constexpr int PER = FN * FM;                     // MFMAs per term
+  constexpr int NMF = NTERM * PER;
+  constexpr int G1 = NPL * PER;                    // MFMAs that only need the leading activation term
+  constexpr int NPU = 4 * FM;                      // pair units per peeled term
+  for (int kt = 0; kt < ktiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // own DMA landed; bare barrier (see vlfb_gemm.hip)
+    // the next tile is fetched unconditionally (past the last tile every lane carries the out-of-range offset and
+    // the copies zero-fill a buffer nobody reads), so the loop body is one basic block
+    prep_tile(kt + 1);
+    const int nbuf = (kt + 1) & 1;
+    const bool live = kt + 1 < ktiles;
+    const char* xa = smem + (kt & 1) * BUF;
+    const char* wb = xa + A_BYTES;
+    bf16x8_v wf[NPL][FN];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WN + j * 16 + l15;
+        wf[pl][j] = *reinterpret_cast<const bf16x8_v*>(wb + pl * BP_BYTES + row * 64 + ((g ^ key64(row)) << 4));
+      }
+    float xr[FM][8];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm * WM + i * 16 + l15;
+      const int key = key128(row);
+      const float4 lo = *reinterpret_cast<const float4*>(xa + row * 128 + (((2 * g) ^ key) << 4));
+      const float4 hi = *reinterpret_cast<const float4*>(xa + row * 128 + (((2 * g + 1) ^ key) << 4));
+      xr[i][0] = lo.x; xr[i][1] = lo.y; xr[i][2] = lo.z; xr[i][3] = lo.w;
+      xr[i][4] = hi.x; xr[i][5] = hi.y; xr[i][6] = hi.z; xr[i][7] = hi.w;
+    }
+    uint32_t xw[NPL][FM][4];                       // activation terms, packed bf16 pairs
+    // leading term: the packed conversion only (one VALU per pair in front of the first MFMA)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int q2 = 0; q2 < 4; ++q2) xw[0][i][q2] = pack_bf2(xr[i][2 * q2], xr[i][2 * q2 + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NMF>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int ts = n / PER, j = (n % PER) / FM, i = n % FM;
+      const uint4 xv = make_uint4(xw[TB[ts]][i][0], xw[TB[ts]][i][1], xw[TB[ts]][i][2], xw[TB[ts]][i][3]);
+      acc[j][i] = mma_bf16(wf[TA[ts]][j], __builtin_bit_cast(bf16x8_v, xv), acc[j][i]);
+      // pair units due after this MFMA: term 1 spread over the first G1 MFMAs, term 2 over the 2 * PER that follow
+      static_for<(NPL - 1) * NPU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int t = 1 + u / NPU, v = u % NPU;
+        constexpr int due = t == 1 ? ((v + 1) * G1 + NPU - 1) / NPU : G1 + ((v + 1) * 2 * PER + NPU - 1) / NPU;
+        if constexpr (due == n + 1) {
+          constexpr int fi = v / 4, q2 = v % 4;
+          // remainder after the previous term (exact in fp32), then its leading bf16 pair
+          const uint32_t hp = xw[t - 1][fi][q2];
+          xr[fi][2 * q2] -= __uint_as_float(hp << 16);
+          xr[fi][2 * q2 + 1] -= __uint_as_float(hp & 0xffff0000u);
+          xw[t][fi][q2] = pack_bf2(xr[fi][2 * q2], xr[fi][2 * q2 + 1]);
+        }
+      });
+      static_for<ND>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (((d + 1) * NMF) / (ND + 1) == n + 1) issue_piece(d, nbuf, live);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  __syncthreads();
+
+  // ---- epilogue: fp32 tile through LDS, 16-byte row accesses (the vec_epi path of gemm_nt_kernel) ----
+  char* Ob = p.O + (long long)z * p.o_bs * 4;
+  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 4 : nullptr;
+  const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 4 : nullptr;
+  constexpr int TPR = BN / 4, RPP = NTHR / TPR, NPASS = BM / RPP, CPR = BN / 4;
+  const int tc = tid % TPR, tr = tid / TPR;
+  const int ncol = n0 + tc * 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm * WM + i * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int c = (wn * WN + j * 16 + g * 4) >> 2;
+      *reinterpret_cast<float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4)) =
+          make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha, acc[j][i][3] * p.alpha);
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int gp = 0; gp < NPASS; ++gp) {
+    const int row = gp * RPP + tr;
+    const int m = m0 + row;
+    if (m < p.M && ncol < p.Ncols) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (tc ^ (row & 7))) << 4));
+      float v[4] = {t.x, t.y, t.z, t.w};
+      if (p.bias_mode == VLFB_BIAS_COL) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + ncol);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      } else if (p.bias_mode == VLFB_BIAS_ROW) {
+        const float b = p.bias[m];
+        v[0] += b; v[1] += b; v[2] += b; v[3] += b;
+      }
+      const long long ridx = (long long)m * p.ldr + ncol;
+      if (Rb) {
+        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Rb) + ridx);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (Mb) {
+        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Mb) + ridx);
+        v[0] = r.x > 0.f ? v[0] : 0.f; v[1] = r.y > 0.f ? v[1] : 0.f;
+        v[2] = r.z > 0.f ? v[2] : 0.f; v[3] = r.w > 0.f ? v[3] : 0.f;
+      }
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ob) + (long long)m * p.ldo + ncol) =
+          make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// =============================================================================================
+// TN: O[pp][qq] = sum_m P[m][pp] * Xg[m][qq], fp32 operands split (2 terms) on their way into LDS
+// =============================================================================================
+struct QRowS {
+  int n, t, h, w;
+  long long base;
+  bool hv;
+};
+__device__ __forceinline__ void qs_refresh(const GP& p, QRowS& r, const TapC& tp) {
+  const int ts = r.t * p.st - p.pt + tp.a * p.dt;
+  const int hs = r.h * p.sh - p.ph + tp.b * p.dh;
+  r.hv = (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+  r.base = ((long long)(r.n * p.Ts + ts) * p.Hs + hs) * p.Ws;
+}
+__device__ __forceinline__ void qs_next(const GP& p, QRowS& r, const TapC& tp) {
+  if (++r.w == p.Wr) {
+    r.w = 0;
+    if (++r.h == p.Hr) {
+      r.h = 0;
+      if (++r.t == p.Tr) { r.t = 0; ++r.n; }
+    }
+    qs_refresh(p, r, tp);
+  }
+}
+__device__ __forceinline__ void qs_jump(const GP& p, QRowS& r, const RowC& d, const TapC& tp) {
+  r.w += d.w; if (r.w >= p.Wr) { r.w -= p.Wr; ++r.h; }
+  r.h += d.h; if (r.h >= p.Hr) { r.h -= p.Hr; ++r.t; }
+  r.t += d.t; if (r.t >= p.Tr) { r.t -= p.Tr; ++r.n; }
+  r.n += d.n;
+  qs_refresh(p, r, tp);
+}
+template <bool PACKW>
+__device__ __forceinline__ uint4 qs_load(const GP& p, const char* base, const QRowS& r, const TapC& tp, bool ok) {
+  ok = ok && tp.ok && r.hv;
+  if (PACKW) {
+    const int w0 = r.w * p.sw - p.pw + tp.c;
+    return ld16_if(base, (r.base + w0) * 16, ok);
+  } else {
+    const int ws = r.w * p.sw - p.pw + tp.c * p.dw;
+    return ld16_if(base, ((r.base + ws) * p.lda + tp.ci) * 4, ok && (unsigned)ws < (unsigned)p.Ws);
+  }
+}
+
+template <int BP, int BQ, bool IDENT, bool PACKW>
+__global__ __launch_bounds__(256) void gemm_tn_sp_kernel(const GP p) {
+  typedef float T;
+  constexpr int EPC = 4, BK = 32;
+  constexpr int NPB = BP / EPC * 8, NQB = BQ / EPC * 8;    // 4 x 4 staging blocks per tile
+  constexpr int ITER = (NPB + NQB + 255) / 256;
+  constexpr int WP = BP / 2, WQ = BQ / 2;
+  constexpr int FP = WP / 16, FQ = WQ / 16;
+  constexpr int BUF = (BP + BQ) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid, split;
+  if (p.splits > 1 && (p.splits & 7) == 0) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    bid = slot % nwg;
+    split = (slot / nwg) * 8 + xcd;
+  } else {
+    bid = xcd_remap(blockIdx.x, nwg);
+    split = blockIdx.y;
+  }
+  const int tile_p = bid / p.tiles_n, tile_q = bid - tile_p * p.tiles_n;
+  const int p0 = tile_p * BP, q0 = tile_q * BQ;
+  const int z = blockIdx.z;
+  const char* Pb = p.P + (long long)z * p.p_bs * 4;
+  const char* Ab = p.A + (long long)z * p.a_bs * 4;
+
+  const int kbeg = split * p.kper;
+  const int kend = min(p.M, kbeg + p.kper);
+  const int ktiles = (kend - kbeg + BK - 1) / BK;
+
+  int blk_kind[ITER], blk_r[ITER], blk_k[ITER];
+  TapC qtap[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int id = tid + it * 256;
+    if (id < NPB) { blk_kind[it] = 0; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
+    else if (id < NPB + NQB) { id -= NPB; blk_kind[it] = 1; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
+    else { blk_kind[it] = 2; blk_r[it] = 0; blk_k[it] = 0; }
+    if (blk_kind[it] == 1) {
+      const int kc = (q0 + blk_r[it] * EPC) / EPC;
+      if (IDENT) { qtap[it].ok = kc * EPC < p.K; qtap[it].a = qtap[it].b = qtap[it].c = 0; qtap[it].ci = 0; }
+      else qtap[it] = decode_tap<T, PACKW>(p, kc);
+    }
+  }
+  QRowS qrow[ITER];
+  RowC jump;
+  if (!IDENT) {
+    jump = decode_row(p, BK - EPC);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (blk_kind[it] == 1) {
+        const RowC r0 = decode_row(p, min(kbeg + blk_k[it] * EPC, p.M - 1));
+        qrow[it].n = r0.n; qrow[it].t = r0.t; qrow[it].h = r0.h; qrow[it].w = r0.w;
+        qs_refresh(p, qrow[it], qtap[it]);
+      }
+    }
+  }
+
+  uint4 stg[ITER][EPC];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int kk = kbeg + kt * BK + blk_k[it] * EPC;
+      if (blk_kind[it] == 0) {
+        const int pc = p0 + blk_r[it] * EPC;
+        const bool cok = pc < p.Ncols;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const int k = kk + j;
+          stg[it][j] = ld16_if(Pb, ((long long)k * p.ldp + pc) * 4, cok && k < kend);
+        }
+      } else if (blk_kind[it] == 1) {
+        if (IDENT) {
+          const int qc = q0 + blk_r[it] * EPC;
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) {
+            const int k = kk + j;
+            stg[it][j] = ld16_if(Ab, ((long long)k * p.lda + qc) * 4, qtap[it].ok && k < kend);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) {
+            stg[it][j] = qs_load<PACKW>(p, Ab, qrow[it], qtap[it], kk + j < kend);
+            qs_next(p, qrow[it], qtap[it]);
+          }
+          qs_jump(p, qrow[it], jump, qtap[it]);
+        }
+      }
+    }
+  };
+  // block (4 positions x 4 channels, stg[j] = the 4 channels of position j) -> per channel the 4 positions as
+  // bf16 h (8 bytes) and m (8 bytes): row = channel, h in the first 64 bytes, m in the second
+  auto store_tile = [&](int buf) {
+    char* pt = smem + buf * BUF;
+    char* qt = pt + BP * 128;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (blk_kind[it] == 2) continue;
+      char* dst = blk_kind[it] == 0 ? pt : qt;
+#pragma unroll
+      for (int c = 0; c < EPC; ++c) {
+        float a0 = __uint_as_float(word_sel(stg[it][0], c)), a1 = __uint_as_float(word_sel(stg[it][1], c));
+        float a2 = __uint_as_float(word_sel(stg[it][2], c)), a3 = __uint_as_float(word_sel(stg[it][3], c));
+        const uint32_t h01 = peel(a0, a1), h23 = peel(a2, a3);
+        const uint32_t m01 = pack_bf2(a0, a1), m23 = pack_bf2(a2, a3);
+        const int row = blk_r[it] * EPC + c;
+        const int ch = blk_k[it] >> 1, half = (blk_k[it] & 1) << 3;
+        char* rowp = dst + row * 128;
+        *reinterpret_cast<uint2*>(rowp + ((ch ^ (row & 7)) << 4) + half) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(rowp + (((4 + ch) ^ (row & 7)) << 4) + half) = make_uint2(m01, m23);
+      }
+    }
+  };
+
+  f32x4_v acc[FQ][FP];
+#pragma unroll
+  for (int a = 0; a < FQ; ++a)
+#pragma unroll
+    for (int b = 0; b < FP; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  if (ktiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const bool more = kt + 1 < ktiles;
+    if (more) load_tile(kt + 1);
+    const char* pt = smem + (kt & 1) * BUF;
+    const char* qt = pt + BP * 128;
+    bf16x8_v pf[2][FP], qf[2][FQ];
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const int row = wp * WP + i * 16 + l15;
+      pf[0][i] = *reinterpret_cast<const bf16x8_v*>(pt + row * 128 + ((g ^ (row & 7)) << 4));
+      pf[1][i] = *reinterpret_cast<const bf16x8_v*>(pt + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      const int row = wq * WQ + j * 16 + l15;
+      qf[0][j] = *reinterpret_cast<const bf16x8_v*>(qt + row * 128 + ((g ^ (row & 7)) << 4));
+      qf[1][j] = *reinterpret_cast<const bf16x8_v*>(qt + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+    }
+#define VLFB_SP_TERM(a, b)                                                        \
+    _Pragma("unroll") for (int j = 0; j < FQ; ++j)                                \
+      _Pragma("unroll") for (int i = 0; i < FP; ++i)                              \
+        acc[j][i] = mma_bf16(qf[a][j], pf[b][i], acc[j][i]);
+    VLFB_SP_TERM(1, 0) VLFB_SP_TERM(0, 1) VLFB_SP_TERM(0, 0)
+#undef VLFB_SP_TERM
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (as gemm_tn_kernel): lane holds qq = qb + 0..3 for output row pp ----
+  const bool vec_ok = (p.ldo & 3) == 0;
+  const bool to_ws = p.splits > 1;
+#pragma unroll
+  for (int i = 0; i < FP; ++i) {
+    const int pp = p0 + wp * WP + i * 16 + l15;
+    if (pp >= p.Ncols) continue;
+    const float rs = (to_ws || !p.rowscale) ? 1.f : p.rowscale[pp];
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      const int qb = q0 + wq * WQ + j * 16 + g * 4;
+      if (qb >= p.K) continue;
+      const int cnt = (p.K - qb) < 4 ? (p.K - qb) : 4;
+      const long long idx = (long long)pp * p.ldo + qb;
+      float v[4];
+      if (to_ws) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r];
+        store4<float>(reinterpret_cast<char*>(p.ws), (long long)split * ((long long)p.Ncols * p.ldo) + idx, v, cnt, vec_ok);
+      } else {
+        char* Ob = p.O + (long long)z * p.o_bs * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[j][i][r] * p.alpha * rs;
+          if (p.accumulate && r < cnt) x += ld_elem<float>(Ob, idx + r);
+          v[r] = x;
+        }
+        store4<float>(Ob, idx, v, cnt, vec_ok);
+      }
+    }
+  }
+}
+
+template <typename K>
+int launch_sp(K kernel, dim3 grid, size_t lds, const GP& gp, hipStream_t s) {
+  static bool configured = false;     // per template instance
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    configured = true;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, gp);
+  return check_launch("split-bf16 conv kernel");
+}
+
+template <int NPL, int BN>
+int launch_nt_sp_shape(const GP& gp, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s) {
+  switch (kind) {
+    case 0: return launch_sp(gemm_nt_sp_kernel<NPL, BN, true, false, false, false>, grid, lds, gp, s);
+    case 1: return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, true>, grid, lds, gp, s)
+                      : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, false>, grid, lds, gp, s);
+    case 2: return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true>, grid, lds, gp, s)
+                      : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, false>, grid, lds, gp, s);
+    default: return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, true, false>, grid, lds, gp, s);
+  }
+}
+
+// ---- fp32 -> bf16 term planes (attention operands; optionally transposed per batch element) -----------------
+template <int NPL>
+__global__ void split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n, long long plane) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n;
+       i += (long long)gridDim.x * blockDim.x * 2) {
+    float a = src[i], b = i + 1 < n ? src[i + 1] : 0.f;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      const uint32_t w = pl + 1 < NPL ? peel(a, b) : pack_bf2(a, b);
+      if (i + 1 < n) *reinterpret_cast<uint32_t*>(dst + pl * plane + i) = w;
+      else dst[pl * plane + i] = (bf16_t)(w & 0xffffu);
+    }
+  }
+}
+template <int NPL>
+__global__ void split_planes_tr_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long rows,
+                                       long long cols, long long plane) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.z;
+  const float* s = src + b * rows * cols;
+  bf16_t* d = dst + b * rows * cols;
+  const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const long long r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = s[r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const long long c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) {
+      float a = tile[threadIdx.x][j], z = 0.f;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const uint32_t w = pl + 1 < NPL ? peel(a, z) : pack_bf2(a, z);
+        d[pl * plane + c * rows + r] = (bf16_t)(w & 0xffffu);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_nt_split(const GP& gp, int npl, int bn, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s) {
+  if (npl == 3) return bn == 128 ? launch_nt_sp_shape<3, 128>(gp, kind, ut, grid, lds, s) : launch_nt_sp_shape<3, 64>(gp, kind, ut, grid, lds, s);
+  return bn == 128 ? launch_nt_sp_shape<2, 128>(gp, kind, ut, grid, lds, s) : launch_nt_sp_shape<2, 64>(gp, kind, ut, grid, lds, s);
+}
+
+int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 grid, size_t lds, hipStream_t s) {
+#define VLFB_TN_SP(BP, BQ)                                                                                     \
+  do {                                                                                                         \
+    if (ident) return launch_sp(gemm_tn_sp_kernel<BP, BQ, true, false>, grid, lds, gp, s);                     \
+    if (packw) return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, true>, grid, lds, gp, s);                     \
+    return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, false>, grid, lds, gp, s);                               \
+  } while (0)
+  if (bp == 128 && bq == 128) VLFB_TN_SP(128, 128);
+  if (bp == 64 && bq == 128) VLFB_TN_SP(64, 128);
+  if (bp == 128 && bq == 64) VLFB_TN_SP(128, 64);
+  VLFB_TN_SP(64, 64);
+#undef VLFB_TN_SP
+}
+
+}  // namespace vlfb
+
+using namespace vlfb;
+
+extern "C" int vlfb_split_planes(const float* src, void* dst, int nplanes, int64_t batch, int64_t rows, int64_t cols,
+                                 int transpose, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && batch > 0 && rows > 0 && cols > 0, "split_planes: bad args");
+  VLFB_REQUIRE(nplanes == 2 || nplanes == 3, "split_planes: nplanes must be 2 or 3");
+  const long long n = (long long)batch * rows * cols;
+  hipStream_t s = (hipStream_t)stream;
+  if (!transpose) {
+    VLFB_REQUIRE(n % 2 == 0, "split_planes: an even element count is required");
+    const int grid = grid_for(n / 2, 256);
+    if (nplanes == 3) hipLaunchKernelGGL(split_planes_kernel<3>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, n, n);
+    else hipLaunchKernelGGL(split_planes_kernel<2>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, n, n);
+  } else {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+    if (nplanes == 3) hipLaunchKernelGGL(split_planes_tr_kernel<3>, grid, dim3(32, 8), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols, n);
+    else hipLaunchKernelGGL(split_planes_tr_kernel<2>, grid, dim3(32, 8), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols, n);
+  }
+  return check_launch("split_planes");
+}

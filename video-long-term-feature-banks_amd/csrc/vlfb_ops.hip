@@ -120,33 +120,60 @@ __global__ void transpose2d_kernel(const T* __restrict__ src, T* __restrict__ ds
   }
 }
 
+// bf16 term planes of the split-bf16 path: value v -> h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)
+// rounded_mul: the fp32-ROUNDED product (hipcc contracts `w * s - h` into an fma otherwise and the remainder terms
+// would expand the unrounded product; the planes are defined as the expansion of the fp32 operand value)
+__device__ __forceinline__ float rounded_mul(float a, float b) {
+  float v = a * b;
+  asm volatile("" : "+v"(v));
+  return v;
+}
+struct SplitW {};       // tag type: weight_prep kernels instantiated with it write planes instead of elements
+template <int NPL>
+__device__ __forceinline__ void store_terms(bf16_t* dst, long long idx, long long plane, float v) {
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) {
+    const bf16_t t = f2bf(v);
+    dst[pl * plane + idx] = t;
+    v -= bf2f(t);
+  }
+}
+template <typename T> struct WStore {
+  __device__ static __forceinline__ void fprop(void* base, long long idx, long long, float v) { Elem<T>::st(reinterpret_cast<T*>(base) + idx, v); }
+  __device__ static __forceinline__ void dgrad(void* base, long long idx, long long, float v) { Elem<T>::st(reinterpret_cast<T*>(base) + idx, v); }
+};
+template <> struct WStore<SplitW> {
+  __device__ static __forceinline__ void fprop(void* base, long long idx, long long plane, float v) { store_terms<3>(reinterpret_cast<bf16_t*>(base), idx, plane, v); }
+  __device__ static __forceinline__ void dgrad(void* base, long long idx, long long plane, float v) { store_terms<2>(reinterpret_cast<bf16_t*>(base), idx, plane, v); }
+};
+
 // w[Cout][taps][Cin] fp32 (+ scale[Cout]) -> fprop copy (same order) in T
 template <typename T>
 __global__ void weight_prep_fprop_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                         T* __restrict__ out, long long per_cout, long long total) {
+                                         void* __restrict__ out, long long per_cout, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const float s = scale ? scale[i / per_cout] : 1.f;
-    Elem<T>::st(out + i, w[i] * s);
+    WStore<T>::fprop(out, i, total, rounded_mul(w[i], s));
   }
 }
 // -> dgrad copy [Cin][taps][Cout]; blockIdx.z = tap; 32x32 LDS tile transpose
 template <typename T>
 __global__ void weight_prep_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                         T* __restrict__ out, int cout, int taps, int cin) {
+                                         void* __restrict__ out, int cout, int taps, int cin) {
   __shared__ float tile[32][33];
   const int tap = blockIdx.z;
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     int co = co0 + j, ci = ci0 + threadIdx.x;
     if (co < cout && ci < cin)
-      tile[j][threadIdx.x] = w[((long long)co * taps + tap) * cin + ci] * (scale ? scale[co] : 1.f);
+      tile[j][threadIdx.x] = rounded_mul(w[((long long)co * taps + tap) * cin + ci], scale ? scale[co] : 1.f);
   }
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     int ci = ci0 + j, co = co0 + threadIdx.x;
     if (co < cout && ci < cin)
-      Elem<T>::st(out + ((long long)ci * taps + tap) * cout + co, tile[threadIdx.x][j]);
+      WStore<T>::dgrad(out, ((long long)ci * taps + tap) * cout + co, (long long)cout * taps * cin, tile[threadIdx.x][j]);
   }
 }
 
@@ -170,15 +197,16 @@ __global__ void weight_prep_batched_kernel(const vlfb_wprep_item* __restrict__ i
   const int tap = t / (tiles_ci * tiles_co);
   const float* w = reinterpret_cast<const float*>(it.w);
   const float* scale = reinterpret_cast<const float*>(it.scale);
-  T* wf = reinterpret_cast<T*>(it.w_fprop);
-  T* wd = reinterpret_cast<T*>(it.w_dgrad);
+  void* wf = it.w_fprop;
+  void* wd = it.w_dgrad;
+  const long long plane = (long long)it.cout * it.taps * it.cin;
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int co = co0 + j, ci = ci0 + threadIdx.x;
     if (co < it.cout && ci < it.cin) {
       const long long idx = ((long long)co * it.taps + tap) * it.cin + ci;
-      const float v = w[idx] * (scale ? scale[co] : 1.f);
+      const float v = rounded_mul(w[idx], scale ? scale[co] : 1.f);     // (no fma contraction into the term remainders)
       tile[j][threadIdx.x] = v;
-      if (wf) Elem<T>::st(wf + idx, v);
+      if (wf) WStore<T>::fprop(wf, idx, plane, v);
     }
   }
   if (!wd) return;
@@ -186,7 +214,7 @@ __global__ void weight_prep_batched_kernel(const vlfb_wprep_item* __restrict__ i
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int ci = ci0 + j, co = co0 + threadIdx.x;
     if (co < it.cout && ci < it.cin)
-      Elem<T>::st(wd + ((long long)ci * it.taps + tap) * it.cout + co, tile[threadIdx.x][j]);
+      WStore<T>::dgrad(wd, ((long long)ci * it.taps + tap) * it.cout + co, plane, tile[threadIdx.x][j]);
   }
 }
 
@@ -1041,23 +1069,27 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
                                 int dtype, int64_t cout, int64_t taps, int64_t cin,
                                 vlfb_stream_t stream) {
   VLFB_REQUIRE(w && (w_fprop || w_dgrad) && cout > 0 && taps > 0 && cin > 0, "weight_prep: bad args");
-  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype), "weight_prep: bad dtype");
+  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype) || dtype == VLFB_SPLIT, "weight_prep: bad dtype");
   VLFB_REQUIRE(taps < 65536, "weight_prep: too many taps");
   hipStream_t s = (hipStream_t)stream;
   const long long total = cout * taps * cin;
   if (w_fprop) {
     int grid = grid_for(total, 256);
     if (dtype == VLFB_F32)
-      hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, (float*)w_fprop, (long long)(taps * cin), total);
+      hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
+    else if (dtype == VLFB_SPLIT)
+      hipLaunchKernelGGL(weight_prep_fprop_kernel<SplitW>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
     else
-      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_fprop_kernel<T16>, dim3(grid), dim3(256), 0, s, w, scale, (T16*)w_fprop, (long long)(taps * cin), total));
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_fprop_kernel<T16>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total));
   }
   if (w_dgrad) {
     dim3 grid((unsigned)((cin + 31) / 32), (unsigned)((cout + 31) / 32), (unsigned)taps);
     if (dtype == VLFB_F32)
-      hipLaunchKernelGGL(weight_prep_dgrad_kernel<float>, grid, dim3(32, 8), 0, s, w, scale, (float*)w_dgrad, (int)cout, (int)taps, (int)cin);
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<float>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
+    else if (dtype == VLFB_SPLIT)
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<SplitW>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else
-      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_dgrad_kernel<T16>, grid, dim3(32, 8), 0, s, w, scale, (T16*)w_dgrad, (int)cout, (int)taps, (int)cin));
+      VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_dgrad_kernel<T16>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin));
   }
   return check_launch("weight_prep");
 }
@@ -1295,6 +1327,8 @@ extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_
     hipLaunchKernelGGL(weight_prep_batched_kernel<float>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else if (is16(dtype))
     VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_batched_kernel<T16>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items));
+  else if (dtype == VLFB_SPLIT)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<SplitW>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
   return check_launch("weight_prep_batched");
 }

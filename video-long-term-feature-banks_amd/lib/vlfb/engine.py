@@ -206,26 +206,34 @@ class ConvStep(Step):
             assert wpad >= self.p[2] and wpad >= self.pack - self.k[2] + self.p[2], "stem needs a W-padded input"
             W = W + 2 * wpad
             common["pw"] = self.p[2] - wpad
+        # split-bf16 math on fp32 storage (Engine dtype "split"): the weight operand copies are bf16 term planes
+        wshape = eng.kernel_shape(self.wname)
+        mf, mb = eng.math_fwd, eng.math_bwd
+        planes = dict(b_pstride=_prod(wshape)) if eng.split else {}
         self.d_f = hip.conv_desc(mode=hip.FPROP, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
                                  Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, relu=int(self.relu),
-                                 bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, **common)
+                                 bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, math=mf,
+                                 **planes, **common)
         self.d_d = None
         if self.x.needs_grad and not self.x.detached:
             assert not self.stem
             self.d_d = hip.conv_desc(mode=hip.DGRAD, out_dtype=code, N=N, Tr=T, Hr=H, Wr=W, Ts=To,
-                                     Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, alpha=1.0 / self.gscale, **common)
+                                     Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, alpha=1.0 / self.gscale, math=mb, **planes, **common)
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
                                      Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
-                                     **common)
+                                     math=mb, **common)
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
-        # operand copies
-        wshape = eng.kernel_shape(self.wname)
-        self.w_f = torch.empty(wshape, device=eng.device, dtype=eng.tdtype)
+        # operand copies (split math: 3 bf16 term planes for FPROP, 2 for DGRAD -- include/vlfb.h VLFB_SPLIT)
+        if eng.split:
+            self.w_f = torch.empty((3,) + tuple(wshape), device=eng.device, dtype=torch.bfloat16)
+        else:
+            self.w_f = torch.empty(wshape, device=eng.device, dtype=eng.tdtype)
         self.w_d = None
         if self.d_d is not None:
-            self.w_d = torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype)
+            self.w_d = (torch.empty(2 * _prod(wshape), device=eng.device, dtype=torch.bfloat16) if eng.split else
+                        torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype))
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
@@ -245,7 +253,7 @@ class ConvStep(Step):
         w = eng.param_tensor(self.wname)
         s = eng.param_tensor(self.sname) if self.sname else None
         hip.call("vlfb_weight_prep", hip.ptr(w), hip.ptr(s), hip.ptr(self.w_f), hip.ptr(self.w_d),
-                 eng.code, Cout, self.taps(), self.Cin_k)
+                 eng.wcode, Cout, self.taps(), self.Cin_k)
         self.refresh_bias()
 
     def refresh_bias(self):
@@ -374,11 +382,17 @@ class AttentionStep(Step):
         if self.single:
             self.ds_ws = torch.empty(B * L2, device=eng.device, dtype=torch.float32)
             return
+        # split math: the B operands (phi, g^T, g, phi^T) are activations, expanded into bf16 term planes by
+        # vlfb_split_planes right before the product that reads them (3 planes forward, 2 backward)
+        mf, mb = eng.math_fwd, eng.math_bwd
+        pl = dict(b_pstride=B * L2 * Ci) if eng.split else {}
         gemm = lambda **kw: hip.conv_desc(mode=hip.FPROP, dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
                                           Ws=L1, batch=B, **kw)
-        self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2)
-        self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci)
-        self.d_dp = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2)
+        self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mf, **pl)
+        self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci, math=mf, **pl)
+        self.d_dp = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mb, **pl)
+        if eng.split:
+            eng.need_scratch_planes(3 * B * L2 * Ci)
         # fp16: dS = scale * P o (dP - <dP, P>) is ~ 1 / L2 of an activation gradient and would leave the fp16
         # range (6e-8) for long key axes (1568 keys in 64-frame clips); it is stored times a power of two, which
         # the two products that consume it divide out again in their epilogues (alpha).  Exact; 1 elsewhere.
@@ -387,14 +401,14 @@ class AttentionStep(Step):
         # times Blob.grad_scale (set at lowering), which the theta / phi convs divide out (ConvStep.gscale)
         gs_th, gs_ph = float(self.theta.root.grad_scale), float(self.phi.root.grad_scale)
         self.d_dth = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
-                          alpha=gs_th / self.ds_scale)
+                          alpha=gs_th / self.ds_scale, math=mb, **pl)
         # contract over L1: out[L2][Ci] = sum_l P[l][L2] * A[l][Ci]
         self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                   Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
-                                  o_bstride=L2 * Ci, splits=1)
+                                  o_bstride=L2 * Ci, splits=1, math=mb)
         self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                       Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
-                                      o_bstride=L2 * Ci, splits=1, alpha=gs_ph / self.ds_scale)
+                                      o_bstride=L2 * Ci, splits=1, alpha=gs_ph / self.ds_scale, math=mb)
         # 16-bit paths: scores + row softmax (and their backward) in one kernel each, the fp32 score matrix never
         # exists (csrc/vlfb_attn.hip) -- per direction, and only where the library reports the fused kernel as
         # measured faster; otherwise GEMM -> fp32 scratch -> softmax kernels
@@ -405,12 +419,25 @@ class AttentionStep(Step):
             eng.need_scratch_f32(B * L1 * L2)
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
 
+    def _planes(self, src, nplanes, transpose):
+        """bf16 term planes of a (B, L2, Ci) fp32 activation (optionally transposed per batch element): the B
+        operand of a split-math product"""
+        dst = self.eng.scratch_planes(nplanes * self.B * self.L2 * self.Ci)
+        hip.call("vlfb_split_planes", hip.ptr(src), hip.ptr(dst), nplanes, self.B, self.L2, self.Ci, int(transpose))
+        return dst
+
     def fwd(self):
         eng = self.eng
         B, Ci, L1, L2 = self.B, self.Ci, self.L1, self.L2
         if self.single:
             hip.call("vlfb_fbo_attn_fwd", self.theta.ptr(), self.phi.ptr(), self.g.ptr(), self.prob.ptr(),
                      self.out.ptr(), eng.code, B, L2, Ci, Ci, self.scale)
+            return
+        if eng.split:
+            S = eng.scratch_f32(B * L1 * L2)
+            hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), 3, False), None, S)
+            hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
+            hip.conv_run(self.d_y, self.prob.storage(), self._planes(self.g.storage(), 3, True), None, self.out.storage())
             return
         if self.fused_fwd:
             hip.call("vlfb_attn_scores_fwd", self.theta.ptr(), self.phi.ptr(), self.prob.ptr(), eng.code, B, L1, L2, Ci,
@@ -440,7 +467,7 @@ class AttentionStep(Step):
         P = self.prob.storage()
         if not self.fused_bwd:
             dP = eng.scratch_f32(B * L1 * L2)
-            hip.conv_run(self.d_dp, dY, self.g.storage(), None, dP)
+            hip.conv_run(self.d_dp, dY, self._planes(self.g.storage(), 2, False) if eng.split else self.g.storage(), None, dP)
         gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
                       supports_add=False, supports_mask=False)
         act = eng.scratch_act(B * L1 * L2 + B * Ci * L2)
@@ -452,7 +479,10 @@ class AttentionStep(Step):
         else:
             hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2,
                      self.scale * self.ds_scale)
-        hip.call("vlfb_transpose2d", self.phi.ptr(), hip.ptr(phT), eng.code, B, L2, Ci)
+        if eng.split:
+            phT = self._planes(self.phi.storage(), 2, True)
+        else:
+            hip.call("vlfb_transpose2d", self.phi.ptr(), hip.ptr(phT), eng.code, B, L2, Ci)
         th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
                       supports_add=False, supports_mask=False)
         ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.storage(), None, dS, out),
@@ -1181,8 +1211,15 @@ class Engine(object):
             raise hip.VlfbError("vlfb.engine needs a GPU: there is no CPU fallback for the hot path")
         self.model = model
         self.tdtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "fp32": torch.float32,
-                       "f32": torch.float32}[dtype]
+                       "f32": torch.float32, "split": torch.float32}[dtype]
         self.code = hip.dtype_code(self.tdtype)
+        # "split": fp32 storage everywhere (as "fp32"), every contraction on the bf16 matrix cores with the operands
+        # expanded into bf16 terms (csrc/vlfb_gemm_split.hip): six MFMAs per product forward (fp32-grade: ReLU / max-pool
+        # decisions must match the oracle's), three backward.  The parity-grade path at several times the fp32-MFMA rate.
+        self.split = dtype == "split"
+        self.math_fwd = self.SPLIT_MATH[0] if self.split else hip.MATH_NATIVE
+        self.math_bwd = self.SPLIT_MATH[1] if self.split else hip.MATH_NATIVE
+        self.wcode = hip.SPLIT if self.split else self.code      # format of the MFMA weight operand copies
         self.esize = 4 if self.tdtype == torch.float32 else 2
         # fp16 storage (v_mfma_f32_16x16x32_f16; BASELINE.json configs[4]): 10 mantissa bits instead of bf16's 7,
         # but gradients of 1e-6 fall below the fp16 normal range, so the loss gradient is scaled by a power of two
@@ -1202,6 +1239,7 @@ class Engine(object):
         self._ws_bytes = 0
         self._sf32 = 0
         self._sact = 0
+        self._spl = 0
         self.lr = float(model.current_lr)
         self.comm = None
         self.side = None
@@ -1218,6 +1256,9 @@ class Engine(object):
         self._graph_stream = None
         self._eager_steps = 0
         model.engine = self
+
+    # (forward, backward) math of the "split" dtype: hip.MATH_BF16X6 / MATH_BF16X3 (see __init__)
+    SPLIT_MATH = (6, 3)
 
     # ---- side stream for parameter gradients ---------------------------------------------------
     class _Side(object):
@@ -1265,6 +1306,13 @@ class Engine(object):
 
     def need_scratch_act(self, n):
         self._sact = max(self._sact, int(n))
+
+    def need_scratch_planes(self, n):
+        self._spl = max(self._spl, int(n))
+
+    def scratch_planes(self, n):
+        assert n <= self._scratch_pl.numel()
+        return self._scratch_pl[:n]
 
     def scratch_f32(self, n):
         assert n <= self._scratch_f32.numel()
@@ -1451,6 +1499,7 @@ class Engine(object):
         biggest = max([b.tensor.numel() for b in self.all_blobs
                        if b.root is b and b.kind == "act" and b.tensor is not None] + [4])
         self._scratch_act = torch.empty(max(self._sact, biggest), device=dev, dtype=self.tdtype)
+        self._scratch_pl = torch.empty(max(self._spl, 8), device=dev, dtype=torch.bfloat16)
 
     # ---- parameters ---------------------------------------------------------------------------
     def _to_kernel_layout(self, name, arr):
@@ -1558,7 +1607,7 @@ class Engine(object):
         tab = self._wprep["all" if all_params else "trainable"]
         if tab is not None:
             dev, n, tiles = tab
-            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.code)
+            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.wcode)
         for st in self.steps:
             if isinstance(st, ConvStep) and st.eff_bias is not None and (all_params or st.params):
                 st.refresh_bias()
@@ -1787,7 +1836,7 @@ class Engine(object):
             self._sgd_launch(off, end, wd, lr)
         if b["wprep"] is not None:
             dev, n, tiles = b["wprep"]
-            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.code)
+            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.wcode)
         for st in b["bias_steps"]:
             st.refresh_bias()
 

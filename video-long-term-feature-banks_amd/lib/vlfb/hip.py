@@ -11,6 +11,8 @@ import os
 import torch
 
 F32, BF16, F16 = 0, 1, 2
+SPLIT = 3                                           # weight-operand format of the split-bf16 path (vlfb.h VLFB_SPLIT)
+MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6     # vlfb_conv_desc.math
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256, ALGO_STREAM = 0, 1, 2, 3
@@ -53,6 +55,7 @@ class ConvDesc(C.Structure):
         ("r_bstride", C.c_int64), ("p_bstride", C.c_int64),
         ("alpha", C.c_float), ("relu", C.c_int32), ("bias_mode", C.c_int32),
         ("accumulate", C.c_int32), ("splits", C.c_int32), ("algo", C.c_int32),
+        ("math", C.c_int32), ("b_pstride", C.c_int64),
     ]
 
 
@@ -95,6 +98,7 @@ _SIGS = {
     "vlfb_transpose2d": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_copy2d": (C.c_int, [_P, _I64, _P, _I64, C.c_int, _I64, _I64, _P]),
     "vlfb_zero_f32": (C.c_int, [_P, _I64, _P]),
+    "vlfb_split_planes": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, C.c_int, _P]),
     "vlfb_weight_prep": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_weight_prep_batched": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vlfb_pool_argmax_bytes": (C.c_int, [C.POINTER(PoolDesc)]),
