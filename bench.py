@@ -30,7 +30,6 @@ for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "split": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                           # HBM3E spec peak (same guide; ~6.3 TB/s measured copy)
-FWD_BWD_GFLOP_PER_CLIP = 1106.1                 # R50-I3D-NL backbone, 3x fwd - conv1 dgrad
 
 
 def parse():
@@ -63,7 +62,45 @@ def parse():
                     help="development: replay the single-GPU step (or its forward pass) as one captured HIP graph "
                          "(Engine.STEP_GRAPH; measured slower than the two-stream enqueue, see engine.py)")
     ap.add_argument("--detail", default="", help="write the per-launch GEMM table of the profiled step to this file")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (with VLFB_DIST_FORCE=1 the "
+                         "one-rank job then runs the RCCL leg: communicator, bucketed all-reduce, stream hand-over)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched job (0 = pick a free one)")
+    ap.add_argument("--split-steps", type=int, default=5, help="timed steps of the extra split-bf16 parity-path measurement")
+    ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 parity-path measurement")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 -- the job create_data_parallel_model describes
+    (lib/models/model_builder_video.py:142-157), one process per GPU instead of one process for all.  Rank 0 prints the
+    JSON line; the return code is the job's."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["VLFB_BENCH_CHILD"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources of libvlfb_hip.so (what a committed PMC traffic file is valid for)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "video-long-term-feature-banks_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def cpu_baseline(workload, frames, crop, rois_per_clip):
@@ -98,11 +135,16 @@ def cpu_baseline(workload, frames, crop, rois_per_clip):
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and not os.environ.get("VLFB_BENCH_CHILD") and (args.gpus > 1 or args.launch):
+        sys.exit(self_launch(args))
     import torch
     from vlfb import dist
     dist.init_from_env()
     world, rank = dist.world_size(), dist.rank()
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the job has %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus %d` "
+                         "(self-launching) or through torch.distributed.run with --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus, args.gpus))
     device = "cuda:%d" % dist.local_rank()
     torch.cuda.set_device(device)
 
@@ -179,15 +221,18 @@ def main():
     # HBM bytes per launch: PMC counters cannot be read from inside this process, so they come from the
     # committed rocprofv3 --pmc passes of THIS command line (profiles/*_hbm_traffic.json, made by
     # scratch/pmc_traffic.py); any other workload / dtype / batch reports null and says why
+    # A traffic file is only valid for the kernels it was measured on: it carries the hash of csrc/ at measurement time
+    # (scratch/pmc_traffic.py) and anything else -- another workload, an edited kernel, an unstamped file -- reports null.
     traffic, traffic_source = {}, "none: no committed PMC pass for this workload/dtype/batch"
-    for tname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if args.workload == "ava_r50_lfb_nl" and args.dtype == "bf16" and clips == 8 and os.path.exists(tpath):
-            t = json.load(open(tpath))
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if args.workload == "ava_r50_lfb_nl" and args.dtype == "bf16" and clips == 8 and os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("csrc_sha256") == kernel_source_hash():
             traffic = {"nt": t["gemm_nt"]["bytes_per_launch"], "tn": t["gemm_tn"]["bytes_per_launch"]}
-            traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, read side x2 " \
-                             "per MI355X_MICROARCH.md; not measured in this run)" % tname
-            break
+            traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on " \
+                             "this kernel source, read side x2 per MI355X_MICROARCH.md; not measured in this run)"
+        else:
+            traffic_source = "none: profiles/hbm_traffic.json was measured on other kernel sources (csrc hash differs)"
     if args.detail and rank == 0:
         with open(args.detail, "w") as fh:
             agg = collections.OrderedDict()
@@ -233,34 +278,55 @@ def main():
                     "parallelism": "dp%d" % world, "final_loss": loss}),
         ("roofline", roof("nt", "gemm_nt_kernel (implicit-GEMM conv fprop+dgrad, attention NT GEMMs)")),
         ("roofline_wgrad", roof("tn", "gemm_tn_kernel (implicit-GEMM conv wgrad, attention TN GEMMs)")),
-        ("model_flops_utilisation", round(value * FWD_BWD_GFLOP_PER_CLIP / 1e3 / (world * peak), 4)),
+        # algorithmic FLOP of every contraction the step launched (this rank's plan: convs, attention products, head) per
+        # wall second against the MFMA peak of all GPUs
+        ("model_flops_utilisation", round((fam["nt"][0] + fam["tn"][0]) * args.steps / elapsed / 1e12 / peak, 4)),
+        ("gflop_per_step_per_gpu", round((fam["nt"][0] + fam["tn"][0]) / 1e9, 1)),
         ("host_enqueue_ms_per_step", round(host_ms, 2)),
     ])
-    if world == 1 and args.dtype != "fp32" and not args.no_fp32_line:
-        # the parity-grade path (exact-fp32 MFMA, fp32 storage: outputs AND gradients within 1e-3 of the fp64
-        # oracle) on the same workload, so that the number next to the parity claim exists
-        try:
-            del eng
-            torch.cuda.empty_cache()
-            eng32 = Engine(model, "fp32", device=device, base_seed=cfg.RNG_SEED)
-            eng32.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in model.input_blob_names))
-            eng32.feed_params(synth.params(model, seed=cfg.RNG_SEED))
-            for k, v in batch.items():
-                if k in model.input_blob_names:
-                    eng32.feed(k, v)
-            eng32.train_step(lr)
-            torch.cuda.synchronize()
-            t32 = time.perf_counter()
-            for _ in range(args.fp32_steps):
-                eng32.train_step(lr)
-            torch.cuda.synchronize()
-            dt32 = (time.perf_counter() - t32) / max(args.fp32_steps, 1)
-            out["fp32_path"] = {"value": round(clips / dt32, 3), "unit": "clips/s", "ms_per_step": round(dt32 * 1e3, 3),
-                                "steps": args.fp32_steps, "dtype": "fp32 storage + v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak)",
-                                "model_flops_utilisation": round(clips / dt32 * FWD_BWD_GFLOP_PER_CLIP / 1e3 / PEAK_TFLOPS["fp32"], 4)}
-            del eng32
-        except Exception as e:   # a report, never a gate
-            out["fp32_path"] = {"value": None, "error": repr(e)}
+    if eng.comm is not None:       # the gradient exchange of this job (None on a one-process run without a process group)
+        out["allreduce"] = {"backend": torch.distributed.get_backend(), "buckets": len(eng.comm.buckets),
+                            "bucket_mb": args.bucket_mb, "payload_mb": round(eng.flat_grad.numel() * 4 / 1e6, 1),
+                            "handoff": Engine.BUCKET_HANDOFF}
+    # The parity-grade paths on the same workload, so that the numbers next to the parity claims exist:
+    #   split_path: fp32 storage, every contraction as split-bf16 products on the bf16 matrix cores (six MFMAs per product
+    #               forward, three backward; csrc/vlfb_gemm_split.hip) -- outputs AND every parameter gradient within 1e-3 of
+    #               the fp64 oracle at the benchmarked size (profiles/r03_parity_fullsize_*.txt)
+    #   fp32_path:  the same with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 matrix rate)
+    step_flops = fam["nt"][0] + fam["tn"][0]
+
+    def extra_path(dtype, steps, what, peak_tf):
+        eng2 = Engine(model, dtype, device=device, base_seed=cfg.RNG_SEED)
+        eng2.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in model.input_blob_names))
+        eng2.feed_params(synth.params(model, seed=cfg.RNG_SEED))
+        for k, v in batch.items():
+            if k in model.input_blob_names:
+                eng2.feed(k, v)
+        eng2.train_step(lr)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            eng2.train_step(lr)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t2) / max(steps, 1)
+        return {"value": round(clips / dt, 3), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": what,
+                "model_flops_utilisation": round(step_flops / dt / 1e12 / peak_tf, 4), "peak_tflops": peak_tf}
+
+    if world == 1 and args.dtype not in ("fp32", "split"):
+        del eng
+        torch.cuda.empty_cache()
+        for key, dtype, steps, skip, what, peak_tf in (
+                ("split_path", "split", args.split_steps, args.no_split_line,
+                 "fp32 storage + split-bf16 products on v_mfma_f32_16x16x32_bf16 (6 per product forward, 3 backward)", 2500.0 / 4.0),
+                ("fp32_path", "fp32", args.fp32_steps, args.no_fp32_line,
+                 "fp32 storage + v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak)", PEAK_TFLOPS["fp32"])):
+            if skip:
+                continue
+            try:
+                out[key] = extra_path(dtype, steps, what, peak_tf)
+                torch.cuda.empty_cache()
+            except Exception as e:   # a report, never a gate
+                out[key] = {"value": None, "error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -328,6 +328,11 @@ int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* rois, void*
                            uint8_t* argbin, int32_t* dbg, int64_t n, int64_t h, int64_t w,
                            int64_t c, int64_t r, int pooled, float spatial_scale,
                            vlfb_stream_t stream);
+/* Test hook: the integer decisions of EVERY bilinear sample of every bin, from the same device functions the operator
+ * uses: dbg int32 [R][pooled][pooled][max_grid][max_grid][8] = {batch, grid_h, grid_w, y_low, x_low, y_high, x_high,
+ * inside}; samples beyond the RoI's adaptive grid carry {.., -2, -2, -2, -2, -1}. */
+int vlfb_roi_align_decisions(const float* rois, int32_t* dbg, int64_t h, int64_t w, int64_t r, int pooled,
+                             float spatial_scale, int max_grid, vlfb_stream_t stream);
 /* dfeat (fp32 [N,H,W,C], must be zeroed by the caller) += scatter of dout through argbin */
 int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois, const uint8_t* argbin,
                            float* dfeat, int64_t n, int64_t h, int64_t w, int64_t c, int64_t r,

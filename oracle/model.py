@@ -217,11 +217,50 @@ def synth_inputs(cfg, n_clips, split="train", seed=2, rois_per_clip=None, crop=N
 # graph
 # --------------------------------------------------------------------------------------------
 class _Ctx(object):
-    def __init__(self, cfg, P, split, dropout_seed_fn, blobs_out):
+    def __init__(self, cfg, P, split, dropout_seed_fn, blobs_out, decisions=None):
         self.cfg, self.P, self.split = cfg, P, split
         self.test = split in ("test", "val")
         self.seed_fn = dropout_seed_fn
         self.B = blobs_out
+        # Discrete decisions handed in by the caller (see `run`): the sign pattern of every ReLU output and the selected
+        # window element of every max pool.  The oracle then evaluates THOSE branches of the piecewise-linear network
+        # instead of taking its own -- a parity check of the arithmetic that a tie at zero cannot disturb.
+        self.dec = decisions
+        self.dec_used, self.dec_missing = set(), set()
+
+
+def _relu(cx, x, name):
+    """ReLU; with caller-supplied decisions: x * [the caller's output was > 0]"""
+    m = cx.dec["relu"].get(name) if cx.dec else None
+    if m is None:
+        if cx.dec:
+            cx.dec_missing.add(name)
+        return torch.relu(x)
+    cx.dec_used.add(name)
+    return x * torch.from_numpy(np.ascontiguousarray(m)).reshape(x.shape).to(x.dtype)
+
+
+def _max_pool(cx, x, name, k, s, p=(0, 0, 0)):
+    """MaxPool over (T, H, W) windows; with caller-supplied decisions (`tap` = index of the selected element inside its
+    window in t, h, w scan order, shape of the output) the output GATHERS those elements"""
+    tap = cx.dec["pool"].get(name) if cx.dec else None
+    if tap is None:
+        if cx.dec:
+            cx.dec_missing.add(name)
+        return F.max_pool3d(x, k, s, p)
+    cx.dec_used.add(name)
+    tap = torch.from_numpy(np.ascontiguousarray(tap)).to(torch.int64)
+    N, C, T, H, W = x.shape
+    To, Ho, Wo = tap.shape[2:]
+    a, rem = tap // (k[1] * k[2]), tap % (k[1] * k[2])
+    b, c = rem // k[2], rem % k[2]
+    ti = torch.arange(To).view(1, 1, To, 1, 1) * s[0] - p[0] + a
+    hi = torch.arange(Ho).view(1, 1, 1, Ho, 1) * s[1] - p[1] + b
+    wi = torch.arange(Wo).view(1, 1, 1, 1, Wo) * s[2] - p[2] + c
+    assert int(ti.min()) >= 0 and int(ti.max()) < T and int(hi.min()) >= 0 and int(hi.max()) < H and \
+        int(wi.min()) >= 0 and int(wi.max()) < W, "max-pool decision of %s selects a padding element" % name
+    lin = (ti * H + hi) * W + wi
+    return x.flatten(2).gather(2, lin.flatten(2)).reshape(N, C, To, Ho, Wo)
 
 
 def _affine(x, P, prefix):
@@ -243,15 +282,15 @@ def _conv_affine(cx, x, prefix, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
 def _bottleneck(cx, x, prefix, dim_in, dim_out, stride, utc, dilation):
     """bottleneck_transformation_3d + _add_shortcut_3d + _generic_residual_block_3d
     (lib/models/resnet_helper.py:35-119)"""
-    h = torch.relu(_conv_affine(cx, x, prefix + "_branch2a", pad=(utc, 0, 0)))
-    h = torch.relu(_conv_affine(cx, h, prefix + "_branch2b", stride=(1, stride, stride),
-                                pad=(0, dilation, dilation), dil=(1, dilation, dilation)))
+    h = _relu(cx, _conv_affine(cx, x, prefix + "_branch2a", pad=(utc, 0, 0)), prefix + "_branch2a_bn")
+    h = _relu(cx, _conv_affine(cx, h, prefix + "_branch2b", stride=(1, stride, stride),
+                               pad=(0, dilation, dilation), dil=(1, dilation, dilation)), prefix + "_branch2b_bn")
     h = _conv_affine(cx, h, prefix + "_branch2c")
     if dim_in == dim_out and stride == 1:
         sc = x
     else:
         sc = _conv_affine(cx, x, prefix + "_branch1", stride=(1, stride, stride))
-    y = torch.relu(h + sc)
+    y = _relu(cx, h + sc, prefix + "_branch2c_bn")
     cx.B[prefix + "_branch2c_bn"] = y  # the in-place Sum/ReLU make this the block output blob
     return y
 
@@ -261,7 +300,7 @@ def _spacetime_nonlocal(cx, x, prefix, dim_inner):
     cfg, P = cx.cfg, cx.P
     Bn = x.shape[0]
     theta = _conv(x, P, prefix + "_theta")
-    xp = F.max_pool3d(x, (1, 2, 2), (1, 2, 2)) if cfg.NONLOCAL.USE_MAXPOOL else x
+    xp = _max_pool(cx, x, prefix + "_pool", (1, 2, 2), (1, 2, 2)) if cfg.NONLOCAL.USE_MAXPOOL else x
     phi = _conv(xp, P, prefix + "_phi")
     g = _conv(xp, P, prefix + "_g")
     shp5 = theta.shape
@@ -328,7 +367,7 @@ def _nl_core(cx, A, Bk, prefix, latent, num_feat2):
     if cfg.FBO_NL.PRE_ACT:
         if cfg.FBO_NL.PRE_ACT_LN:
             t = _layer_norm(t)
-        t = torch.relu(t)
+        t = _relu(cx, t, prefix + "_y_ln_relu")
     out = _conv(t, P, prefix + "_out")
     if not cfg.FBO_NL.PRE_ACT:
         out = _layer_norm(out)
@@ -364,7 +403,7 @@ def _fbo_head(cx, x, x_name, lfb, num_lfb_feat):
         pre = "lfb_nl%d" % l
         A = _nl_core(cx, A, Bk, pre, lat, num_lfb_feat) + A
         if not cfg.FBO_NL.PRE_ACT:
-            A = torch.relu(A)
+            A = _relu(cx, A, pre + "_relu")
         cx.B[pre + ("_sum" if cfg.FBO_NL.PRE_ACT else "_relu")] = A
     return A
 
@@ -388,12 +427,14 @@ def softmax_with_loss(logits, labels, scale):
 
 
 def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torch.float64,
-            dropout_seed_fn=None, suffix="", num_gpus=None):
+            dropout_seed_fn=None, suffix="", num_gpus=None, decisions=None):
     """resnet_video.create_model (lib/models/resnet_video.py:133-351).
     params: {name: tensor} in reference layouts; inputs: data/labels/proposals/lfb tensors.
     Returns an OrderedDict of named blobs (reference names, NCTHW)."""
     B = OrderedDict()
-    cx = _Ctx(cfg, params, split, dropout_seed_fn or (lambda name: 0), B)
+    cx = _Ctx(cfg, params, split, dropout_seed_fn or (lambda name: 0), B, decisions)
+    if decisions is not None:      # which supplied decisions were consumed / which sites decided for themselves
+        decisions["_used"], decisions["_missing"] = cx.dec_used, cx.dec_missing
     arc = temporal_arc(cfg)
     n1, n2, n3, n4 = BLOCK_CONFIG[cfg.MODEL.DEPTH]
     x = inputs["data"].to(dtype)
@@ -402,9 +443,9 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
     pool_stride = int(frames / 2)
     utc1 = arc[0][0]
     x = F.conv3d(x, params["conv1_w"], None, (1, 2, 2), (utc1, 3, 3))
-    x = torch.relu(_affine(x, params, "res_conv1_bn"))
+    x = _relu(cx, _affine(x, params, "res_conv1_bn"), "res_conv1_bn")
     B["res_conv1_bn"] = x
-    x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    x = _max_pool(cx, x, "pool1", (1, 3, 3), (1, 2, 2), (0, 1, 1))
     B["pool1"] = x
     w = cfg.RESNETS.NUM_GROUPS * cfg.RESNETS.WIDTH_PER_GROUP
     mod3 = 2 if cfg.MODEL.DEPTH == 101 else cfg.NONLOCAL.LAYER_MOD
@@ -427,7 +468,7 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
         return x
 
     x = stage(x, "res2", n1, 64, 256, 1, arc[1], 1, 1000, None, False)
-    x = F.max_pool3d(x, (2, 1, 1), (2, 1, 1))
+    x = _max_pool(cx, x, "pool2", (2, 1, 1), (2, 1, 1))
     B["pool2"] = x
     x = stage(x, "res3", n2, 256, 512, 2, arc[2], 1, mod3, "nonlocal_conv3", True)  # USE_AFFINE branch: grouped
     x = stage(x, "res4", n3, 512, 1024, 2, arc[3], 1, mod4, "nonlocal_conv4", False)
@@ -448,7 +489,12 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
         rf = roi_align_torch(pooled, np.asarray(rois, dtype=np.float32), res, 1.0 / cfg.ROI.SCALE_FACTOR)
         B["roi_feat_3d"] = rf
         if res > 1:
-            rf = F.max_pool2d(rf, (res, res), (1, 1))
+            if decisions is not None and decisions.get("roi_bin") is not None:   # the caller's arg-max bin per (RoI, channel)
+                binidx = torch.from_numpy(np.ascontiguousarray(decisions["roi_bin"])).to(torch.int64)
+                rf = rf.flatten(2).gather(2, binidx.view(rf.shape[0], rf.shape[1], 1)).view(rf.shape[0], rf.shape[1], 1, 1)
+                cx.dec_used.add("roi_bin")
+            else:
+                rf = F.max_pool2d(rf, (res, res), (1, 1))
         feat = rf.reshape(-1, 2048, 1, 1, 1)
         B["box_pooled"] = feat
         x_name = "box_pooled"
@@ -485,8 +531,15 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
 
 
 def run(cfg, params_np, inputs_np, split="train", dtype=torch.float64, backward=True,
-        dropout_seed_fn=None, lfb_infer_only=False, num_gpus=None, threads=None):
-    """Convenience wrapper: numpy in, (blobs, grads) out (all torch tensors of `dtype`)."""
+        dropout_seed_fn=None, lfb_infer_only=False, num_gpus=None, threads=None, decisions=None):
+    """Convenience wrapper: numpy in, (blobs, grads) out (all torch tensors of `dtype`).
+
+    decisions (optional) = {"relu": {blob: bool array, reference layout}, "pool": {blob: selected tap per output
+    element}, "roi_bin": (R, C) arg-max bin}: the discrete decisions of ANOTHER evaluation of the same network (the
+    engine under test, vlfb.engine.Engine.discrete_decisions).  The network is piecewise linear in between, and a
+    pre-activation within fp32 rounding of zero is decided one way in fp64 and possibly the other way in fp32; ONE such
+    unit of res5 moves every upstream gradient by ~1e-3 when the loss gradient is sparse (AVA: a few RoIs).  With the
+    decisions supplied the comparison measures the arithmetic on identical branches."""
     if threads:
         torch.set_num_threads(threads)
     P = OrderedDict()
@@ -500,7 +553,7 @@ def run(cfg, params_np, inputs_np, split="train", dtype=torch.float64, backward=
     for k, v in inputs_np.items():
         t = torch.from_numpy(np.asarray(v))
         I[k] = t if t.dtype in (torch.int32, torch.int64) or k == "proposals" else t.to(dtype)
-    blobs = forward(cfg, P, I, split, lfb_infer_only, dtype, dropout_seed_fn, num_gpus=num_gpus)
+    blobs = forward(cfg, P, I, split, lfb_infer_only, dtype, dropout_seed_fn, num_gpus=num_gpus, decisions=decisions)
     grads = OrderedDict()
     if backward and "loss" in blobs:
         blobs["loss"].backward()

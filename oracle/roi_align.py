@@ -84,6 +84,29 @@ def roi_align_loop(feat, rois, pooled=7, spatial_scale=1.0 / 16):
     return out, dbg
 
 
+def roi_decisions(rois, H, W, pooled=7, spatial_scale=1.0 / 16, max_grid=4):
+    """integer decisions of EVERY bilinear sample: (R, pooled, pooled, max_grid, max_grid, 8) int32 =
+    {batch, grid_h, grid_w, y_low, x_low, y_high, x_high, inside}; samples beyond the RoI's adaptive grid carry
+    {.., -2, -2, -2, -2, -1} (the layout of vlfb_roi_align_decisions)"""
+    R = rois.shape[0]
+    dbg = np.zeros((R, pooled, pooled, max_grid, max_grid, 8), dtype=np.int32)
+    for r in range(R):
+        batch, start_w, start_h, bin_h, bin_w, grid_h, grid_w = _geom(rois[r], spatial_scale, pooled)
+        assert grid_h <= max_grid and grid_w <= max_grid
+        for ph in range(pooled):
+            for pw in range(pooled):
+                for iy in range(max_grid):
+                    for ix in range(max_grid):
+                        if iy >= grid_h or ix >= grid_w:
+                            dbg[r, ph, pw, iy, ix] = [batch, grid_h, grid_w, -2, -2, -2, -2, -1]
+                            continue
+                        y = f32(f32(start_h + f32(f32(ph) * bin_h)) + f32(f32(f32(f32(iy) + f32(0.5)) * bin_h) / f32(grid_h)))
+                        x = f32(f32(start_w + f32(f32(pw) * bin_w)) + f32(f32(f32(f32(ix) + f32(0.5)) * bin_w) / f32(grid_w)))
+                        inside, yl, xl, yh, xh = _bilinear(y, x, H, W)[:5]
+                        dbg[r, ph, pw, iy, ix] = [batch, grid_h, grid_w, yl, xl, yh, xh, int(inside)]
+    return dbg
+
+
 def roi_align_vec(feat, rois, pooled=7, spatial_scale=1.0 / 16):
     """Independent vectorised implementation (per RoI: all bins x samples at once)."""
     N, C, H, W = feat.shape

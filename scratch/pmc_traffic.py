@@ -3,7 +3,8 @@
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.txt> <out.json> "<command line>"
 Units: the counters are KiB; FETCH_SIZE is doubled (gfx950 counts 128-byte requests of wide
 coalesced reads as 64 B)."""
-import sys, glob, sqlite3, json, collections
+import sys, glob, sqlite3, json, collections, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_family(root, counter):
@@ -12,7 +13,7 @@ def per_family(root, counter):
     fam = collections.defaultdict(lambda: [0, 0.0])
     q = "select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name = ? group by dispatch_id"
     for name, _, v in cur.execute(q, (counter,)):
-        key = 'gemm_nt' if ('gemm_nt_kernel' in name or 'gemm_nt8_kernel' in name or 'gemm_nts_kernel' in name or 'stem_fprop_kernel' in name or 'conv_rows64_kernel' in name) else 'gemm_tn' if ('gemm_tn_' in name or 'gemm_tn8_' in name or 'stem_wgrad' in name or 'wgrad_rows' in name or 'wgrad_reduce' in name) else None
+        key = 'gemm_nt' if ('gemm_nt_kernel' in name or 'gemm_nt_sp_kernel' in name or 'gemm_nt8_kernel' in name or 'gemm_nts_kernel' in name or 'stem_fprop_kernel' in name or 'conv_rows64_kernel' in name) else 'gemm_tn' if ('gemm_tn_' in name or 'gemm_tn8_' in name or 'stem_wgrad' in name or 'wgrad_rows' in name or 'wgrad_reduce' in name) else None
         if key:
             if 'wgrad_reduce' not in name:
                 fam[key][0] += 1
@@ -33,6 +34,9 @@ for k in ('gemm_nt', 'gemm_tn'):
     lines.append("%-8s launches %5d  FETCH_SIZE/launch %8.2f MiB (x2 corrected %8.2f MiB)  WRITE_SIZE/launch %8.2f MiB  -> HBM traffic/launch %8.2f MiB"
                  % (k, n, fm, 2 * fm, wm, tot))
     js[k] = {"launches": n, "bytes_per_launch": tot * 1048576.0}
+from bench import kernel_source_hash
+js["csrc_sha256"] = kernel_source_hash()      # bench.py reports these bytes only for the kernel sources they were measured on
+js["command"] = cmd
 open(out_txt, 'w').write('\n'.join(lines) + '\n')
 json.dump(js, open(out_json, 'w'))
 print('\n'.join(lines))

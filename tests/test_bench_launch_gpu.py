@@ -1,0 +1,40 @@
+"""bench.py starts its own ranks: `python bench.py --gpus N` without a launcher re-executes itself under
+torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous) and rank 0 prints the one JSON line.  On the one-GPU
+box the path is driven with --launch and VLFB_DIST_FORCE=1, which makes the single rank a real RCCL job: communicator,
+weight broadcast, bucketed all-reduce during backward (model_builder_video.py:142-157)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VLFB_BENCH_CHILD", "VLFB_DIST_FORCE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--clips-per-gpu", "1", "--frames", "16",
+           "--crop", "64", "--no-cpu-baseline", "--no-fp32-line", "--no-split-line"] + extra
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    return r
+
+
+def test_self_launched_one_rank_rccl_job_prints_one_json_line():
+    r = _run(["--gpus", "1", "--launch"], {"VLFB_DIST_FORCE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["allreduce"]["backend"] == "nccl" and out["allreduce"]["buckets"] >= 1, out.get("allreduce")
+
+
+def test_job_size_mismatch_is_an_error_not_a_hang():
+    """a rank count that differs from --gpus must fail before any GPU work (it used to be a bare assert)"""
+    r = _run(["--gpus", "2"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)

@@ -60,3 +60,36 @@ def test_bucketed_allreduce_world_size_2():
         p.join(120)
         assert p.exitcode == 0
     assert dict(out) == {0: 1, 1: 1}
+
+
+def _convert_worker(rank, world, port, ckpt_dir, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "video-long-term-feature-banks_amd", "lib"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from core.config import config as cfg
+    import utils.checkpoints as ck
+    cfg.CHECKPOINT.DIR = ckpt_dir
+    try:
+        ck.convert_model(os.path.join(ckpt_dir, "does_not_exist.pkl"))
+        out[rank] = "returned"
+    except Exception as e:
+        out[rank] = type(e).__name__
+    td.destroy_process_group()
+
+
+def test_failed_conversion_on_rank_0_raises_on_every_rank_instead_of_hanging(tmp_path):
+    """rank 0 converts the pretrained file and the others wait for it (utils/checkpoints.py convert_model): a missing /
+    corrupt file on rank 0 must end the job everywhere -- the other ranks used to sit in the barrier forever"""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_convert_worker, args=(r, world, port, str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "a rank hung or crashed"
+    assert set(out.keys()) == {0, 1} and all(v != "returned" for v in out.values()), dict(out)

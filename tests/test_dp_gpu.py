@@ -103,7 +103,7 @@ def test_two_replicas_match_one_process_with_both_clips():
         assert rel(results[0][n], eng.fetch_grad(n)) < 2e-4, (n, rel(results[0][n], eng.fetch_grad(n)))
 
 
-def _nccl_worker(port, q):
+def _nccl_worker(port, q, handoff):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       VLFB_DIST_FORCE="1", VLFB_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -111,6 +111,8 @@ def _nccl_worker(port, q):
     from vlfb.presets import load_preset
     from core.config import config as cfg
     from oracle import model as om
+    from vlfb.engine import Engine
+    Engine.BUCKET_HANDOFF = handoff
     dist.init_from_env()
     assert torch.distributed.get_backend() == "nccl"
     load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1] + OV)
@@ -123,16 +125,19 @@ def _nccl_worker(port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_rccl_bucketed_allreduce_one_rank():
+@pytest.mark.parametrize("handoff", ["streams", "join"])
+def test_rccl_bucketed_allreduce_one_rank(handoff):
     """the RCCL (backend "nccl") leg of GradComm on the one visible GPU: communicator set-up, weight
-    broadcast, async bucket all-reduces issued during backward, solver-side wait.  A one-rank sum is
-    the identity, so the gradients must equal those of a run without a process group."""
+    broadcast, async bucket all-reduces issued during backward, solver-side wait -- with the bucket hand-off on the
+    third stream (two events, no compute stream waits) and with the conservative main-stream join
+    (Engine.BUCKET_HANDOFF).  A one-rank sum is the identity, so the gradients must equal those of a run without a
+    process group."""
     import torch.multiprocessing as mp
     _setup_paths()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_nccl_worker, args=(port, q))
+    p = ctx.Process(target=_nccl_worker, args=(port, q, handoff))
     p.start()
     got = q.get(timeout=600)
     p.join(120)

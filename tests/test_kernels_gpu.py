@@ -542,6 +542,13 @@ def test_roi_align_max_head(dtype):
     hip.call("vlfb_roi_align_max_fwd", hip.ptr(Fg), code, gp(rois), hip.ptr(O), hip.ptr(AB), hip.ptr(DBG),
              N, H, W, Cc, R, 7, 1.0 / 16)
     assert np.array_equal(DBG.cpu().numpy(), dbg_np), "RoIAlign integer decisions must be bit-exact"
+    if dtype == torch.float32:
+        # ... and those of EVERY grid sample (2 x 2 per bin for the largest box here), not only the first of each bin
+        from oracle.roi_align import roi_decisions
+        ALL = torch.empty(R, 7, 7, 3, 3, 8, device=dev(), dtype=torch.int32)
+        hip.call("vlfb_roi_align_decisions", gp(rois), hip.ptr(ALL), H, W, R, 7, 1.0 / 16, 3)
+        want = roi_decisions(rois.numpy(), H, W, 7, 1.0 / 16, 3)
+        assert want[..., 1].max() >= 2 and np.array_equal(ALL.cpu().numpy(), want)
     flat = torch.from_numpy(out_np).reshape(R, Cc, 49)
     ref_max, ref_arg = flat.max(dim=2)
     assert rel_err(O.float(), q(ref_max, dtype)) < (1e-6 if dtype == torch.float32 else 4e-3)

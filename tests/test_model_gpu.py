@@ -111,7 +111,18 @@ def test_forward_backward_matches_oracle(preset, dtype):
     out_err = dict(report)
     assert out_err["prob"] < 1e-3 and out_err["loss"] < 1e-3, report
     if dtype in ("fp32", "split"):
+        # raw comparison: one ReLU / max-pool tie decided differently in fp32 and fp64 shifts every gradient upstream of
+        # it (module docstring) -- regression gate only
         assert med < 1e-3 and worst[0][1] < 5e-3, (med, worst)
+        # the parity claim: on the SAME branches (oracle re-evaluated with this engine's discrete decisions) every
+        # parameter gradient is inside the north-star bar
+        dec = eng.discrete_decisions()
+        _, g2 = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn, decisions=dec)
+        assert not dec["_missing"], sorted(dec["_missing"])
+        cond = sorted(((rel(eng.fetch_grad(n), g2[n].numpy()), n) for n, _ in greport), reverse=True)
+        print("[%s %s] gradients on identical ReLU / max-pool decisions: median %.2e worst %s"
+              % (preset, dtype, float(np.median([x for x, _ in cond])), ["%s=%.2e" % (n, x) for x, n in cond[:4]]))
+        assert cond[0][0] < 1e-3, cond[:5]
     else:
         assert p90 < 0.12 and worst[0][1] < 0.30, (p90, worst)
 
@@ -183,6 +194,23 @@ def test_fp16_path_matches_oracle(preset):
     assert rel(eng.fetch_param("pred_w"), want) < 1e-5
 
 
+def test_fp16_scaled_activation_gradients_are_fetched_unscaled():
+    """fp16 keeps the theta / phi gradients of a non-local block times a power of two (Blob.grad_scale) so that they
+    stay in the fp16 normal range; Engine.fetch('<blob>_grad') has to divide that out again (and the loss scale)"""
+    got = {}
+    for dtype in ("fp32", "fp16"):
+        cfg, model, eng, inputs, params, seed_fn = build("charades_r50_baseline", dtype)
+        eng.forward()
+        eng.backward()
+        torch.cuda.synchronize()
+        if dtype == "fp16":
+            assert eng.env["nonlocal_conv4_1_theta"].root.grad_scale > 1.0 and eng.loss_scale > 1.0
+        got[dtype] = {n: eng.fetch(n + "_grad") for n in ("nonlocal_conv4_1_theta", "nonlocal_conv4_1_phi", "nonlocal_conv4_1_g")}
+        del eng
+    for n in got["fp32"]:
+        assert rel(got["fp16"][n], got["fp32"][n]) < 5e-2, (n, rel(got["fp16"][n], got["fp32"][n]))
+
+
 def test_c5_r101_64_frame_clip_fp16_full_size():
     """BASELINE.json configs[4] / SURVEY 8d C5 at real size: ava_r101_lfb_nl_3l (R101-I3D-NL, 23 res4 blocks,
     3-layer FBO-NL), ONE 64-frame 224^2 clip (pool stride 32, 8 non-local groups in res3, res4 affinities
@@ -246,25 +274,47 @@ def test_full_size_clip_matches_oracle(preset):
         ref_loss = float(blobs["loss"].detach())
         acts.append(("loss", abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) / abs(ref_loss)))
         gmax = max(float(g.norm()) for g in grads.values())
-        gerr = [(n, rel(eng.fetch_grad(n), grads[n].numpy())) for n in eng.trainable
-                if float(grads[n].norm()) > 1e-9 * gmax]
+        names = [n for n in eng.trainable if float(grads[n].norm()) > 1e-9 * gmax]
+        got_g = {n: eng.fetch_grad(n) for n in names}
+        gerr = [(n, rel(got_g[n], grads[n].numpy())) for n in names]
         e = np.sort([x for _, x in gerr])
         med, p90, mx = float(np.median(e)), float(e[int(0.9 * (len(e) - 1))]), float(e[-1])
         lines.append("== %s %s, 1 clip 32x224x224: activations/outputs (relative L2 vs fp64 oracle)" % (preset, dtype))
         lines += ["  %-28s %.3e" % x for x in acts]
         lines.append("   parameter gradients: median %.3e  p90 %.3e  max %.3e (%d tensors)" % (med, p90, mx, len(gerr)))
-        lines += ["  %-44s %.3e" % x for x in sorted(gerr, key=lambda x: -x[1])]
-        print("\n".join(lines[-(len(gerr) + len(acts) + 2):][:len(acts) + 8]))
+        cond = None
+        if dtype != "bf16":
+            # The same comparison on IDENTICAL BRANCHES: the fp64 oracle re-evaluated with this engine's ReLU sign patterns
+            # and max-pool selections (a pre-activation within fp32 rounding of zero is decided either way; ONE such unit of
+            # res5 under AVA's sparse loss gradient moves every upstream gradient by ~1e-3)
+            dec = eng.discrete_decisions()
+            nflip = sum(int(((blobs[n].detach().numpy() > 0) != m).sum()) for n, m in dec["relu"].items() if n in blobs)
+            _, g2 = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn, decisions=dec)
+            assert not dec["_missing"], "decision sites the engine did not cover: %r" % sorted(dec["_missing"])
+            cond = [(n, rel(got_g[n], g2[n].numpy())) for n in names]
+            ce = np.sort([x for _, x in cond])
+            lines.append("   same parameter gradients against the oracle evaluated on THIS engine's ReLU / max-pool decisions "
+                         "(%d ReLU units of the checked blobs decided differently): median %.3e  p90 %.3e  max %.3e"
+                         % (nflip, float(np.median(ce)), float(ce[int(0.9 * (len(ce) - 1))]), float(ce[-1])))
+            cd = dict(cond)
+            lines += ["  %-44s %.3e   (same decisions: %.3e)" % (n, x, cd[n]) for n, x in sorted(gerr, key=lambda x: -x[1])]
+        else:
+            lines += ["  %-44s %.3e" % x for x in sorted(gerr, key=lambda x: -x[1])]
+        print("\n".join(lines[-(len(gerr) + len(acts) + 3):][:len(acts) + 9]))
         a = dict(acts)
         if dtype in ("fp32", "split"):
             assert max(a.values()) < 1e-3, acts
-            assert med < 1e-3 and mx < 5e-3, (med, mx)
+            # arithmetic parity (identical branches): EVERY gradient inside the north-star bar
+            assert float(ce[-1]) < 1e-3, sorted(cond, key=lambda x: -x[1])[:5]
+            # raw comparison: tie-limited (measured 3e-5 .. 2e-3 median, up to 9e-3 on conv1_w, from run to run of
+            # mathematically equivalent kernels) -- a regression gate, not the parity claim
+            assert med < 5e-3 and mx < 3e-2, (med, mx)
         else:
             assert max(v for k, v in a.items() if k not in ("prob", "loss")) < 2e-2, acts
             assert a["prob"] < 1e-3 and a["loss"] < 1e-3, acts
             # measured: charades p90 5e-2 / max 0.24, ava p90 6.8e-2 / max 0.32 (conv1_w, the end of the chain;
             # 401 408-row tensors amplify the forward-rounding budget of oracle/bf16_budget.py a little further)
-            assert p90 < 0.12 and mx < 0.45, (p90, mx)
+            assert p90 < 0.10 and mx < 0.35, (p90, mx)
         del eng
         torch.cuda.empty_cache()
     out = os.environ.get("VLFB_PARITY_DIR")

@@ -169,3 +169,29 @@ def test_softmax_with_loss_matches_closed_form_and_autograd():
     p = torch.softmax(x.detach(), 1)
     p[torch.arange(5), t.long()] -= 1
     assert torch.allclose(x.grad, 0.25 * p / 5, atol=1e-14)
+
+
+def test_oracle_evaluates_the_branches_it_is_given():
+    """oracle.model.run(decisions=...): with its OWN ReLU sign patterns the result is unchanged; with one unit of the last
+    block switched off the gradients upstream move (the mechanism the GPU parity tests use to take ties out of the
+    comparison, tests/test_model_gpu.py)"""
+    import torch
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from oracle import model as om
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 32])
+    inputs = om.synth_inputs(cfg, 1, "train", seed=3, crop=32, frames=8)
+    params = om.synth_params(cfg, seed=3)
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda n: 5)
+    names = [n for n in blobs if n.endswith("_branch2c_bn") or n == "res_conv1_bn"]
+    dec = {"relu": {n: (blobs[n].detach().numpy() > 0) for n in names}, "pool": {}, "roi_bin": None}
+    b2, g2 = om.run(cfg, params, inputs, "train", torch.float64, True, lambda n: 5, decisions=dec)
+    assert dec["_used"] == set(names) and "res2_0_branch2a_bn" in dec["_missing"] and "pool1" in dec["_missing"]
+    for n in grads:
+        assert torch.equal(grads[n], g2[n]), n
+    last = "res5_2_branch2c_bn"
+    flat = dec["relu"][last].reshape(-1)
+    on = np.flatnonzero(flat)
+    flat[on[: max(1, len(on) // 50)]] = False
+    b3, g3 = om.run(cfg, params, inputs, "train", torch.float64, True, lambda n: 5, decisions=dec)
+    assert float((g3["conv1_w"] - grads["conv1_w"]).norm()) > 1e-6 * float(grads["conv1_w"].norm())

@@ -473,6 +473,7 @@ extern "C" int vlfb_attn_scores_supported(int dtype, int64_t l1, int64_t l2, int
 extern "C" int vlfb_attn_scores_fwd(const void* theta, const void* phi, void* prob, int dtype, int64_t batch,
                                     int64_t l1, int64_t l2, int64_t ci, float scale, vlfb_stream_t stream) {
   VLFB_REQUIRE(theta && phi && prob && batch > 0, "attn_scores_fwd: bad args");
+  VLFB_REQUIRE(scale > 0.f, "attn_scores_fwd: scale must be positive (the row maximum is taken before scaling)");
   if (!supported(dtype, l1, l2, ci))
     return set_error(VLFB_ERR_UNSUPPORTED, "attn_scores_fwd: needs a 16-bit dtype, 512 <= L2 <= 1024 (L2 %% 8 == 0), Ci %% 64 == 0");
   AttnP p{(const char*)theta, (const char*)phi, nullptr, (char*)prob, (int)l1, (int)l2, (int)ci, scale};
@@ -483,6 +484,7 @@ extern "C" int vlfb_attn_scores_bwd(const void* dy, const void* g, const void* p
                                     int64_t batch, int64_t l1, int64_t l2, int64_t ci, float scale,
                                     vlfb_stream_t stream) {
   VLFB_REQUIRE(dy && g && prob && ds && batch > 0, "attn_scores_bwd: bad args");
+  VLFB_REQUIRE(scale > 0.f, "attn_scores_bwd: scale must be positive");
   if (!supported(dtype, l1, l2, ci))
     return set_error(VLFB_ERR_UNSUPPORTED, "attn_scores_bwd: needs a 16-bit dtype, 512 <= L2 <= 1024 (L2 %% 8 == 0), Ci %% 64 == 0");
   AttnP p{(const char*)dy, (const char*)g, (const char*)prob, (char*)ds, (int)l1, (int)l2, (int)ci, scale};

@@ -225,6 +225,9 @@ __global__ void softmax_ce_kernel(const float* __restrict__ logits, const int32_
     for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
     const float inv = 1.0f / z;
     const int t = labels ? labels[r] : -1;
+    // a label outside [0, cols) is an error upstream (Caffe2's SoftmaxWithLoss enforces the range): poison the loss so that
+    // the NaN guard of the training loop (utils.misc.check_nan_losses) stops on it instead of training on a silent zero
+    if (labels && (unsigned)t >= (unsigned)cols && lane == 0) ls = __builtin_nanf("");
     for (int c = lane; c < cols; c += 64) {
       const float p = expf(x[c] - m) * inv;
       if (prob) prob[(long long)r * cols + c] = p;

@@ -214,6 +214,41 @@ extern "C" int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* 
   return check_launch("roi_align_max_fwd");
 }
 
+// Integer decisions of EVERY bilinear sample (test hook, never on the hot path): the same roi_geom / bilinear device
+// functions and the same coordinate expressions as the loops above, one thread per (RoI, bin).
+namespace vlfb { namespace {
+__global__ void roi_decisions_kernel(const float* __restrict__ rois, int32_t* __restrict__ dbg, int R, int H, int W,
+                                     int pooled, float spatial_scale, int max_grid) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= R * pooled * pooled) return;
+  const int r = id / (pooled * pooled), ph = (id / pooled) % pooled, pw = id % pooled;
+  const RoiGeom g = roi_geom(rois + (long long)r * 5, spatial_scale, pooled);
+  int32_t* d0 = dbg + (long long)id * max_grid * max_grid * 8;
+  for (int iy = 0; iy < max_grid; ++iy)
+    for (int ix = 0; ix < max_grid; ++ix) {
+      int32_t* d = d0 + (iy * max_grid + ix) * 8;
+      if (iy >= g.grid_h || ix >= g.grid_w) {
+        d[0] = g.batch; d[1] = g.grid_h; d[2] = g.grid_w; d[3] = d[4] = d[5] = d[6] = -2; d[7] = -1;   // no such sample
+        continue;
+      }
+      const float y = g.start_h + (float)ph * g.bin_h + (((float)iy + 0.5f) * g.bin_h) / (float)g.grid_h;
+      const float x = g.start_w + (float)pw * g.bin_w + (((float)ix + 0.5f) * g.bin_w) / (float)g.grid_w;
+      const Bilin b = bilinear(y, x, H, W);
+      d[0] = g.batch; d[1] = g.grid_h; d[2] = g.grid_w;
+      d[3] = b.y_low; d[4] = b.x_low; d[5] = b.y_high; d[6] = b.x_high; d[7] = b.inside ? 1 : 0;
+    }
+}
+} }
+
+extern "C" int vlfb_roi_align_decisions(const float* rois, int32_t* dbg, int64_t h, int64_t w, int64_t r, int pooled,
+                                        float spatial_scale, int max_grid, vlfb_stream_t stream) {
+  VLFB_REQUIRE(rois && dbg && r > 0 && pooled > 0 && max_grid > 0, "roi_align_decisions: bad args");
+  const int n = (int)r * pooled * pooled;
+  hipLaunchKernelGGL(vlfb::roi_decisions_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, rois, dbg, (int)r,
+                     (int)h, (int)w, pooled, spatial_scale, max_grid);
+  return vlfb::check_launch("roi_align_decisions");
+}
+
 extern "C" int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois,
                                       const uint8_t* argbin, float* dfeat, int64_t n, int64_t h,
                                       int64_t w, int64_t c, int64_t r, int pooled, float spatial_scale,

@@ -146,13 +146,25 @@ def convert_model(model_path):
     <checkpoint dir>/converted_model.pkl as a bare dict (checkpoints.py:152-183)"""
     from vlfb import dist
     out_path = os.path.join(create_and_get_checkpoint_directory(), "converted_model.pkl")
+    error = None
     if dist.rank() == 0:          # one process per GPU: rank 0 converts, the others wait for the file
-        blobs = load_and_convert_caffe2_cls_model(model_path)["blobs"]
-        for k in [k for k in blobs if "pred" in k or "momentum" in k]:
-            del blobs[k]
-        blobs["lr"] = 0.00125
-        write_blobs(out_path, blobs, wrap=False)
-    dist.barrier()
+        try:
+            blobs = load_and_convert_caffe2_cls_model(model_path)["blobs"]
+            for k in [k for k in blobs if "pred" in k or "momentum" in k]:
+                del blobs[k]
+            blobs["lr"] = 0.00125
+            write_blobs(out_path, blobs, wrap=False)
+        except Exception as e:    # (a missing / corrupt file must not leave the other ranks in the barrier forever)
+            error = e
+    # every rank learns whether the conversion worked BEFORE anyone returns: a failure raises everywhere
+    ok = dist.all_ok(error is None)
+    if error is not None:
+        raise error
+    if not ok:
+        raise RuntimeError("convert_model: rank 0 failed to convert %r" % (model_path,))
+    if not os.path.exists(out_path):
+        raise RuntimeError("convert_model: %s was written by rank 0 but is not visible on rank %d (the checkpoint "
+                           "directory must be shared by all ranks)" % (out_path, dist.rank()))
     return out_path
 
 

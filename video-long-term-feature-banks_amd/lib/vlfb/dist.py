@@ -54,3 +54,13 @@ def init_from_env(backend=None):
 def barrier():
     if initialized():
         td.barrier()
+
+
+def all_ok(flag):
+    """logical AND of `flag` over all ranks (a barrier that also carries a success bit); plain `flag` without a group"""
+    if not initialized():
+        return bool(flag)
+    dev = "cuda:%d" % local_rank() if td.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+    td.all_reduce(t, op=td.ReduceOp.MIN)
+    return bool(int(t.item()))

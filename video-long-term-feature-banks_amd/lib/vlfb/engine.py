@@ -1679,6 +1679,8 @@ class Engine(object):
         t = src.detach().float().cpu()
         if grad and self.loss_scale != 1.0:
             t = t / self.loss_scale
+        if grad and b.root.grad_scale != 1.0:     # fp16: theta / phi gradients are stored times a power of two
+            t = t / b.root.grad_scale
         if getattr(b.root, "pad_c", None) and not grad:
             wpad = getattr(b.root, "pad_w", 0)
             W = b.shape[-1]
@@ -1687,6 +1689,27 @@ class Engine(object):
         stor = t[:b.numel].view([b.shape[ax] for ax in order])
         inv = [order.index(ax) for ax in range(len(b.shape))]
         return stor.permute(inv).contiguous().numpy()
+
+    def discrete_decisions(self):
+        """The discrete decisions of the last forward pass in the reference layout: the sign pattern of every ReLU output
+        ({blob: bool array}), the selected window element of every max pool ({blob: tap index in t, h, w scan order}) and
+        the arg-max bin of the RoI head ((R, C)).  Test support: the oracle can evaluate the same branches of the
+        piecewise-linear network (oracle.model.run(decisions=...)), which separates arithmetic parity from ties at zero."""
+        dec = {"relu": {}, "pool": {}, "roi_bin": None}
+        for b in self.all_blobs:
+            if b.root is b and b.relu and b.kind == "act" and b.tensor is not None and not getattr(b, "dead", False):
+                dec["relu"][b.name] = self.fetch(b.name) > 0
+        for st in self.steps:
+            if isinstance(st, PoolStep) and st.is_max and st.argmax is not None:
+                N, Cc = st.out.shape[0], st.out.shape[1]
+                sp = tuple(st.out.shape[2:])
+                raw = st.argmax.cpu().numpy()
+                nb = raw.size // st.out.numel
+                idx = raw.view(np.uint16) if nb == 2 else raw
+                dec["pool"][st.out.name] = idx.reshape((N,) + sp + (Cc,)).transpose(0, 4, 1, 2, 3).astype(np.int64)
+            elif isinstance(st, RoiAlignMaxStep):
+                dec["roi_bin"] = st.argbin.cpu().numpy().reshape(st.R, st.Cc).astype(np.int64)
+        return dec
 
     # ---- execution ----------------------------------------------------------------------------
     def forward(self):
@@ -1796,16 +1819,21 @@ class Engine(object):
         operand copies).  Safe because nothing later in backward reads a parameter of a finished bucket: the
         dgrad of a layer is enqueued (main stream) before the event this hand-off waits for."""
         eager = self._eager_lr is not None
-        if self.side is None:                       # single-stream development mode
+        if self.side is None or self.BUCKET_HANDOFF == "join":
+            # single-stream development mode, or the simple hand-off (Engine.BUCKET_HANDOFF = "join"): the main stream
+            # joins the parameter-gradient stream and issues the collective itself -- no third stream, no cross-stream
+            # events to get wrong; costs the overlap of the wgrad stream at every bucket boundary
+            self.join_side_stream()
             works = self.comm.after_step(i) if self.comm is not None else []
             if eager:
                 for w in works:
                     w.wait()
                 self._solve_ready_buckets(i)
             return
+        # position of the dgrad chain (main stream) and of the parameter-gradient stream; the third stream waits for
+        # both -- neither of the two compute streams waits for anything here
         ev = torch.cuda.Event()
         ev.record()
-        self.side.wait_event(ev)
         ev2 = torch.cuda.Event()
         ev2.record(self.side)
         sol = self.solver_stream
@@ -1936,6 +1964,11 @@ class Engine(object):
     # solver of a bucket to follow its all-reduce directly.  "tail" = solve the finished buckets together beside the
     # last wgrad of backward (the MFMA-bound stem wgrad leaves HBM idle): 440.5 vs 440.4 clips/s, no gain either.
     EAGER_SOLVER = False
+
+    # "streams": finished gradient buckets are handed to a third stream (all-reduce + optional per-bucket solver) by
+    # two events, the compute streams never wait; "join": the main stream joins the parameter-gradient stream at every
+    # bucket boundary and issues the collective itself (the conservative fallback; tests/test_dp_gpu.py runs both)
+    BUCKET_HANDOFF = "streams"
 
     # True: from its second call on, train_step() replays the whole step (forward, backward on both streams,
     # solver, operand refresh) as ONE captured HIP graph; "forward": only the forward pass.  Nothing in the step
