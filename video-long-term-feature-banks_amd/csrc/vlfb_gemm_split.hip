@@ -368,46 +368,6 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
 // =============================================================================================
 // TN: O[pp][qq] = sum_m P[m][pp] * Xg[m][qq], fp32 operands split (2 terms) on their way into LDS
 // =============================================================================================
-struct QRowS {
-  int n, t, h, w;
-  long long base;
-  bool hv;
-};
-__device__ __forceinline__ void qs_refresh(const GP& p, QRowS& r, const TapC& tp) {
-  const int ts = r.t * p.st - p.pt + tp.a * p.dt;
-  const int hs = r.h * p.sh - p.ph + tp.b * p.dh;
-  r.hv = (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
-  r.base = ((long long)(r.n * p.Ts + ts) * p.Hs + hs) * p.Ws;
-}
-__device__ __forceinline__ void qs_next(const GP& p, QRowS& r, const TapC& tp) {
-  if (++r.w == p.Wr) {
-    r.w = 0;
-    if (++r.h == p.Hr) {
-      r.h = 0;
-      if (++r.t == p.Tr) { r.t = 0; ++r.n; }
-    }
-    qs_refresh(p, r, tp);
-  }
-}
-__device__ __forceinline__ void qs_jump(const GP& p, QRowS& r, const RowC& d, const TapC& tp) {
-  r.w += d.w; if (r.w >= p.Wr) { r.w -= p.Wr; ++r.h; }
-  r.h += d.h; if (r.h >= p.Hr) { r.h -= p.Hr; ++r.t; }
-  r.t += d.t; if (r.t >= p.Tr) { r.t -= p.Tr; ++r.n; }
-  r.n += d.n;
-  qs_refresh(p, r, tp);
-}
-template <bool PACKW>
-__device__ __forceinline__ uint4 qs_load(const GP& p, const char* base, const QRowS& r, const TapC& tp, bool ok) {
-  ok = ok && tp.ok && r.hv;
-  if (PACKW) {
-    const int w0 = r.w * p.sw - p.pw + tp.c;
-    return ld16_if(base, (r.base + w0) * 16, ok);
-  } else {
-    const int ws = r.w * p.sw - p.pw + tp.c * p.dw;
-    return ld16_if(base, ((r.base + ws) * p.lda + tp.ci) * 4, ok && (unsigned)ws < (unsigned)p.Ws);
-  }
-}
-
 template <int BP, int BQ, bool IDENT, bool PACKW>
 __global__ __launch_bounds__(256) void gemm_tn_sp_kernel(const GP p) {
   typedef float T;
@@ -444,63 +404,99 @@ __global__ __launch_bounds__(256) void gemm_tn_sp_kernel(const GP p) {
   const int kend = min(p.M, kbeg + p.kper);
   const int ktiles = (kend - kbeg + BK - 1) / BK;
 
+  // Staging blocks: 4 positions x 4 channels (one 16-byte load per position).  Block id -> (operand, channel group
+  // blk_r, position group blk_k); the operand of a block is uniform per WAVE (NPB, NQB are multiples of 128).
+  // All loads are buffer loads with 32-bit offsets: the per-lane part is loop invariant for the gradient operand and
+  // for plain rows (the k-tile advance is the scalar offset, rows past the end of this split's slab are zero-filled by
+  // the descriptor's range check), so a k-tile costs no address arithmetic and no select on the data -- with 64-bit
+  // global loads hipcc recycled the address temporaries of one block into the destination registers of the other and
+  // waited for the loads in between (s_waitcnt vmcnt(3..1) at the top of every k-tile: 44 % of the wave time parked).
   int blk_kind[ITER], blk_r[ITER], blk_k[ITER];
   TapC qtap[ITER];
+  unsigned bvo[ITER][EPC];                          // loop-invariant byte offsets of the block's 4 positions (P / plain Q)
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     int id = tid + it * 256;
     if (id < NPB) { blk_kind[it] = 0; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
     else if (id < NPB + NQB) { id -= NPB; blk_kind[it] = 1; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
     else { blk_kind[it] = 2; blk_r[it] = 0; blk_k[it] = 0; }
-    if (blk_kind[it] == 1) {
+    unsigned b0 = kOOB, ldb4 = 0;
+    if (blk_kind[it] == 0) {
+      const int pc = p0 + blk_r[it] * EPC;
+      if (pc < p.Ncols) { b0 = (unsigned)((kbeg + blk_k[it] * EPC) * p.ldp + pc) * 4u; ldb4 = (unsigned)p.ldp * 4u; }
+    } else if (blk_kind[it] == 1) {
       const int kc = (q0 + blk_r[it] * EPC) / EPC;
-      if (IDENT) { qtap[it].ok = kc * EPC < p.K; qtap[it].a = qtap[it].b = qtap[it].c = 0; qtap[it].ci = 0; }
-      else qtap[it] = decode_tap<T, PACKW>(p, kc);
-    }
-  }
-  QRowS qrow[ITER];
-  RowC jump;
-  if (!IDENT) {
-    jump = decode_row(p, BK - EPC);
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      if (blk_kind[it] == 1) {
-        const RowC r0 = decode_row(p, min(kbeg + blk_k[it] * EPC, p.M - 1));
-        qrow[it].n = r0.n; qrow[it].t = r0.t; qrow[it].h = r0.h; qrow[it].w = r0.w;
-        qs_refresh(p, qrow[it], qtap[it]);
+      if (IDENT) {
+        qtap[it].ok = kc * EPC < p.K; qtap[it].a = qtap[it].b = qtap[it].c = 0; qtap[it].ci = 0;
+        if (qtap[it].ok) { b0 = (unsigned)((kbeg + blk_k[it] * EPC) * p.lda + q0 + blk_r[it] * EPC) * 4u; ldb4 = (unsigned)p.lda * 4u; }
+      } else {
+        qtap[it] = decode_tap<T, PACKW>(p, kc);
       }
     }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) bvo[it][j] = b0 == kOOB ? kOOB : b0 + (unsigned)j * ldb4;
   }
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(Pb, (unsigned)kend * (unsigned)p.ldp * 4u);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(Ab, IDENT ? (unsigned)kend * (unsigned)p.lda * 4u : p.a_bytes);
+  // gather cursor of a Q block (generic path): output position of the block's first row in the next k-tile
+  RowC qpos[ITER];
+  RowC jump;
+  if (!IDENT) {
+    jump = decode_row(p, BK - EPC);                 // after a tile the cursor already moved EPC positions
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+      if (blk_kind[it] == 1) qpos[it] = decode_row(p, min(kbeg + blk_k[it] * EPC, p.M - 1));
+  }
+  // branch-free cursor arithmetic (selects only: the k-loop must not grow per-lane control flow around the loads)
+  auto pos_next = [&](RowC& r) {
+    ++r.w;
+    const int c0 = r.w == p.Wr; r.w = c0 ? 0 : r.w; r.h += c0;
+    const int c1 = r.h == p.Hr; r.h = c1 ? 0 : r.h; r.t += c1;
+    const int c2 = r.t == p.Tr; r.t = c2 ? 0 : r.t; r.n += c2;
+  };
+  auto pos_jump = [&](RowC& r, const RowC& d) {
+    r.w += d.w; const int c0 = r.w >= p.Wr; r.w -= c0 ? p.Wr : 0; r.h += c0;
+    r.h += d.h; const int c1 = r.h >= p.Hr; r.h -= c1 ? p.Hr : 0; r.t += c1;
+    r.t += d.t; const int c2 = r.t >= p.Tr; r.t -= c2 ? p.Tr : 0; r.n += c2;
+    r.n += d.n;
+  };
+  auto gather_off = [&](const RowC& r, const TapC& tp, bool live) -> unsigned {
+    const int ts = r.t * p.st - p.pt + tp.a * p.dt;
+    const int hs = r.h * p.sh - p.ph + tp.b * p.dh;
+    bool ok = live && tp.ok && (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+    const int rowpix = ((r.n * p.Ts + ts) * p.Hs + hs) * p.Ws;
+    if (PACKW) {
+      const int w0 = r.w * p.sw - p.pw + tp.c;       // W-padded stem input: always inside the row
+      return ok ? (unsigned)(rowpix + w0) * 16u : kOOB;
+    }
+    const int ws = r.w * p.sw - p.pw + tp.c * p.dw;
+    ok = ok && (unsigned)ws < (unsigned)p.Ws;
+    return ok ? (unsigned)((rowpix + ws) * p.lda + tp.ci) * 4u : kOOB;
+  };
 
   uint4 stg[ITER][EPC];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-      const int kk = kbeg + kt * BK + blk_k[it] * EPC;
-      if (blk_kind[it] == 0) {
-        const int pc = p0 + blk_r[it] * EPC;
-        const bool cok = pc < p.Ncols;
+      const int kind = __builtin_amdgcn_readfirstlane(blk_kind[it]);      // wave uniform
+      if (kind == 2) continue;
+      if (kind == 0 || IDENT) {
+        const unsigned ld = kind == 0 ? (unsigned)p.ldp : (unsigned)p.lda;
+        const unsigned soff = (unsigned)(kt * BK) * ld * 4u;
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
-          const int k = kk + j;
-          stg[it][j] = ld16_if(Pb, ((long long)k * p.ldp + pc) * 4, cok && k < kend);
+          if (kind == 0) stg[it][j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)bvo[it][j], (int)soff, 0));
+          else stg[it][j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)bvo[it][j], (int)soff, 0));
         }
-      } else if (blk_kind[it] == 1) {
-        if (IDENT) {
-          const int qc = q0 + blk_r[it] * EPC;
+      } else {
+        const int kk = kbeg + kt * BK + blk_k[it] * EPC;
 #pragma unroll
-          for (int j = 0; j < EPC; ++j) {
-            const int k = kk + j;
-            stg[it][j] = ld16_if(Ab, ((long long)k * p.lda + qc) * 4, qtap[it].ok && k < kend);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < EPC; ++j) {
-            stg[it][j] = qs_load<PACKW>(p, Ab, qrow[it], qtap[it], kk + j < kend);
-            qs_next(p, qrow[it], qtap[it]);
-          }
-          qs_jump(p, qrow[it], jump, qtap[it]);
+        for (int j = 0; j < EPC; ++j) {
+          const unsigned vo = gather_off(qpos[it], qtap[it], kk + j < kend);
+          stg[it][j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)vo, 0, 0));
+          pos_next(qpos[it]);
         }
+        pos_jump(qpos[it], jump);
       }
     }
   };
