@@ -368,19 +368,23 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
 // =============================================================================================
 // TN: O[pp][qq] = sum_m P[m][pp] * Xg[m][qq], fp32 operands split (2 terms) on their way into LDS
 // =============================================================================================
-template <int BP, int BQ, bool IDENT, bool PACKW>
-__global__ __launch_bounds__(256) void gemm_tn_sp_kernel(const GP p) {
+template <int BP, int BQ, bool IDENT, bool PACKW, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_sp_kernel(const GP p) {
+  // NW = 4: waves 2 (p) x 2 (q).  NW = 8: 2 x 4 on the same tile -- twice the wavefronts per CU on the same LDS (the
+  // staging phase of one wave overlaps the MFMAs of the others; SQ_WAIT_ANY was 44 % of the wave time with 4 waves)
   typedef float T;
+  constexpr int NTHR = 64 * NW, NWQ = NW / 2;
   constexpr int EPC = 4, BK = 32;
   constexpr int NPB = BP / EPC * 8, NQB = BQ / EPC * 8;    // 4 x 4 staging blocks per tile
-  constexpr int ITER = (NPB + NQB + 255) / 256;
-  constexpr int WP = BP / 2, WQ = BQ / 2;
+  constexpr int ITER = (NPB + NQB + NTHR - 1) / NTHR;
+  constexpr int WP = BP / 2, WQ = BQ / NWQ;
+  static_assert(WQ >= 16, "tile too narrow for this many waves");
   constexpr int FP = WP / 16, FQ = WQ / 16;
   constexpr int BUF = (BP + BQ) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wp = wave >> 1, wq = wave & 1;
+  const int wp = wave / NWQ, wq = wave % NWQ;
   const int l15 = lane & 15, g = lane >> 4;
 
   const int nwg = p.tiles_m * p.tiles_n;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256) void gemm_tn_sp_kernel(const GP p) {
   unsigned bvo[ITER][EPC];                          // loop-invariant byte offsets of the block's 4 positions (P / plain Q)
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    int id = tid + it * 256;
+    int id = tid + it * NTHR;
     if (id < NPB) { blk_kind[it] = 0; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
     else if (id < NPB + NQB) { id -= NPB; blk_kind[it] = 1; blk_r[it] = id >> 3; blk_k[it] = id & 7; }
     else { blk_kind[it] = 2; blk_r[it] = 0; blk_k[it] = 0; }
@@ -597,13 +601,13 @@ __global__ __launch_bounds__(256) void gemm_tn_sp_kernel(const GP p) {
 }
 
 template <typename K>
-int launch_sp(K kernel, dim3 grid, size_t lds, const GP& gp, hipStream_t s) {
+int launch_sp(K kernel, dim3 grid, size_t lds, const GP& gp, hipStream_t s, int threads = 256) {
   static bool configured = false;     // per template instance
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     configured = true;
   }
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, gp);
+  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, gp);
   return check_launch("split-bf16 conv kernel");
 }
 
@@ -669,9 +673,10 @@ int launch_nt_split(const GP& gp, int npl, int bn, int kind, bool ut, dim3 grid,
 int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 grid, size_t lds, hipStream_t s) {
 #define VLFB_TN_SP(BP, BQ)                                                                                     \
   do {                                                                                                         \
-    if (ident) return launch_sp(gemm_tn_sp_kernel<BP, BQ, true, false>, grid, lds, gp, s);                     \
-    if (packw) return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, true>, grid, lds, gp, s);                     \
-    return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, false>, grid, lds, gp, s);                               \
+    constexpr int NW = ((BP) >= 128 && (BQ) >= 128) ? 8 : 4;   /* (64-row tiles measured slower with 8 waves) */                                                                  \
+    if (ident) return launch_sp(gemm_tn_sp_kernel<BP, BQ, true, false, NW>, grid, lds, gp, s, 64 * NW);        \
+    if (packw) return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, true, NW>, grid, lds, gp, s, 64 * NW);        \
+    return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, false, NW>, grid, lds, gp, s, 64 * NW);                  \
   } while (0)
   if (bp == 128 && bq == 128) VLFB_TN_SP(128, 128);
   if (bp == 64 && bq == 128) VLFB_TN_SP(64, 128);
