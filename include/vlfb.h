@@ -138,6 +138,14 @@ typedef struct vlfb_conv_desc {
                          families give bit-identical results. */
   int32_t math;       /* VLFB_MATH_* (dtype VLFB_F32 only) */
   int64_t b_pstride;  /* math != 0, FPROP / DGRAD: elements between the bf16 term planes of B (0 = batch * Cn * ldb) */
+  /* math != 0: activations / gradients that some earlier launch already wrote as bf16 term planes next to their fp32
+   * values (o_planes below) can be handed in pre-split -- the kernel then spends no VALU on the expansion:
+   *   a_planes  0 = A is fp32; 2 (BF16X3) = A points at [plane][position][lda] bf16 planes, a_pstride elements apart
+   *   p_planes  WGRAD only: the same for P (ldp); WGRAD takes both operands as planes or neither
+   *   o_planes  FPROP / DGRAD: additionally write the first o_planes (2) bf16 terms of every output value to the
+   *             O_planes argument of vlfb_conv_run_planes, [plane][row][ldo], o_pstride elements apart */
+  int32_t a_planes, p_planes, o_planes, reserved0;
+  int64_t a_pstride, p_pstride, o_pstride;
 } vlfb_conv_desc;
 
 /* fills the desc with zeros and safe defaults (1x1x1, stride 1, alpha 1, batch 1) */
@@ -150,6 +158,10 @@ int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d);
 int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void* B, const void* P, void* O,
                   const float* bias, const float* rowscale, const void* R, const void* Mask,
                   void* workspace, int64_t workspace_bytes, vlfb_stream_t stream);
+/* the same with the destination of the output's term planes (desc.o_planes > 0; NULL otherwise) */
+int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, const void* P, void* O,
+                         const float* bias, const float* rowscale, const void* R, const void* Mask,
+                         void* workspace, int64_t workspace_bytes, void* O_planes, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / dtype movers at the boundary.

@@ -231,3 +231,76 @@ def test_split_math_is_refused_where_it_does_not_apply():
     f = torch.zeros(64 * 64, device=dev(), dtype=torch.float32)
     with pytest.raises(hip.VlfbError):
         hip.conv_run(d, f, None, f, f)
+
+
+@pytest.mark.parametrize("case", ["pw_ident", "temporal3", "spatial3", "wide", "big_k3", "big_pw", "spatial3_s2"])
+def test_split_products_on_presplit_operands(case):
+    """Activations / gradients handed in as bf16 term planes (vlfb_conv_desc.a_planes / p_planes), the format an earlier
+    launch wrote through o_planes: DGRAD and FPROP read them by DMA with no VALU in the k-loop, WGRAD takes both operands
+    as planes (DMA + transposed LDS reads, three MFMAs per fragment pair).  Same bars as the in-kernel split, and the
+    planes an epilogue writes are bit for bit the expansion of its fp32 output."""
+    cases = dict(CONV_CASES)
+    cases["big_k3"] = (2, 128, 256, 3, 14, 14, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1))
+    cases["big_pw"] = (1, 512, 136, 2, 15, 15, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1))
+    N, Cin, Cout, T, H, W, k, s, p, d = cases[case]
+    strided = s != (1, 1, 1)
+    gen = torch.Generator().manual_seed(sum(map(ord, case)) + 1)
+    x = torch.randn(N, Cin, T, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, *k, generator=gen) * (1.0 / math.sqrt(Cin * k[0] * k[1] * k[2]))
+    To, Ho, Wo = conv_out_dims(T, H, W, k, s, p, d)
+    taps = k[0] * k[1] * k[2]
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_lin = F.conv3d(xd, wd, None, s, p, d)
+    dy = torch.randn(N, Cout, To, Ho, Wo, generator=gen)
+    gx, gw = torch.autograd.grad(y_lin, (xd, wd), dy.double())
+    A = gpu(to_nthwc(x))
+    G = gpu(to_nthwc(dy))
+    wk = gpu(w_to_kernel(w).contiguous())
+    Wf = torch.empty(3, Cout, taps, Cin, device=dev(), dtype=torch.bfloat16)
+    Wd = torch.empty(2, Cin, taps, Cout, device=dev(), dtype=torch.bfloat16)
+    hip.call("vlfb_weight_prep", hip.ptr(wk), None, hip.ptr(Wf), hip.ptr(Wd), hip.SPLIT, Cout, taps, Cin)
+    plane = Cout * taps * Cin
+    Mi, Mo = N * T * H * W, N * To * Ho * Wo
+    Ap = torch.empty(3, Mi, Cin, device=dev(), dtype=torch.bfloat16)
+    Gp = torch.empty(2, Mo, Cout, device=dev(), dtype=torch.bfloat16)
+    hip.call("vlfb_split_planes", hip.ptr(A), hip.ptr(Ap), 3, 1, Mi, Cin, 0)
+    hip.call("vlfb_split_planes", hip.ptr(G), hip.ptr(Gp), 2, 1, Mo, Cout, 0)
+    g = geom_kwargs(k, s, p, d)
+    # FPROP on a pre-split activation (three terms), writing the output's planes as well
+    O = torch.full((N, To, Ho, Wo, Cout), float("nan"), device=dev(), dtype=torch.float32)
+    Op = torch.full((2, Mo, Cout), float("nan"), device=dev(), dtype=torch.bfloat16)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout,
+                         relu=1, math=hip.MATH_BF16X6, b_pstride=plane, a_planes=3, a_pstride=Mi * Cin, o_planes=2, o_pstride=Mo * Cout, **g)
+    hip.conv_run(desc, Ap, Wf, None, O, O_planes=Op)
+    assert rel_err(to_ncthw(O), torch.relu(y_lin)) < TOL6, "fprop on planes"
+    assert torch.equal(Op.cpu(), planes_of(O.cpu().reshape(Mo, Cout), 2)), "o_planes must be the expansion of the fp32 output"
+    # the in-kernel-split kernel writes the same planes
+    Op2 = torch.empty_like(Op)
+    O2 = torch.empty_like(O)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout,
+                         relu=1, math=hip.MATH_BF16X6, b_pstride=plane, o_planes=2, o_pstride=Mo * Cout, **g)
+    hip.conv_run(desc, A, Wf, None, O2, O_planes=Op2)
+    assert torch.equal(Op2.cpu(), planes_of(O2.cpu().reshape(Mo, Cout), 2))
+    # DGRAD on the pre-split gradient (two terms); strided convs have no scalar tap cursor and keep the fp32 operand
+    if not strided:
+        DX = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=torch.float32)
+        desc = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin,
+                             math=hip.MATH_BF16X3, b_pstride=plane, a_planes=2, a_pstride=Mo * Cout, **g)
+        hip.conv_run(desc, Gp, Wd, None, DX)
+        assert rel_err(to_ncthw(DX), gx) < TOL3, "dgrad on planes"
+    else:
+        with pytest.raises(hip.VlfbError):
+            desc = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo, Cs=Cout,
+                                 Cn=Cin, math=hip.MATH_BF16X3, b_pstride=plane, a_planes=2, a_pstride=Mo * Cout, **g)
+            hip.conv_run(desc, Gp, Wd, None, torch.empty(N, T, H, W, Cin, device=dev()))
+    # WGRAD on both operands pre-split: library split, direct, forced split
+    scale = torch.rand(Cout, generator=gen) + 0.5
+    gw_ref = w_to_kernel(gw * scale.double().view(-1, 1, 1, 1, 1))
+    for splits in (0, 1, 3):
+        DW = torch.full((Cout, k[0], k[1], k[2], Cin), float("nan"), device=dev(), dtype=torch.float32)
+        desc = hip.conv_desc(mode=hip.WGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout,
+                             splits=splits, math=hip.MATH_BF16X3, a_planes=3, a_pstride=Mi * Cin, p_planes=2, p_pstride=Mo * Cout, **g)
+        ws = torch.empty(max(hip.conv_workspace_bytes(desc), 16) // 4, device=dev(), dtype=torch.float32)
+        hip.conv_run(desc, Ap, None, Gp, DW, rowscale=gpu(scale), workspace=ws)
+        assert rel_err(DW, gw_ref) < TOL3, "wgrad on planes, splits=%d" % splits

@@ -694,13 +694,17 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const GP p) {
 // The DMAs are issued through bufglds16_hidden: with the builtin, hipcc put s_waitcnt vmcnt(0) in front of the
 // transposed reads of every k-tile, i.e. it waited for the NEXT tile's DMA right after issuing it.
 // =============================================================================================
-template <typename T, typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4>
+template <typename T, typename OutT, int BP, int BQ, bool IDENT, bool PACKW, int NW = 4, bool SP = false>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   // NW = 4: waves 2 (p) x 2 (q).  NW = 8: waves 2 x 4 on the same tile -- twice the wavefronts per CU.
+  // SP (split-bf16 math on fp32 storage, vlfb_gemm_split.hip): BOTH operands arrive as two bf16 term planes [plane][position]
+  // [channel] (h = bf16(x), m = bf16(x - h); a_ps / p_ps elements apart) and a fragment pair issues three MFMAs
+  // (m.h, h.m, h.h); k-tiles of 32 positions keep the two-plane tiles at the LDS footprint of the plain kernel.
   typedef typename V16<T>::V vec_t;
   constexpr int NTHR = 64 * NW;
   constexpr int NWQ = NW / 2;
-  constexpr int BK = 64;                         // positions per k-tile
+  constexpr int NPL = SP ? 2 : 1;
+  constexpr int BK = SP ? 32 : 64;               // positions per k-tile
   constexpr int RSP = BP * 2, RSQ = BQ * 2;      // LDS row bytes (one position)
   constexpr int CP = BP / 8, CQ = BQ / 8;        // 16-byte chunks per row
   constexpr int PI = BK * CP / NTHR, QI = BK * CQ / NTHR;   // DMA pieces per thread
@@ -708,7 +712,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   constexpr int WP = BP / 2, WQ = BQ / NWQ;
   static_assert(PI >= 1 && QI >= 1 && WQ >= 16, "tile too small for this many waves");
   constexpr int FP = WP / 16, FQ = WQ / 16;
-  constexpr int BUF = BK * (RSP + RSQ);
+  constexpr int PLP = BK * RSP, PLQ = BK * RSQ;  // bytes of one plane tile
+  constexpr int BUF = NPL * (PLP + PLQ);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -762,8 +767,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   // DMA through buffer descriptors whose extent ends at position `kend`: rows past the end of this
   // split's slab (only the last k-tile can have them) are zero-filled by the range check, the k-tile
   // advance is the scalar offset, and the per-lane part is a loop-invariant 32-bit byte offset.
-  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(Pb, (unsigned)kend * (unsigned)p.ldp * 2u);
-  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(Ab, IDENT ? (unsigned)kend * (unsigned)p.lda * 2u : p.a_bytes);
+  // (one descriptor per term plane: the range check that zero-fills the ragged last k-tile is per plane)
+  __amdgpu_buffer_rsrc_t rsP[NPL], rsQ[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) {
+    rsP[pl] = make_rsrc(Pb + (long long)pl * p.p_ps * 2, (unsigned)kend * (unsigned)p.ldp * 2u);
+    rsQ[pl] = make_rsrc(Ab + (long long)pl * p.a_ps * 2, IDENT ? (unsigned)kend * (unsigned)p.lda * 2u : p.a_bytes);
+  }
   unsigned poff[PI], qoff[IDENT ? QI : 1];
 #pragma unroll
   for (int i = 0; i < PI; ++i)
@@ -776,15 +786,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
 
   auto load_tile = [&](int kt, int buf) {
     char* pt = smem + buf * BUF + wave_u * 1024;
-    char* qt = smem + buf * BUF + BK * RSP + wave_u * 1024;
+    char* qt = smem + buf * BUF + NPL * PLP + wave_u * 1024;
     const int kb = kbeg + kt * BK;
     const unsigned pstep = (unsigned)(kt * BK) * (unsigned)p.ldp * 2u;
 #pragma unroll
-    for (int i = 0; i < PI; ++i) bufglds16_hidden(rsP, poff[i], pstep, pt + i * (NTHR * 16));
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int i = 0; i < PI; ++i) bufglds16_hidden(rsP[pl], poff[i], pstep, pt + pl * PLP + i * (NTHR * 16));
     if (IDENT) {
       const unsigned qstep = (unsigned)(kt * BK) * (unsigned)p.lda * 2u;
 #pragma unroll
-      for (int i = 0; i < QI; ++i) bufglds16_hidden(rsQ, qoff[i], qstep, qt + i * (NTHR * 16));
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int i = 0; i < QI; ++i) bufglds16_hidden(rsQ[pl], qoff[i], qstep, qt + pl * PLQ + i * (NTHR * 16));
     } else {
 #pragma unroll
       for (int i = 0; i < QI; ++i) {
@@ -799,7 +813,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
           off = ok ? (unsigned)((qcur[i].base + ws) * p.lda + qtap.ci) * 2u : kOOB;
         }
         qrow_jump(p, qcur[i], jump, qtap);
-        bufglds16_hidden(rsQ, off, 0, qt + i * (NTHR * 16));
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) bufglds16_hidden(rsQ[pl], off, 0, qt + pl * PLQ + i * (NTHR * 16));
       }
     }
   };
@@ -817,19 +832,32 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (kt + 1 < ktiles) load_tile(kt + 1, (kt + 1) & 1);
     const char* pt = smem + (kt & 1) * BUF;
-    const char* qt = pt + BK * RSP;
+    const char* qt = pt + NPL * PLP;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      vec_t pf[FP], qf[FQ];
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      vec_t pf[NPL][FP], qf[NPL][FQ];
 #pragma unroll
-      for (int i = 0; i < FP; ++i) pf[i] = tr_frag<RSP, vec_t>(pt, wp * WP + i * 16, ks, lane);
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-      for (int j = 0; j < FQ; ++j) qf[j] = tr_frag<RSQ, vec_t>(qt, wq * WQ + j * 16, ks, lane);
+        for (int i = 0; i < FP; ++i) pf[pl][i] = tr_frag<RSP, vec_t>(pt + pl * PLP, wp * WP + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < FQ; ++j) qf[pl][j] = tr_frag<RSQ, vec_t>(qt + pl * PLQ, wq * WQ + j * 16, ks, lane);
+      }
+      if constexpr (SP) {      // cross terms first, then the leading product (16 accumulators between two MFMAs on one)
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+#pragma unroll
+          for (int i = 0; i < FP; ++i) acc[j][i] = V16<T>::mma(qf[NPL - 1][j], pf[0][i], acc[j][i]);
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+#pragma unroll
+          for (int i = 0; i < FP; ++i) acc[j][i] = V16<T>::mma(qf[0][j], pf[NPL - 1][i], acc[j][i]);
+      }
 #pragma unroll
       for (int j = 0; j < FQ; ++j)
 #pragma unroll
         for (int i = 0; i < FP; ++i)
-          acc[j][i] = V16<T>::mma(qf[j], pf[i], acc[j][i]);
+          acc[j][i] = V16<T>::mma(qf[0][j], pf[0][i], acc[j][i]);
     }
   }
 
@@ -1092,6 +1120,7 @@ struct Plan {
   int nts_mode;
   int sp;         // split-bf16 math (vlfb_gemm_split.hip): bf16 terms per operand (2 | 3), 0 = native MFMA of the dtype
   int sp_kind;    //   NT: 0 plain rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem
+  int sp_pl;      //   operands arrive as bf16 term planes (WGRAD: both; FPROP / DGRAD: the activation operand)
   size_t stem_lds;
   dim3 grid;
   size_t lds;
@@ -1110,7 +1139,13 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   VLFB_REQUIRE(d->math != VLFB_MATH_BF16X6 || d->mode != VLFB_CONV_WGRAD, "conv: WGRAD has no BF16X6 form (use BF16X3)");
   pl->sp = d->math == VLFB_MATH_BF16X6 ? 3 : d->math == VLFB_MATH_BF16X3 ? 2 : 0;
   pl->sp_kind = 0;
-  const int es = d->dtype == VLFB_F32 ? 4 : 2;
+  VLFB_REQUIRE(pl->sp || (!d->a_planes && !d->p_planes && !d->o_planes), "conv: term planes belong to split-bf16 math");
+  VLFB_REQUIRE(d->mode == VLFB_CONV_WGRAD ? (d->a_planes ? d->a_planes >= 2 && d->p_planes == 2 : d->p_planes == 0) && !d->o_planes
+                                         : (d->a_planes == 0 || d->a_planes >= pl->sp) && !d->p_planes && (d->o_planes == 0 || d->o_planes == 2),
+               "conv: bad a_planes / p_planes / o_planes for this mode");
+  pl->sp_pl = d->a_planes > 0;
+  // operands handed in as bf16 term planes are 2-byte elements for all address arithmetic below
+  const int es = (d->dtype == VLFB_F32 && !pl->sp_pl) ? 4 : 2;
   const int epc = 16 / es;
   const int batch = d->batch > 0 ? d->batch : 1;
   VLFB_REQUIRE(d->N > 0 && d->Tr > 0 && d->Hr > 0 && d->Wr > 0, "conv: empty row space");
@@ -1158,6 +1193,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   g.p_bs = d->p_bstride;
   g.alpha = d->alpha; g.relu = d->relu; g.bias_mode = d->bias_mode; g.accumulate = d->accumulate;
   g.s2 = 0; g.s2_mq = 0; g.s2_tpc = 0;
+  g.a_ps = d->a_pstride; g.p_ps = d->p_pstride; g.o_ps = d->o_pstride; g.op_n = d->o_planes; g.OP = nullptr;
   VLFB_REQUIRE((pl->packw || g.lda % epc == 0) && (d->mode == VLFB_CONV_WGRAD || g.ldb % epc == 0) &&
                    (d->mode != VLFB_CONV_WGRAD || g.ldp % epc == 0),
                "conv: leading dimensions must keep 16-byte alignment");
@@ -1213,8 +1249,13 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // 32 MFMAs per wave per k-tile of staging and the P panel is re-read half as often
     pl->tn_tr = is16(d->dtype) && d->Cn % 8 == 0;
     if (pl->tn8) pl->tn_tr = 1;
+    if (pl->sp_pl) {       // two-plane operands: the DMA + transposed-read kernel in its SP form
+      VLFB_REQUIRE(d->Cn % 8 == 0 && g.lda % 8 == 0 && g.ldp % 8 == 0 && d->a_pstride % 8 == 0 && d->p_pstride % 8 == 0,
+                   "conv: plane operands need channel counts / strides in multiples of 8");
+      pl->tn_tr = 1;
+    }
     if (!pl->tn_tr && pl->bm == 64 && K >= 256 && is16(d->dtype)) pl->bn = 256;
-    if (pl->tn_tr && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
+    if (pl->tn_tr && !pl->sp && pl->packw && d->Cn == 64 && d->pack_w == 8 && d->Wr % 8 == 0 && d->Wr <= 128 &&
         d->dt == 1 && d->dh == 1 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && (d->Ws * 8) % 16 == 0) {
       const int taps_ab = d->kt * d->kh;
       const long long npieces = (long long)taps_ab * (d->Ws * 8 / 16);
@@ -1236,7 +1277,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     }
     // whole-row kernel (vlfb_wgrad_rows.hip): 64 -> 64 channels, unit stride, same-size output, rows of <= 64
     // positions (res2 3x3 / 3x1x1): every operand byte is read once, taps are LDS row offsets
-    if (!pl->stem && pl->tn_tr && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && d->Cs == 64 && d->Cn == 64 &&
+    if (!pl->stem && pl->tn_tr && !pl->sp && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && d->Cs == 64 && d->Cn == 64 &&
         d->st == 1 && d->sh == 1 && d->sw == 1 && d->dt == 1 && d->dh == 1 && d->dw == 1 && d->Tr == d->Ts &&
         d->Hr == d->Hs && d->Wr == d->Ws && d->Wr % 8 == 0 && d->Ws + d->kw - 1 <= 64 && d->pw < d->kw &&
         wgrad_rows_ct(K) > 0 && d->kt * d->kh == 3 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && g.lda == 64 && g.ldp == 64) {
@@ -1255,7 +1296,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         pl->stem_lds = (size_t)2 * ((size_t)d->kt * d->kh * (d->Ws + d->kw - 1) * 128 + (size_t)d->Wr * 128) + 1024;
       }
     }
-    if (!pl->stem && !pl->rows && pl->tn_tr && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && d->Cs == 256 &&
+    if (!pl->stem && !pl->rows && pl->tn_tr && !pl->sp && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && d->Cs == 256 &&
         d->Cn == 64 && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->dt == 1 &&
         d->Tr == d->Ts && d->Hr == d->Hs && d->Wr == d->Ws && d->ph == 0 && d->pw == 0 && d->pt < 3 && d->Wr % 8 == 0 &&
         d->Wr <= 64 && d->splits <= 0 && batch == 1 && g.ldo == (int)K && g.lda == 256 && g.ldp == 64) {
@@ -1277,7 +1318,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     if (!pl->stem && !pl->rows) {
       g.tiles_m = (d->Cn + pl->bm - 1) / pl->bm;
       g.tiles_n = (int)((K + pl->bn - 1) / pl->bn);
-      const int bk = 128 / es;
+      const int bk = pl->sp_pl ? 32 : 128 / es;          // positions per k-tile of the kernel that will run
       int splits = d->splits;
       if (splits <= 0) {
         // Pick the split count that fills whole rounds of `slots` workgroups best (every extra split
@@ -1418,7 +1459,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   }
   pl->ut = 0;
   if (d->mode != VLFB_CONV_WGRAD) {
-    pl->ut = !pl->ident && !d->pack_w && ((long long)d->Cs * es) % pl->rb == 0 &&
+    pl->ut = !pl->ident && !d->pack_w && (pl->sp ? d->Cs % 32 == 0 : ((long long)d->Cs * es) % pl->rb == 0) &&
              (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1));
     const long long ktiles = (K * es + pl->rb - 1) / pl->rb;
     const size_t buf = (size_t)(pl->bm + pl->bn) * pl->rb;
@@ -1431,7 +1472,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       pl->sp_kind = pl->ident ? 0 : pl->packw ? 3 : d->mode == VLFB_CONV_FPROP ? 1 : 2;
       pl->threads = kThreads;
       pl->pre = 0;
-      const size_t sbuf = (size_t)128 * 128 + (size_t)pl->sp * pl->bn * 64;
+      VLFB_REQUIRE(!pl->sp_pl || ((pl->ident || pl->ut) && d->a_pstride % 8 == 0 && g.lda % 8 == 0),
+                   "conv: a pre-split activation operand needs plain rows or taps that span whole 32-element k-tiles");
+      VLFB_REQUIRE(!d->o_planes || (d->o_pstride % 4 == 0 && batch == 1), "conv: o_planes needs batch 1 and an aligned o_pstride");
+      const size_t sbuf = (pl->sp_pl ? (size_t)pl->sp * 128 * 64 : (size_t)128 * 128) + (size_t)pl->sp * pl->bn * 64;
       pl->lds = 2 * sbuf;
       if (pl->lds < (size_t)128 * pl->bn * 4) pl->lds = (size_t)128 * pl->bn * 4;
     }
@@ -1487,12 +1531,12 @@ void launch_tn(const Plan& pl, hipStream_t s) {
   else launch_k(gemm_tn_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
 }
 
-template <typename T, typename OutT, bool IDENT, bool PACKW>
+template <typename T, typename OutT, bool IDENT, bool PACKW, bool SP = false>
 void launch_tn_tr(const Plan& pl, hipStream_t s) {
-  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<T, OutT, 128, 128, IDENT, PACKW, 8>, pl, s);   // 8 waves
-  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<T, OutT, 64, 128, IDENT, PACKW>, pl, s);
-  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<T, OutT, 128, 64, IDENT, PACKW>, pl, s);
-  else launch_k(gemm_tn_tr_kernel<T, OutT, 64, 64, IDENT, PACKW>, pl, s);
+  if (pl.bm == 128 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<T, OutT, 128, 128, IDENT, PACKW, 8, SP>, pl, s);   // 8 waves
+  else if (pl.bm == 64 && pl.bn == 128) launch_k(gemm_tn_tr_kernel<T, OutT, 64, 128, IDENT, PACKW, 4, SP>, pl, s);
+  else if (pl.bm == 128 && pl.bn == 64) launch_k(gemm_tn_tr_kernel<T, OutT, 128, 64, IDENT, PACKW, 4, SP>, pl, s);
+  else launch_k(gemm_tn_tr_kernel<T, OutT, 64, 64, IDENT, PACKW, 4, SP>, pl, s);
 }
 
 template <typename T, typename OutT>
@@ -1581,6 +1625,13 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
                              void* O, const float* bias, const float* rowscale, const void* R,
                              const void* Mask, void* workspace, int64_t workspace_bytes,
                              vlfb_stream_t stream) {
+  return vlfb_conv_run_planes(d, A, B, P, O, bias, rowscale, R, Mask, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
+                                    void* O, const float* bias, const float* rowscale, const void* R,
+                                    const void* Mask, void* workspace, int64_t workspace_bytes, void* O_planes,
+                                    vlfb_stream_t stream) {
   Plan pl;
   int rc = cached_plan(d, &pl);
   if (rc != VLFB_OK) return rc;
@@ -1595,11 +1646,19 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   g.A = (const char*)A; g.B = (const char*)B; g.P = (const char*)P; g.O = (char*)O;
   g.bias = bias; g.rowscale = rowscale; g.R = (const char*)R; g.Mask = (const char*)Mask;
   g.ws = (float*)workspace;
+  VLFB_REQUIRE((d->o_planes > 0) == (O_planes != nullptr), "conv: O_planes goes with desc.o_planes");
+  g.OP = (char*)O_planes;
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
   if (pl.sp) {
-    rc = d->mode == VLFB_CONV_WGRAD ? launch_tn_split(g, pl.bm, pl.bn, pl.ident, pl.packw, pl.grid, pl.lds, s)
-                                    : launch_nt_split(g, pl.sp, pl.bn, pl.sp_kind, pl.ut != 0, pl.grid, pl.lds, s);
+    if (d->mode == VLFB_CONV_WGRAD && pl.sp_pl) {
+      if (pl.ident) launch_tn_tr<bf16_t, float, true, false, true>(pl, s);
+      else if (pl.packw) launch_tn_tr<bf16_t, float, false, true, true>(pl, s);
+      else launch_tn_tr<bf16_t, float, false, false, true>(pl, s);
+      rc = check_launch("conv wgrad (planes) kernel");
+    } else if (d->mode == VLFB_CONV_WGRAD) rc = launch_tn_split(g, pl.bm, pl.bn, pl.ident, pl.packw, pl.grid, pl.lds, s);
+    else if (pl.sp_pl) rc = launch_nt_planes(g, pl.sp, pl.bn, pl.sp_kind, pl.grid, pl.lds, s);
+    else rc = launch_nt_split(g, pl.sp, pl.bn, pl.sp_kind, pl.ut != 0, pl.grid, pl.lds, s);
   } else if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
   else if (d->dtype == VLFB_F16) rc = d->out_dtype == VLFB_F32 ? dispatch<f16_t, float>(d, pl, s) : dispatch<f16_t, f16_t>(d, pl, s);
   else rc = d->out_dtype == VLFB_F32 ? dispatch<bf16_t, float>(d, pl, s) : dispatch<bf16_t, bf16_t>(d, pl, s);

@@ -42,6 +42,11 @@ struct GP {
   int s2_tpc;         // row tiles per class
   // split-bf16 math (vlfb_gemm_split.hip): element stride between the bf16 term planes of the weight operand
   long long b_ps;
+  // ... of the activation / gradient operands when they arrive pre-split (vlfb_conv_desc.a_planes / p_planes), and the
+  // optional term-plane copy of an NT output (o_planes planes at OP, o_ps elements apart, written by the epilogue)
+  long long a_ps, p_ps, o_ps;
+  char* OP;
+  int op_n;
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered
@@ -75,6 +80,9 @@ int launch_conv_rows64(const GP& gp, int mode, int dtype, hipStream_t s);
 // rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem FPROP; ut = scalar tap cursor.  TN: 2 terms, tiles 128 | 64.
 int launch_nt_split(const GP& gp, int npl, int bn, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s);
 int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 grid, size_t lds, hipStream_t s);
+// NT with the activation operand pre-split into npl bf16 term planes (kind 0 plain rows, 1 / 2 gathered FPROP / DGRAD with
+// the scalar tap cursor)
+int launch_nt_planes(const GP& gp, int npl, int bn, int kind, dim3 grid, size_t lds, hipStream_t s);
 
 namespace {
 

@@ -83,6 +83,74 @@ __device__ __forceinline__ f32x4_v mma_bf16(bf16x8_v a, bf16x8_v b, f32x4_v c) {
 }
 
 // =============================================================================================
+// Epilogue of the NT kernels (4 waves as 2 x 2, 64 x BN/2 outputs each): fp32 tile through LDS, then 16-byte row
+// accesses: v = alpha * acc + bias + R; relu; mask; fp32 store -- and, when the launch asks for them (GP::op_n == 2),
+// the first two bf16 terms of v as planes [plane][row][ldo]: the operand format a later split launch reads without
+// spending VALU on the expansion (vlfb_conv_desc.o_planes).
+// =============================================================================================
+template <int BN, int FN, int FM>
+__device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN][FM], char* smem, int m0, int n0, int z, int tid,
+                                            int wm, int wn, int l15, int g) {
+  constexpr int BM = 128, NTHR = 256, WM = 64, WN = BN / 2;
+  char* Ob = p.O + (long long)z * p.o_bs * 4;
+  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 4 : nullptr;
+  const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 4 : nullptr;
+  constexpr int TPR = BN / 4, RPP = NTHR / TPR, NPASS = BM / RPP, CPR = BN / 4;
+  const int tc = tid % TPR, tr = tid / TPR;
+  const int ncol = n0 + tc * 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm * WM + i * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int c = (wn * WN + j * 16 + g * 4) >> 2;
+      *reinterpret_cast<float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4)) =
+          make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha, acc[j][i][3] * p.alpha);
+    }
+  }
+  __syncthreads();
+  const bool planes = p.op_n == 2;
+#pragma unroll 4
+  for (int gp = 0; gp < NPASS; ++gp) {
+    const int row = gp * RPP + tr;
+    const int m = m0 + row;
+    if (m < p.M && ncol < p.Ncols) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (tc ^ (row & 7))) << 4));
+      float v[4] = {t.x, t.y, t.z, t.w};
+      if (p.bias_mode == VLFB_BIAS_COL) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + ncol);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      } else if (p.bias_mode == VLFB_BIAS_ROW) {
+        const float b = p.bias[m];
+        v[0] += b; v[1] += b; v[2] += b; v[3] += b;
+      }
+      const long long ridx = (long long)m * p.ldr + ncol;
+      if (Rb) {
+        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Rb) + ridx);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (Mb) {
+        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Mb) + ridx);
+        v[0] = r.x > 0.f ? v[0] : 0.f; v[1] = r.y > 0.f ? v[1] : 0.f;
+        v[2] = r.z > 0.f ? v[2] : 0.f; v[3] = r.w > 0.f ? v[3] : 0.f;
+      }
+      const long long oidx = (long long)m * p.ldo + ncol;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ob) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
+      if (planes) {
+        bf16_t* op = reinterpret_cast<bf16_t*>(p.OP) + oidx;
+        const uint32_t h01 = peel(v[0], v[1]), h23 = peel(v[2], v[3]);
+        *reinterpret_cast<uint2*>(op) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(op + p.o_ps) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // NT: O[m][n] = sum_k X[m][k] * W[n][k];  X fp32 (gathered), W = NPL bf16 planes, O / R / Mask fp32
 // =============================================================================================
 template <int NPL, int BN, bool IDENT, bool DGRAD, bool PACKW, bool UT>
@@ -313,56 +381,157 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
   }
   __syncthreads();
 
-  // ---- epilogue: fp32 tile through LDS, 16-byte row accesses (the vec_epi path of gemm_nt_kernel) ----
-  char* Ob = p.O + (long long)z * p.o_bs * 4;
-  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 4 : nullptr;
-  const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 4 : nullptr;
-  constexpr int TPR = BN / 4, RPP = NTHR / TPR, NPASS = BM / RPP, CPR = BN / 4;
-  const int tc = tid % TPR, tr = tid / TPR;
-  const int ncol = n0 + tc * 4;
+  nt_epilogue<BN, FN, FM>(p, acc, smem, m0, n0, z, tid, wm, wn, l15, g);
+}
+
+// =============================================================================================
+// NT with the ACTIVATION operand pre-split as well: both operands are NPL bf16 term planes that the DMA drops into LDS
+// as they lie -- the k-loop is fragment reads and MFMAs, no VALU (the in-kernel split above costs 2.5 VALU per MFMA in
+// the three-MFMA form and every activation fragment is split by both wave columns).  Plain rows or the scalar tap cursor.
+// =============================================================================================
+template <int NPL, int BN, bool IDENT, bool DGRAD>
+__global__ __launch_bounds__(256) void gemm_nt_pl_kernel(const GP p) {
+  constexpr int BM = 128, NTHR = 256, NWN = 2;
+  constexpr int RPPS = NTHR / 4;                   // 64 tile rows per DMA pass (64-byte rows, 4 chunks)
+  constexpr int A_ITP = BM / RPPS, B_ITP = BN / RPPS;
+  constexpr int WM = BM / 2, WN = BN / NWN;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int PLA = BM * 64, PLB = BN * 64;
+  constexpr int BUF = NPL * (PLA + PLB);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const char* Ab = p.A + (long long)z * p.a_bs * 2;
+  const char* Bb = p.B + (long long)z * p.b_bs * 2;
+
+  const int cb = tid & 3, rb0 = tid >> 2;
+  const int cbg = cb ^ key64(rb0);                 // (rows rb0 + 64 i share the key)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  RowC arow[A_ITP];
+  bool aok[A_ITP];
+  unsigned aoff[A_ITP], boff[B_ITP];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = wm * WM + i * 16 + l15;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int c = (wn * WN + j * 16 + g * 4) >> 2;
-      *reinterpret_cast<float4*>(smem + ((row * CPR + (c ^ (row & 7))) << 4)) =
-          make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha, acc[j][i][3] * p.alpha);
+  for (int i = 0; i < A_ITP; ++i) {
+    const int m = m0 + rb0 + RPPS * i;
+    aok[i] = m < p.M;
+    if (IDENT) {
+      aoff[i] = aok[i] ? (unsigned)(m * p.lda + cbg * 8) * 2u : kOOB;
+    } else {
+      RowC& r = arow[i];
+      r = decode_row(p, aok[i] ? m : 0);
+      if (!DGRAD) { r.t = r.t * p.st - p.pt; r.h = r.h * p.sh - p.ph; r.w = r.w * p.sw - p.pw; }
+      else { r.t += p.pt; r.h += p.ph; r.w += p.pw; }
+      aoff[i] = (unsigned)((((r.n * p.Ts + r.t) * p.Hs + r.h) * p.Ws + r.w) * p.lda + cbg * 8) * 2u;   // wraps for padding rows
     }
+  }
+#pragma unroll
+  for (int i = 0; i < B_ITP; ++i) {
+    const int n = n0 + rb0 + RPPS * i;
+    boff[i] = n < p.Ncols ? (unsigned)(n * p.ldb + cbg * 8) * 2u : kOOB;
+  }
+  const unsigned a_plane = (unsigned)p.a_ps * 2u, b_plane = (unsigned)p.b_ps * 2u;
+  int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
+  const int ktiles = (p.K + 31) >> 5;
+
+  constexpr int ND = NPL * (A_ITP + B_ITP);
+  unsigned avo[A_ITP], aso;                        // the activation pieces of the tile being fetched
+  bool kokb;
+  auto prep_tile = [&](int kt) {
+    kokb = (kt * 4 + cbg) * 8 < p.K;
+    if (IDENT) {
+#pragma unroll
+      for (int i = 0; i < A_ITP; ++i) avo[i] = kokb ? aoff[i] : kOOB;
+      aso = (unsigned)kt * 64u;
+    } else {
+      const int sgn = DGRAD ? -1 : 1;
+      const int da = sgn * u_a * p.dt, db = sgn * u_b * p.dh, dc = sgn * u_c * p.dw;
+      const unsigned dbyte = (unsigned)(((da * p.Hs + db) * p.Ws + dc) * p.lda + u_ci) * 2u;
+#pragma unroll
+      for (int i = 0; i < A_ITP; ++i) {
+        const bool ok = aok[i] && (unsigned)(arow[i].t + da) < (unsigned)p.Ts &&
+                        (unsigned)(arow[i].h + db) < (unsigned)p.Hs && (unsigned)(arow[i].w + dc) < (unsigned)p.Ws;
+        avo[i] = ok ? aoff[i] + dbyte : kOOB;
+      }
+      aso = 0;
+      u_ci += 32;
+      const int w0 = u_ci >= p.Cs;
+      u_ci = w0 ? 0 : u_ci; u_c += w0;
+      const int w1 = u_c == p.kw;
+      u_c = w1 ? 0 : u_c; u_b += w1;
+      const int w2 = u_b == p.kh;
+      u_b = w2 ? 0 : u_b; u_a += w2;
+    }
+  };
+  // piece d: activation planes first (pl, i), then weight planes; past the last tile through zero-record descriptors
+  auto issue_piece = [&](int d, int buf, int kt, bool live) {
+    char* base = smem + buf * BUF + wave_u * 1024;
+    if (d < NPL * A_ITP) {
+      const int pl = d / A_ITP, i = d % A_ITP;
+      bufglds16(make_rsrc(Ab, live ? (unsigned)(NPL - 1) * a_plane + p.a_bytes : 0u), avo[i], aso + (unsigned)pl * a_plane,
+                base + pl * PLA + i * (RPPS * 64));
+    } else {
+      const int e = d - NPL * A_ITP, pl = e / B_ITP, i = e % B_ITP;
+      bufglds16(make_rsrc(Bb, live ? p.b_bytes : 0u), kokb ? boff[i] : kOOB, (unsigned)kt * 64u + (unsigned)pl * b_plane,
+                base + NPL * PLA + pl * PLB + i * (RPPS * 64));
+    }
+  };
+
+  f32x4_v acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+  if (ktiles > 0) {
+    prep_tile(0);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) issue_piece(d, 0, 0, true);
+  }
+  constexpr int NTERM = NPL == 3 ? 6 : 3;
+  constexpr int TA[6] = {0, 1, NPL == 3 ? 2 : 0, 0, 1, 0};
+  constexpr int TB[6] = {0, 0, NPL == 3 ? 0 : 1, 1, 1, 2};
+  constexpr int PER = FN * FM, NMF = NTERM * PER;
+  int aro[FM], bro[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) { const int row = wm * WM + i * 16 + l15; aro[i] = row * 64 + ((g ^ key64(row)) << 4); }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) { const int row = wn * WN + j * 16 + l15; bro[j] = row * 64 + ((g ^ key64(row)) << 4); }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    prep_tile(kt + 1);
+    const int nbuf = (kt + 1) & 1;
+    const bool live = kt + 1 < ktiles;
+    const char* xa = smem + (kt & 1) * BUF;
+    const char* wb = xa + NPL * PLA;
+    bf16x8_v wf[NPL][FN], xf[NPL][FM];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[pl][j] = *reinterpret_cast<const bf16x8_v*>(wb + pl * PLB + bro[j]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) xf[pl][i] = *reinterpret_cast<const bf16x8_v*>(xa + pl * PLA + aro[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NMF>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int ts = n / PER, j = (n % PER) / FM, i = n % FM;
+      acc[j][i] = mma_bf16(wf[TA[ts]][j], xf[TB[ts]][i], acc[j][i]);
+      static_for<ND>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (((d + 1) * NMF) / (ND + 1) == n + 1) issue_piece(d, nbuf, kt + 1, live);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
   __syncthreads();
-#pragma unroll 4
-  for (int gp = 0; gp < NPASS; ++gp) {
-    const int row = gp * RPP + tr;
-    const int m = m0 + row;
-    if (m < p.M && ncol < p.Ncols) {
-      const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (tc ^ (row & 7))) << 4));
-      float v[4] = {t.x, t.y, t.z, t.w};
-      if (p.bias_mode == VLFB_BIAS_COL) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + ncol);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      } else if (p.bias_mode == VLFB_BIAS_ROW) {
-        const float b = p.bias[m];
-        v[0] += b; v[1] += b; v[2] += b; v[3] += b;
-      }
-      const long long ridx = (long long)m * p.ldr + ncol;
-      if (Rb) {
-        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Rb) + ridx);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (Mb) {
-        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Mb) + ridx);
-        v[0] = r.x > 0.f ? v[0] : 0.f; v[1] = r.y > 0.f ? v[1] : 0.f;
-        v[2] = r.z > 0.f ? v[2] : 0.f; v[3] = r.w > 0.f ? v[3] : 0.f;
-      }
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ob) + (long long)m * p.ldo + ncol) =
-          make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
+  nt_epilogue<BN, FN, FM>(p, acc, smem, m0, n0, z, tid, wm, wn, l15, g);
 }
 
 // =============================================================================================
@@ -604,7 +773,7 @@ template <typename K>
 int launch_sp(K kernel, dim3 grid, size_t lds, const GP& gp, hipStream_t s, int threads = 256) {
   static bool configured = false;     // per template instance
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     configured = true;
   }
   hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, gp);
@@ -670,13 +839,27 @@ int launch_nt_split(const GP& gp, int npl, int bn, int kind, bool ut, dim3 grid,
   return bn == 128 ? launch_nt_sp_shape<2, 128>(gp, kind, ut, grid, lds, s) : launch_nt_sp_shape<2, 64>(gp, kind, ut, grid, lds, s);
 }
 
+template <int NPL, int BN>
+int launch_nt_pl_shape(const GP& gp, int kind, dim3 grid, size_t lds, hipStream_t s) {
+  if (kind == 0) return launch_sp(gemm_nt_pl_kernel<NPL, BN, true, false>, grid, lds, gp, s);
+  if (kind == 1) return launch_sp(gemm_nt_pl_kernel<NPL, BN, false, false>, grid, lds, gp, s);
+  return launch_sp(gemm_nt_pl_kernel<NPL, BN, false, true>, grid, lds, gp, s);
+}
+
+int launch_nt_planes(const GP& gp, int npl, int bn, int kind, dim3 grid, size_t lds, hipStream_t s) {
+  if (kind == 3) return set_error(VLFB_ERR_UNSUPPORTED, "conv: the packed stem takes its activation operand as fp32");
+  if (npl == 3) return bn == 128 ? launch_nt_pl_shape<3, 128>(gp, kind, grid, lds, s) : launch_nt_pl_shape<3, 64>(gp, kind, grid, lds, s);
+  return bn == 128 ? launch_nt_pl_shape<2, 128>(gp, kind, grid, lds, s) : launch_nt_pl_shape<2, 64>(gp, kind, grid, lds, s);
+}
+
 int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 grid, size_t lds, hipStream_t s) {
 #define VLFB_TN_SP(BP, BQ)                                                                                     \
   do {                                                                                                         \
-    constexpr int NW = ((BP) >= 128 && (BQ) >= 128) ? 8 : 4;   /* (64-row tiles measured slower with 8 waves) */                                                                  \
-    if (ident) return launch_sp(gemm_tn_sp_kernel<BP, BQ, true, false, NW>, grid, lds, gp, s, 64 * NW);        \
-    if (packw) return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, true, NW>, grid, lds, gp, s, 64 * NW);        \
-    return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, false, NW>, grid, lds, gp, s, 64 * NW);                  \
+    constexpr int NW8 = ((BP) >= 128 && (BQ) >= 128) ? 8 : 4;  /* (64-row tiles measured slower with 8 waves ...) */                                                                  \
+    constexpr int NWS = (BQ) >= 128 ? 8 : 4;                   /* (... except the packed stem: 3.55 -> 2.8 ms) */  \
+    if (ident) return launch_sp(gemm_tn_sp_kernel<BP, BQ, true, false, NW8>, grid, lds, gp, s, 64 * NW8);      \
+    if (packw) return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, true, NWS>, grid, lds, gp, s, 64 * NWS);      \
+    return launch_sp(gemm_tn_sp_kernel<BP, BQ, false, false, NW8>, grid, lds, gp, s, 64 * NW8);                \
   } while (0)
   if (bp == 128 && bq == 128) VLFB_TN_SP(128, 128);
   if (bp == 64 && bq == 128) VLFB_TN_SP(64, 128);

@@ -61,6 +61,7 @@ class Blob(object):
         self.slot = None              # GradSlot (root only)
         self.producer = None
         self.grad_scale = 1.0         # the stored gradient is the true one times this power of two (fp16 range)
+        self.planes = None            # "split" dtype: bf16 term planes [2][numel] of the values, written by the producing conv
 
     @property
     def numel(self):
@@ -99,10 +100,17 @@ class GradSlot(object):
         self.buf = None
         self.count = 0
         self.cur = None
+        self.planes = None            # "split" dtype: bf16 term planes [2][numel] of the FINISHED gradient ...
+        self.planes_valid = False     # ... valid when the last contribution came from a conv epilogue that wrote them
 
     def reset(self):
         self.count = 0
         self.cur = None
+        self.planes_valid = False
+
+    def value_planes(self):
+        """term planes of the finished gradient, or None (the consumer then splits the fp32 values itself)"""
+        return self.planes if (self.planes_valid and self.cur is self.buf) else None
 
     def _flags(self):
         self.count += 1
@@ -112,10 +120,17 @@ class GradSlot(object):
         mask = self.blob.tensor if (last and self.blob.relu) else None
         return self.cur, mask
 
-    def contribute(self, fn, supports_add=True, supports_mask=True):
-        """fn(out, add, mask) launches a kernel writing out = value (+ add), masked by mask > 0."""
+    def contribute(self, fn, supports_add=True, supports_mask=True, writes_planes=False):
+        """fn(out, add, mask) launches a kernel writing out = value (+ add), masked by mask > 0.
+        writes_planes: fn takes a fourth argument, the destination of the output's bf16 term planes (or None); it is
+        handed this slot's planes when the contribution is the LAST one, i.e. when `out` is the finished gradient."""
         add, mask = self._flags()
-        if (add is None or supports_add) and (mask is None or supports_mask):
+        last = self.count == self.expected
+        if writes_planes:
+            want = self.planes if last else None
+            fn(self.buf, add, mask, want)
+            self.planes_valid = want is not None
+        elif (add is None or supports_add) and (mask is None or supports_mask):
             fn(self.buf, add, mask)
         else:
             tmp = self.engine.scratch_act(self.buf.numel(), self.buf.dtype)
@@ -225,6 +240,13 @@ class ConvStep(Step):
                                      Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
                                      math=mb, **common)
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
+        # Pre-split operands ("split" dtype, Engine.PLANES): a conv epilogue can write the bf16 term planes of its output
+        # next to the fp32 values (o_planes), and DGRAD / WGRAD launches that find their activation / gradient operands in
+        # that form spend no VALU on the expansion (a_planes / p_planes).  Variants are built lazily (_pl_desc).
+        self._pl = {}
+        unit = tuple(self.s) == (1, 1, 1)
+        plain = unit and tuple(self.k) == (1, 1, 1) and tuple(self.p) == (0, 0, 0)
+        self.dgrad_takes_planes = bool(eng.split and eng.PLANES and (plain or (unit and Cout % 32 == 0)))
         # operand copies (split math: 3 bf16 term planes for FPROP, 2 for DGRAD -- include/vlfb.h VLFB_SPLIT)
         if eng.split:
             self.w_f = torch.empty((3,) + tuple(wshape), device=eng.device, dtype=torch.bfloat16)
@@ -273,31 +295,64 @@ class ConvStep(Step):
             return self.eng.param_tensor(self.bname)
         return None
 
+    def _pl_desc(self, base, **planes):
+        """copy of a conv descriptor with plane fields set (cached per combination)"""
+        key = (id(base),) + tuple(sorted(planes.items()))
+        d = self._pl.get(key)
+        if d is None:
+            d = hip.ConvDesc.from_buffer_copy(bytes(base))
+            for k, v in planes.items():
+                setattr(d, k, v)
+            self._pl[key] = d
+        return d
+
     def fwd(self):
         R = self.residual.storage() if self.residual is not None else None
+        op = self.out.root.planes
+        if op is not None:
+            hip.conv_run(self._pl_desc(self.d_f, o_planes=2, o_pstride=op.numel() // 2), self.x.storage(), self.w_f, None,
+                         self.out.storage(), bias=self.bias_tensor(), R=R, O_planes=op)
+            return
         hip.conv_run(self.d_f, self.x.storage(), self.w_f, None, self.out.storage(),
                      bias=self.bias_tensor(), R=R)
 
     def bwd(self):
         eng = self.eng
         g = self.out_grad()
+        gp = self.out.root.slot.value_planes()         # term planes of the finished output gradient, or None
         if self.residual is not None and self.residual.needs_grad and not self.residual.detached:
             self.residual.root.slot.contribute_alias(g)
         if self.d_w is not None or (self.cbname and eng.is_trainable(self.cbname)):
             # weight / bias gradients are leaves of the backward graph: they run on the side stream
             # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
             with eng.on_side_stream():
-                self._param_grads(g)
+                self._param_grads(g, gp)
         if self.d_d is not None:
-            self.x.root.slot.contribute(
-                lambda out, add, mask: hip.conv_run(self.d_d, g, self.w_d, None, out, R=add, mask=mask))
+            # the gradient operand as planes when it has them and this launch can take them (plain rows or taps that
+            # span whole k-tiles at unit stride); the input gradient's planes when this is its last contribution
+            a_pl = gp is not None and self.dgrad_takes_planes
+            def dgrad(out, add, mask, planes):
+                kw = {}
+                if a_pl:
+                    kw.update(a_planes=2, a_pstride=gp.numel() // 2)
+                if planes is not None:
+                    kw.update(o_planes=2, o_pstride=planes.numel() // 2)
+                d = self._pl_desc(self.d_d, **kw) if kw else self.d_d
+                hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes)
+            self.x.root.slot.contribute(dgrad, writes_planes=True)
 
-    def _param_grads(self, g):
+    def _param_grads(self, g, gp=None):
         eng = self.eng
         if self.d_w is not None:
             s = eng.param_tensor(self.sname) if self.sname else None
-            hip.conv_run(self.d_w, self.x.storage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
-                         workspace=eng.workspace)
+            xp = self.x.root.planes
+            if gp is not None and xp is not None and not self.stem:
+                # both operands pre-split: DMA + transposed LDS reads, no VALU in the k-loop
+                d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2)
+                hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
+            else:
+                hip.conv_run(self.d_w, self.x.storage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
+                             workspace=eng.workspace)
             if self.stem:   # keep the zero padding of the packed stem weight exactly zero
                 gw = eng.grad_tensor(self.wname)
                 hip.call("vlfb_add", hip.ptr(gw), None, hip.ptr(gw), hip.ptr(eng.stem_mask), hip.F32,
@@ -1259,6 +1314,11 @@ class Engine(object):
 
     # (forward, backward) math of the "split" dtype: hip.MATH_BF16X6 / MATH_BF16X3 (see __init__)
     SPLIT_MATH = (6, 3)
+    # "split" dtype: conv epilogues also write the bf16 term planes of their outputs / input gradients, and the DGRAD / WGRAD
+    # launches that find their operands in that form read them without expanding (ConvStep.bwd); tensors with more rows
+    # than PLANES_MAX_ROWS (the HBM-bound res2 / stem stages) stay fp32-only
+    PLANES = True
+    PLANES_MAX_ROWS = 450000
 
     # ---- side stream for parameter gradients ---------------------------------------------------
     class _Side(object):
@@ -1494,6 +1554,18 @@ class Engine(object):
                 b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.int32)
             if self.train and b.slot.expected > 0:
                 b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=b.tensor.dtype)
+            # "split" dtype: bf16 term planes next to the fp32 values of conv-produced tensors whose consumers are
+            # MFMA-bound convs (the large res2 / stem tensors are HBM-bound: a second copy would only cost traffic)
+            if self.split and self.PLANES and self.train and b.kind == "act" and isinstance(b.producer, ConvStep) and \
+                    not getattr(b, "pad_c", None) and b.rows <= self.PLANES_MAX_ROWS and b.C % 8 == 0:
+                # ... and only around the gathered convs (3x3, 3x1x1): their WGRAD / DGRAD gain 1.4-1.7x from pre-split
+                # operands, the 1x1x1 layers gain nothing that pays for writing a second copy of their (wide) tensors
+                gathered = lambda st: st.k[0] * st.k[1] * st.k[2] > 1
+                if any(isinstance(st, ConvStep) and st.d_w is not None and st.x.root is b and not st.stem and gathered(st)
+                       for st in self.steps):
+                    b.planes = torch.zeros(2 * b.numel, device=dev, dtype=torch.bfloat16)
+                if b.slot.expected > 0 and gathered(b.producer):
+                    b.slot.planes = torch.zeros(2 * b.numel, device=dev, dtype=torch.bfloat16)
         self.workspace = torch.empty(max(self._ws_bytes // 4, 4), device=dev, dtype=torch.float32)
         self._scratch_f32 = torch.empty(max(self._sf32, 4), device=dev, dtype=torch.float32)
         biggest = max([b.tensor.numel() for b in self.all_blobs

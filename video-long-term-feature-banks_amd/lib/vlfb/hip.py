@@ -56,6 +56,8 @@ class ConvDesc(C.Structure):
         ("alpha", C.c_float), ("relu", C.c_int32), ("bias_mode", C.c_int32),
         ("accumulate", C.c_int32), ("splits", C.c_int32), ("algo", C.c_int32),
         ("math", C.c_int32), ("b_pstride", C.c_int64),
+        ("a_planes", C.c_int32), ("p_planes", C.c_int32), ("o_planes", C.c_int32), ("reserved0", C.c_int32),
+        ("a_pstride", C.c_int64), ("p_pstride", C.c_int64), ("o_pstride", C.c_int64),
     ]
 
 
@@ -91,6 +93,7 @@ _SIGS = {
     "vlfb_conv_desc_init": (None, [C.POINTER(ConvDesc)]),
     "vlfb_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
     "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "vlfb_conv_run_planes": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
     "vlfb_ncthw_to_nthwc_wpad": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "vlfb_nthwc_to_ncthw": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
@@ -246,15 +249,15 @@ def conv_tag(d):
 PROFILE = None
 
 
-def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None):
+def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None, O_planes=None):
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     prof = PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().vlfb_conv_run(C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale),
-                             ptr(R), ptr(mask), ptr(workspace), ws_bytes, stream())
+    rc = lib().vlfb_conv_run_planes(C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale),
+                                    ptr(R), ptr(mask), ptr(workspace), ws_bytes, ptr(O_planes), stream())
     if prof is not None:
         e1.record()
         prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d), conv_bytes(d, R is not None, mask is not None)))
