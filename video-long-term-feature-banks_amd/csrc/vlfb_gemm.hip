@@ -1329,6 +1329,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         const long long tiles = (long long)g.tiles_m * g.tiles_n * batch;
         // (split-bf16 math: one 4-wave workgroup per CU leaves every SIMD with a single wave, whose staging and MFMA
         // phases then run back to back; two per CU -- 2 x 64 KiB of LDS -- overlap them)
+        // (re-measured in round 3 on the bf16 path, one box: 256 -> 448.7, 384 -> 436.8, 512 -> 429.9, 768 -> 426.0 clips/s)
         const long long slots = (pl->sp && pl->bm > 64) ? 512 : 256;   // (the 64-row tiles of res2 measured slower at 512)
         long long maxs = (M + 8 * bk - 1) / (8 * bk);
         const long long slab_cap = (96ll << 20) / ((long long)d->Cn * K * 4);   // <= 96 MiB of fp32 slabs
