@@ -15,8 +15,9 @@
  *   - "NCTHW" = the reference's blob layout (kwargs['order']='NCHW',
  *     lib/models/model_builder_video.py:69).  "NTHWC" = this library's internal
  *     channels-last activation layout (rows = N*T*H*W positions, C contiguous).
- *   - element types: VLFB_F32 (parity path, fp32 MFMA) and VLFB_BF16 (throughput path,
- *     bf16 MFMA with fp32 accumulation).
+ *   - element types: VLFB_BF16 / VLFB_F16 (throughput paths: 16-bit storage, bf16 / fp16 MFMA with fp32
+ *     accumulation) and VLFB_F32 -- with vlfb_conv_desc.math = 0 the exact-fp32 MFMA, with math = BF16X6 /
+ *     BF16X3 the parity-grade path: fp32 storage, every product as split-bf16 products on the bf16 matrix cores.
  */
 #ifndef VLFB_H_
 #define VLFB_H_
