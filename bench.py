@@ -62,6 +62,8 @@ def parse():
                     help="development: replay the single-GPU step (or its forward pass) as one captured HIP graph "
                          "(Engine.STEP_GRAPH; measured slower than the two-stream enqueue, see engine.py)")
     ap.add_argument("--detail", default="", help="write the per-launch GEMM table of the profiled step to this file")
+    ap.add_argument("--engine", nargs="*", default=[], metavar="ATTR=VALUE",
+                    help="development: Engine class switches for an A/B inside one call, e.g. --engine PLANES=False STEM_PLANES=False")
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (with VLFB_DIST_FORCE=1 the "
                          "one-rank job then runs the RCCL leg: communicator, bucketed all-reduce, stream hand-over)")
@@ -160,6 +162,10 @@ def main():
                                 "TRAIN.VIDEO_LENGTH", args.frames, "TRAIN.CROP_SIZE", args.crop] + list(args.set))
     model = ModelBuilder(train=True, split="train", name="bench")
     model.build_model(suffix="_train")
+    for kv in args.engine:
+        k, v = kv.split("=", 1)
+        assert hasattr(Engine, k), "Engine has no switch %r" % k
+        setattr(Engine, k, {"True": True, "False": False}.get(v, v if not v.lstrip("-").isdigit() else int(v)))
     Engine.FORWARD_BRANCHES = not args.no_forward_branches
     Engine.STEP_GRAPH = {"off": False, "step": True, "forward": "forward"}[args.graph]
     Engine.EAGER_SOLVER = {"after": False, "eager": True, "tail": "tail"}[args.solver]

@@ -174,6 +174,24 @@ def test_split_stem_packed(hw):
     hip.conv_run(desc, X4, None, G, DW, workspace=ws)
     assert rel_err(DW[:, :, :, :7, :3].permute(0, 4, 1, 2, 3), gw) < TOL3
     assert float(DW[..., 3].abs().max()) == 0.0
+    # the same two launches on pre-split operands (the clip's and the output gradient's term planes from a split pass)
+    nin, nout = X4.numel(), G.numel()
+    Xp = torch.empty(3 * nin, device=dev(), dtype=torch.bfloat16)
+    Gp = torch.empty(2 * nout, device=dev(), dtype=torch.bfloat16)
+    hip.call("vlfb_split_planes", hip.ptr(X4), hip.ptr(Xp), 3, 1, nin // 8, 8, 0)
+    hip.call("vlfb_split_planes", hip.ptr(G), hip.ptr(Gp), 2, 1, nout // 8, 8, 0)
+    O2 = torch.empty_like(O)
+    desc = hip.conv_desc(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=WP, Cs=4,
+                         Cn=Cout, pack_w=8, math=hip.MATH_BF16X6, b_pstride=Cout * 1120, a_planes=3, a_pstride=nin, **gk)
+    hip.conv_run(desc, Xp, Wf, None, O2)
+    assert rel_err(to_ncthw(O2), y_ref) < TOL6
+    DW2 = torch.empty_like(DW)
+    desc = hip.conv_desc(mode=hip.WGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=WP, Cs=4,
+                         Cn=Cout, pack_w=8, math=hip.MATH_BF16X3, a_planes=3, a_pstride=nin, p_planes=2, p_pstride=nout, **gk)
+    ws = torch.empty(max(hip.conv_workspace_bytes(desc), 16) // 4, device=dev(), dtype=torch.float32)
+    hip.conv_run(desc, Xp, None, Gp, DW2, workspace=ws)
+    assert rel_err(DW2[:, :, :, :7, :3].permute(0, 4, 1, 2, 3), gw) < TOL3
+    assert float(DW2[..., 3].abs().max()) == 0.0
 
 
 def test_split_batched_products_of_the_nonlocal_block():

@@ -1250,7 +1250,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->tn_tr = is16(d->dtype) && d->Cn % 8 == 0;
     if (pl->tn8) pl->tn_tr = 1;
     if (pl->sp_pl) {       // two-plane operands: the DMA + transposed-read kernel in its SP form
-      VLFB_REQUIRE(d->Cn % 8 == 0 && g.lda % 8 == 0 && g.ldp % 8 == 0 && d->a_pstride % 8 == 0 && d->p_pstride % 8 == 0,
+      VLFB_REQUIRE(d->Cn % 8 == 0 && (g.lda % 8 == 0 || pl->packw) && g.ldp % 8 == 0 && d->a_pstride % 8 == 0 && d->p_pstride % 8 == 0,
                    "conv: plane operands need channel counts / strides in multiples of 8");
       pl->tn_tr = 1;
     }
@@ -1468,12 +1468,21 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     const size_t tile = (size_t)pl->bm * pl->bn * 4;
     g.epi = (int)((tile + pl->lds - 1) / pl->lds);
     if (g.epi > 2) { pl->lds = tile / 2; g.epi = 2; }
+    // (re-measured in round 3: prefetching for <= 16 / 36 / all k-tiles instead of 8 moves the bf16 step by -0.1 .. -0.7 %)
     pl->pre = g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
     if (pl->sp) {
       pl->sp_kind = pl->ident ? 0 : pl->packw ? 3 : d->mode == VLFB_CONV_FPROP ? 1 : 2;
       pl->threads = kThreads;
       pl->pre = 0;
-      VLFB_REQUIRE(!pl->sp_pl || ((pl->ident || pl->ut) && d->a_pstride % 8 == 0 && g.lda % 8 == 0),
+      if (pl->packw && d->mode == VLFB_CONV_FPROP && d->pack_w == 8) {
+        // The packed stem at k-tiles of 32 elements: one k-tile IS one (a, b) tap row (8 kw pixels x 4 channels), so the
+        // gather is the scalar-cursor one of a conv with kw = 1, 32 "channels" per tap and 4 elements per pixel -- no
+        // per-lane tap decode (it cost ~100 VALU per k-tile next to 48 MFMAs).  The W-padded input keeps every w in range.
+        g.kw = 1; g.Cs = d->pack_w * 4; g.lda = 4;
+        pl->ut = 1;
+        pl->sp_kind = 1;
+      }
+      VLFB_REQUIRE(!pl->sp_pl || ((pl->ident || pl->ut) && d->a_pstride % 8 == 0 && (g.lda % 8 == 0 || pl->packw)),
                    "conv: a pre-split activation operand needs plain rows or taps that span whole 32-element k-tiles");
       VLFB_REQUIRE(!d->o_planes || (d->o_pstride % 4 == 0 && batch == 1), "conv: o_planes needs batch 1 and an aligned o_pstride");
       const size_t sbuf = (pl->sp_pl ? (size_t)pl->sp * 128 * 64 : (size_t)128 * 128) + (size_t)pl->sp * pl->bn * 64;

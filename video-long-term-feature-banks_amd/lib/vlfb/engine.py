@@ -244,6 +244,14 @@ class ConvStep(Step):
         # next to the fp32 values (o_planes), and DGRAD / WGRAD launches that find their activation / gradient operands in
         # that form spend no VALU on the expansion (a_planes / p_planes).  Variants are built lazily (_pl_desc).
         self._pl = {}
+        # the stem reads the clip: its term planes are made once per forward pass by a split pass (3 planes for the
+        # six-product FPROP, of which the WGRAD reads the first two next to a split pass over its output gradient)
+        self.x_planes = self.g_planes = None
+        if self.stem and eng.split and eng.PLANES and eng.STEM_PLANES:
+            n_in = self.x.root.numel // self.x.root.C // self.x.root.shape[-1] * W * self.Cin_k     # W is the padded width here
+            self.x_planes = torch.empty(3 * n_in, device=eng.device, dtype=torch.bfloat16)
+            if eng.is_trainable(self.wname):
+                self.g_planes = torch.empty(2 * self.out.numel, device=eng.device, dtype=torch.bfloat16)
         unit = tuple(self.s) == (1, 1, 1)
         plain = unit and tuple(self.k) == (1, 1, 1) and tuple(self.p) == (0, 0, 0)
         self.dgrad_takes_planes = bool(eng.split and eng.PLANES and (plain or (unit and Cout % 32 == 0)))
@@ -309,6 +317,12 @@ class ConvStep(Step):
     def fwd(self):
         R = self.residual.storage() if self.residual is not None else None
         op = self.out.root.planes
+        if self.x_planes is not None:
+            n = self.x_planes.numel() // 3
+            hip.call("vlfb_split_planes", self.x.ptr(), hip.ptr(self.x_planes), 3, 1, n // 8, 8, 0)
+            hip.conv_run(self._pl_desc(self.d_f, a_planes=3, a_pstride=n), self.x_planes, self.w_f, None, self.out.storage(),
+                         bias=self.bias_tensor(), R=R)
+            return
         if op is not None:
             hip.conv_run(self._pl_desc(self.d_f, o_planes=2, o_pstride=op.numel() // 2), self.x.storage(), self.w_f, None,
                          self.out.storage(), bias=self.bias_tensor(), R=R, O_planes=op)
@@ -346,7 +360,12 @@ class ConvStep(Step):
         if self.d_w is not None:
             s = eng.param_tensor(self.sname) if self.sname else None
             xp = self.x.root.planes
-            if gp is not None and xp is not None and not self.stem:
+            if self.g_planes is not None:          # stem: both operands through a split pass (the clip's planes exist)
+                n = self.x_planes.numel() // 3
+                hip.call("vlfb_split_planes", hip.ptr(g), hip.ptr(self.g_planes), 2, 1, self.out.numel // 8, 8, 0)
+                d = self._pl_desc(self.d_w, a_planes=3, a_pstride=n, p_planes=2, p_pstride=self.out.numel)
+                hip.conv_run(d, self.x_planes, None, self.g_planes, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
+            elif gp is not None and xp is not None and not self.stem:
                 # both operands pre-split: DMA + transposed LDS reads, no VALU in the k-loop
                 d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2)
                 hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
@@ -1319,6 +1338,7 @@ class Engine(object):
     # than PLANES_MAX_ROWS (the HBM-bound res2 / stem stages) stay fp32-only
     PLANES = True
     PLANES_MAX_ROWS = 450000
+    STEM_PLANES = True          # conv1: clip and output gradient through a split pass, FPROP / WGRAD on planes
 
     # ---- side stream for parameter gradients ---------------------------------------------------
     class _Side(object):
