@@ -1334,10 +1334,10 @@ class Engine(object):
     # (forward, backward) math of the "split" dtype: hip.MATH_BF16X6 / MATH_BF16X3 (see __init__)
     SPLIT_MATH = (6, 3)
     # "split" dtype: conv epilogues also write the bf16 term planes of their outputs / input gradients, and the DGRAD / WGRAD
-    # launches that find their operands in that form read them without expanding (ConvStep.bwd); tensors with more rows
-    # than PLANES_MAX_ROWS (the HBM-bound res2 / stem stages) stay fp32-only
+    # launches that find their operands in that form read them without expanding (ConvStep.bwd); tensors with more than
+    # PLANES_MAX_NUMEL elements (the wide res2 / stem tensors: a second copy costs more HBM time than it saves) stay fp32-only
     PLANES = True
-    PLANES_MAX_ROWS = 450000
+    PLANES_MAX_NUMEL = 52 << 20
     STEM_PLANES = True          # conv1: clip and output gradient through a split pass, FPROP / WGRAD on planes
 
     # ---- side stream for parameter gradients ---------------------------------------------------
@@ -1577,7 +1577,7 @@ class Engine(object):
             # "split" dtype: bf16 term planes next to the fp32 values of conv-produced tensors whose consumers are
             # MFMA-bound convs (the large res2 / stem tensors are HBM-bound: a second copy would only cost traffic)
             if self.split and self.PLANES and self.train and b.kind == "act" and isinstance(b.producer, ConvStep) and \
-                    not getattr(b, "pad_c", None) and b.rows <= self.PLANES_MAX_ROWS and b.C % 8 == 0:
+                    not getattr(b, "pad_c", None) and b.numel <= self.PLANES_MAX_NUMEL and b.C % 8 == 0:
                 # ... and only around the gathered convs (3x3, 3x1x1): their WGRAD / DGRAD gain 1.4-1.7x from pre-split
                 # operands, the 1x1x1 layers gain nothing that pays for writing a second copy of their (wide) tensors
                 gathered = lambda st: st.k[0] * st.k[1] * st.k[2] > 1
