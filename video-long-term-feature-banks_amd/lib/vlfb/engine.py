@@ -1329,6 +1329,8 @@ class Engine(object):
         self._graph_key = None
         self._graph_stream = None
         self._eager_steps = 0
+        self._trace = None             # recorded step (STEP_TRACE)
+        self._trace_key = None
         model.engine = self
 
     # (forward, backward) math of the "split" dtype: hip.MATH_BF16X6 / MATH_BF16X3 (see __init__)
@@ -1349,9 +1351,8 @@ class Engine(object):
             eng = self.eng
             if eng.side is None:
                 return self
-            ev = torch.cuda.Event()
-            ev.record()                       # everything enqueued so far on the main stream
-            eng.side.wait_event(ev)
+            ev = eng.record_event()           # everything enqueued so far on the main stream
+            eng.wait_event(eng.side, ev)
             self.ctx = torch.cuda.stream(eng.side)
             self.ctx.__enter__()
             eng.side_dirty = True
@@ -1365,13 +1366,35 @@ class Engine(object):
     def on_side_stream(self):
         return Engine._Side(self)
 
+    # stream-ordering primitives of a step: like the kernel launches (hip.call) they append themselves to hip.TRACE
+    # while a step is being recorded, so that a replay re-issues the same edges between the same streams
+    def record_event(self, stream=None):
+        ev = torch.cuda.Event()
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        ev.record(stream)
+        if hip.TRACE is not None:
+            hip.TRACE.append((ev.record, (stream,), "event record"))
+        return ev
+
+    def wait_event(self, stream, ev):
+        stream.wait_event(ev)
+        if hip.TRACE is not None:
+            hip.TRACE.append((stream.wait_event, (ev,), "stream wait"))
+
+    def wait_stream(self, other):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(other)
+        if hip.TRACE is not None:
+            hip.TRACE.append((cur.wait_stream, (other,), "stream join"))
+
     def join_side_stream(self):
         """make the main stream wait for every parameter-gradient kernel issued so far"""
         if self.side is not None and self.side_dirty:
-            torch.cuda.current_stream().wait_stream(self.side)
+            self.wait_stream(self.side)
             self.side_dirty = False
         if self.solver_stream is not None and self.solver_dirty:
-            torch.cuda.current_stream().wait_stream(self.solver_stream)
+            self.wait_stream(self.solver_stream)
             self.solver_dirty = False
 
     # ---- bookkeeping used by steps ------------------------------------------------------------
@@ -1822,16 +1845,14 @@ class Engine(object):
             on_side = i in self._fwd_side
             stream = self.side if on_side else main
             for j in self._fwd_wait[i]:
-                stream.wait_event(done[j])
+                self.wait_event(stream, done[j])
             if on_side:
                 with torch.cuda.stream(self.side):
                     st.fwd()
             else:
                 st.fwd()
             if i in self._fwd_signal:
-                ev = torch.cuda.Event()
-                ev.record(stream)
-                done[i] = ev
+                done[i] = self.record_event(stream)
 
     # independent forward branches on the second stream (Engine.forward)
     FORWARD_BRANCHES = True
@@ -1924,13 +1945,9 @@ class Engine(object):
             return
         # position of the dgrad chain (main stream) and of the parameter-gradient stream; the third stream waits for
         # both -- neither of the two compute streams waits for anything here
-        ev = torch.cuda.Event()
-        ev.record()
-        ev2 = torch.cuda.Event()
-        ev2.record(self.side)
         sol = self.solver_stream
-        sol.wait_event(ev)
-        sol.wait_event(ev2)
+        self.wait_event(sol, self.record_event())
+        self.wait_event(sol, self.record_event(self.side))
         with torch.cuda.stream(sol):
             works = self.comm.after_step(i) if self.comm is not None else []
             if eager:
@@ -2078,9 +2095,22 @@ class Engine(object):
     # profiled steps (hip.PROFILE) always use the stream path.
     STEP_GRAPH = False
 
+    # True: the second train_step() records every call it makes into the library and every event / stream edge
+    # (hip.TRACE), and later steps re-issue that list instead of walking the step objects: same kernels, same streams,
+    # same order, same cross-stream edges -- only the Python between the calls (operand lookup, gradient-slot
+    # bookkeeping, descriptor selection, ~450 ctypes argument conversions) is gone.  Unlike STEP_GRAPH the device
+    # still sees ordinary stream launches, so the two-stream overlap is kept.  The per-iteration values (learning rate,
+    # dropout seeds) are read from device memory as in a captured step.  Bit-identical to the stream path
+    # (tests/test_step_graph_gpu.py).  Data-parallel steps (the collectives are issued by torch) and profiled steps
+    # use the stream path; the trace is re-recorded when the stream or a class switch changes.
+    STEP_TRACE = False
+
     def train_step(self, lr=None):
         if lr is not None:
             self.lr = float(lr)
+        if self.STEP_TRACE and not self.STEP_GRAPH and self.comm is None and hip.PROFILE is None and \
+                self._eager_steps >= 1 and not self.dry_run:
+            return self._trace_step()
         if self.STEP_GRAPH and self.comm is None and hip.PROFILE is None and self._eager_steps >= 1 and \
                 not self.dry_run:
             if self.STEP_GRAPH == "forward":
@@ -2111,6 +2141,36 @@ class Engine(object):
             chunk = vals[c:c + 8]
             arr = (C.c_uint64 * len(chunk))(*chunk)
             hip.call("vlfb_store_scalars", hip.ptr(self._scalars_dev) + 8 * c, len(chunk), arr)
+
+    def _trace_step(self):
+        if self._operand_version != self._pstate[0]:
+            self.refresh_operands(all_params=True)
+        key = (torch.cuda.current_stream().cuda_stream, self.side is None, self.EAGER_SOLVER, self.FORWARD_BRANCHES,
+               self.BUCKET_HANDOFF)
+        self._store_step_scalars()
+        if self._trace is None or self._trace_key != key:
+            self._trace, self._trace_key = None, None
+            self._dev_scalars = True
+            hip.TRACE = rec = []
+            try:
+                self._train_step_streams()           # runs the step for real while recording it
+            finally:
+                self._dev_scalars = False
+                hip.TRACE = None
+            self._trace_losses = [st for st in self.steps if isinstance(st, LossStep)]
+            for st in self._trace_losses:
+                st.ring_push()
+            self._trace, self._trace_key = rec, key
+            return
+        for fn, args, name in self._trace:
+            rc = fn(*args)
+            if rc:
+                hip._check(rc, name)
+        for st in self._trace_losses:
+            st.ring_push()
+        self._pstate[0] += 1
+        self._operand_version = self._pstate[0]
+        self.iteration += 1
 
     def _capture_step(self, key, scope):
         losses = [st for st in self.steps if isinstance(st, LossStep)]

@@ -189,10 +189,27 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# When a list, every stream-ordered call is also appended to it as (function, arguments incl. the stream, name):
+# Engine.train_step records one step this way and replays the list (Engine.STEP_TRACE).
+TRACE = None
+
+
+def freeze_args(fn, args):
+    """convert plain ints / floats to the ctypes objects of the signature once, so a replayed call converts nothing"""
+    types = getattr(fn, "argtypes", None)
+    if not types:
+        return args
+    return tuple(t(a) if isinstance(a, (int, float)) and issubclass(t, C._SimpleCData) else a
+                 for t, a in zip(types, args))
+
+
 def call(name, *args):
     """Call a status-returning entry point, appending the current HIP stream."""
     fn = getattr(lib(), name)
-    _check(fn(*args, stream()), name)
+    args = args + (stream(),)
+    if TRACE is not None:
+        TRACE.append((fn, freeze_args(fn, args), name))
+    _check(fn(*args), name)
 
 
 def conv_desc(**kw):
@@ -256,8 +273,12 @@ def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspa
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().vlfb_conv_run_planes(C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale),
-                                    ptr(R), ptr(mask), ptr(workspace), ws_bytes, ptr(O_planes), stream())
+    fn = lib().vlfb_conv_run_planes
+    args = (C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale), ptr(R), ptr(mask), ptr(workspace),
+            ws_bytes, ptr(O_planes), stream())
+    if TRACE is not None:
+        TRACE.append((fn, freeze_args(fn, args), "vlfb_conv_run_planes"))
+    rc = fn(*args)
     if prof is not None:
         e1.record()
         prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d), conv_bytes(d, R is not None, mask is not None)))
