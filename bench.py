@@ -289,6 +289,7 @@ def main():
         ("model_flops_utilisation", round((fam["nt"][0] + fam["tn"][0]) * args.steps / elapsed / 1e12 / peak, 4)),
         ("gflop_per_step_per_gpu", round((fam["nt"][0] + fam["tn"][0]) / 1e9, 1)),
         ("host_enqueue_ms_per_step", round(host_ms, 2)),
+        ("host_enqueue_path", "recorded call list (Engine.STEP_TRACE)" if eng._trace is not None else "step objects"),
     ])
     if eng.comm is not None:       # the gradient exchange of this job (None on a one-process run without a process group)
         out["allreduce"] = {"backend": torch.distributed.get_backend(), "buckets": len(eng.comm.buckets),

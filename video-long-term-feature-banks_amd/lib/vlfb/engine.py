@@ -2103,7 +2103,10 @@ class Engine(object):
     # dropout seeds) are read from device memory as in a captured step.  Bit-identical to the stream path
     # (tests/test_step_graph_gpu.py).  Data-parallel steps (the collectives are issued by torch) and profiled steps
     # use the stream path; the trace is re-recorded when the stream or a class switch changes.
-    STEP_TRACE = False
+    # Measured on one MI355X (8 clips bf16, idle queue): enqueuing a step takes 6.1-6.3 ms through the step objects,
+    # 1.9-2.8 ms from the trace (C3 frozen backbone: 2.5 -> 0.75 ms); the step itself is GPU-bound either way
+    # (440.1 vs 440.1 clips/s), the point is the host thread the data loader shares.
+    STEP_TRACE = True
 
     def train_step(self, lr=None):
         if lr is not None:
