@@ -165,7 +165,9 @@ def main():
     for kv in args.engine:
         k, v = kv.split("=", 1)
         assert hasattr(Engine, k), "Engine has no switch %r" % k
-        setattr(Engine, k, {"True": True, "False": False}.get(v, v if not v.lstrip("-").isdigit() else int(v)))
+        if "," in v:
+            v = tuple(int(x) for x in v.split(","))
+        setattr(Engine, k, {"True": True, "False": False}.get(v, v if not str(v).lstrip("-").isdigit() else int(v)))
     Engine.FORWARD_BRANCHES = not args.no_forward_branches
     Engine.STEP_GRAPH = {"off": False, "step": True, "forward": "forward"}[args.graph]
     Engine.EAGER_SOLVER = {"after": False, "eager": True, "tail": "tail"}[args.solver]
