@@ -298,8 +298,8 @@ def main():
                             "bucket_mb": args.bucket_mb, "payload_mb": round(eng.flat_grad.numel() * 4 / 1e6, 1),
                             "handoff": Engine.BUCKET_HANDOFF}
     # The parity-grade paths on the same workload, so that the numbers next to the parity claims exist:
-    #   split_path: fp32 storage, every contraction as split-bf16 products on the bf16 matrix cores (six MFMAs per product
-    #               forward, three backward; csrc/vlfb_gemm_split.hip) -- outputs AND every parameter gradient within 1e-3 of
+    #   split_path: fp32 storage, every contraction as split-bf16 products on the bf16 matrix cores (three MFMAs per product,
+    #               Engine.SPLIT_MATH; csrc/vlfb_gemm_split.hip) -- outputs AND every parameter gradient within 1e-3 of
     #               the fp64 oracle at the benchmarked size (profiles/r03_parity_fullsize_*.txt)
     #   fp32_path:  the same with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 matrix rate)
     step_flops = fam["nt"][0] + fam["tn"][0]
@@ -326,7 +326,8 @@ def main():
         torch.cuda.empty_cache()
         for key, dtype, steps, skip, what, peak_tf in (
                 ("split_path", "split", args.split_steps, args.no_split_line,
-                 "fp32 storage + split-bf16 products on v_mfma_f32_16x16x32_bf16 (6 per product forward, 3 backward)", 2500.0 / 4.0),
+                 "fp32 storage + split-bf16 products on v_mfma_f32_16x16x32_bf16 (%d per product forward, %d backward)" % Engine.SPLIT_MATH,
+                 2500.0 * 3.0 / (Engine.SPLIT_MATH[0] + 2 * Engine.SPLIT_MATH[1])),   # 1/3 of a step's FLOP are forward
                 ("fp32_path", "fp32", args.fp32_steps, args.no_fp32_line,
                  "fp32 storage + v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak)", PEAK_TFLOPS["fp32"])):
             if skip:

@@ -100,7 +100,8 @@ int vlfb_affine_nd_bwd(const float* dy, const float* scale, float* dx,
  * ------------------------------------------------------------------------------------------ */
 enum { VLFB_CONV_FPROP = 0, VLFB_CONV_DGRAD = 1, VLFB_CONV_WGRAD = 2 };
 enum { VLFB_BIAS_NONE = 0, VLFB_BIAS_COL = 1, VLFB_BIAS_ROW = 2 };
-enum { VLFB_ALGO_AUTO = 0, VLFB_ALGO_TILE128 = 1, VLFB_ALGO_PIPE256 = 2, VLFB_ALGO_STREAM = 3 };
+enum { VLFB_ALGO_AUTO = 0, VLFB_ALGO_TILE128 = 1, VLFB_ALGO_PIPE256 = 2, VLFB_ALGO_STREAM = 3,
+       VLFB_ALGO_CLASSES = 4 /* split-math DGRAD of a (1,2,2)-strided conv: force the parity-class walk (AUTO takes it for kh*kw > 1) */ };
 
 typedef struct vlfb_conv_desc {
   int32_t mode;

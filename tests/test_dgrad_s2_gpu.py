@@ -61,3 +61,57 @@ def test_class_major_strided_dgrad_is_bit_identical_and_matches_fp64(case, tdt):
     gx, = torch.autograd.grad(F.conv3d(xd, w.double(), None, s, p, d), xd, dy.double())
     assert rel_err(to_ncthw(got[hip.ALGO_AUTO][0].float()), torch.where(mask_src.double() > 0, gx + add_src.double(), torch.zeros_like(gx))) < tol
     assert rel_err(to_ncthw(got[hip.ALGO_AUTO][3].float()), 0.5 * gx) < tol
+
+
+SPLIT_CASES = dict(CASES)
+SPLIT_CASES["conv1x1"] = (2, 256, 64, 2, 12, 20, (1, 1, 1), (0, 0, 0))           # three of the four classes have no tap at all
+SPLIT_CASES["conv3x3_ragged"] = (1, 72, 128, 2, 18, 14, (1, 3, 3), (0, 1, 1))    # Cin not a multiple of the column tile
+
+
+@pytest.mark.parametrize("case", sorted(SPLIT_CASES))
+def test_class_major_strided_dgrad_split_bf16(case):
+    """the same walk in the split-bf16 kernel (csrc/vlfb_gemm_split.hip, gemm_nt_sp_kernel<.., S2>: scalar tap cursor
+    over the class's taps, fp32 storage, three bf16 products per product): bit-identical to the plain enumeration for
+    every epilogue, planes of the result included, and within the three-term bar of fp64 autograd"""
+    from vlfb import hip
+    hip.lib()
+    N, Cin, Cout, T, H, W, k, p = SPLIT_CASES[case]
+    s, d = (1, 2, 2), (1, 1, 1)
+    gen = torch.Generator().manual_seed(sum(map(ord, case)) + 7)
+    x = torch.randn(N, Cin, T, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, *k, generator=gen) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    To, Ho, Wo = [(a + 2 * pp - (kk - 1) - 1) // ss + 1 for a, kk, ss, pp in zip((T, H, W), k, s, p)]
+    taps = k[0] * k[1] * k[2]
+    dy = torch.randn(N, Cout, To, Ho, Wo, generator=gen)
+    mask_src = torch.randn(N, Cin, T, H, W, generator=gen)
+    add_src = torch.randn(N, Cin, T, H, W, generator=gen)
+    G = to_nthwc(dy).to(dev())
+    wk = w.permute(0, 2, 3, 4, 1).contiguous().to(dev())
+    Wf = torch.empty(3, Cout, taps, Cin, device=dev(), dtype=torch.bfloat16)
+    Wd = torch.empty(2, Cin, taps, Cout, device=dev(), dtype=torch.bfloat16)
+    hip.call("vlfb_weight_prep", hip.ptr(wk), None, hip.ptr(Wf), hip.ptr(Wd), hip.SPLIT, Cout, taps, Cin)
+    Rm, Mm = to_nthwc(add_src).to(dev()), to_nthwc(mask_src).to(dev())
+    geom = dict(kt=k[0], kh=k[1], kw=k[2], st=1, sh=2, sw=2, pt=p[0], ph=p[1], pw=p[2], dt=1, dh=1, dw=1)
+    Mi = N * T * H * W
+    got = {}
+    for algo in (hip.ALGO_TILE128, hip.ALGO_CLASSES):       # (AUTO takes the class walk for kh * kw > 1 only)
+        outs = []
+        for kw in (dict(R=Rm, mask=Mm), dict(R=Rm), dict(mask=Mm), dict()):
+            DX = torch.full((N, T, H, W, Cin), float("nan"), device=dev())
+            DXp = torch.full((2, Mi, Cin), float("nan"), device=dev(), dtype=torch.bfloat16)
+            desc = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo,
+                                 Cs=Cout, Cn=Cin, alpha=0.5 if not kw else 1.0, algo=algo, math=hip.MATH_BF16X3,
+                                 b_pstride=Cin * taps * Cout, o_planes=2, o_pstride=Mi * Cin, **geom)
+            hip.conv_run(desc, G, Wd, None, DX, O_planes=DXp, **kw)
+            torch.cuda.synchronize()
+            outs.append((DX, DXp))
+        got[algo] = outs
+    for (a, ap), (b, bp) in zip(got[hip.ALGO_CLASSES], got[hip.ALGO_TILE128]):
+        assert not torch.isnan(a).any() and not torch.isnan(ap.float()).any()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert torch.equal(ap.view(torch.int16), bp.view(torch.int16))
+    xd = x.double().requires_grad_(True)
+    gx, = torch.autograd.grad(F.conv3d(xd, w.double(), None, s, p, d), xd, dy.double())
+    want = torch.where(mask_src.double() > 0, gx + add_src.double(), torch.zeros_like(gx))
+    assert rel_err(to_ncthw(got[hip.ALGO_CLASSES][0][0]), want) < 2e-5
+    assert rel_err(to_ncthw(got[hip.ALGO_CLASSES][3][0]), 0.5 * gx) < 2e-5

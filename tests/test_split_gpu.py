@@ -300,6 +300,19 @@ def test_split_products_on_presplit_operands(case):
                          relu=1, math=hip.MATH_BF16X6, b_pstride=plane, o_planes=2, o_pstride=Mo * Cout, **g)
     hip.conv_run(desc, A, Wf, None, O2, O_planes=Op2)
     assert torch.equal(Op2.cpu(), planes_of(O2.cpu().reshape(Mo, Cout), 2))
+    # three-term FPROP (the engine's default forward math) on the first two planes, with a residual, against the same
+    # launch on the fp32 operand: the two kernels form the same products in the same order
+    Rs = gpu(torch.randn(N, To, Ho, Wo, Cout, generator=gen))
+    O3, O4 = torch.full_like(O, float("nan")), torch.full_like(O, float("nan"))
+    Op3 = torch.full_like(Op, float("nan"))
+    common = dict(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout,
+                  relu=1, math=hip.MATH_BF16X3, b_pstride=plane, **g)
+    hip.conv_run(hip.conv_desc(a_planes=2, a_pstride=Mi * Cin, o_planes=2, o_pstride=Mo * Cout, **common), Ap, Wf, None, O3, R=Rs,
+                 O_planes=Op3)
+    hip.conv_run(hip.conv_desc(**common), A, Wf, None, O4, R=Rs)
+    want = torch.relu(y_lin + Rs.cpu().double().permute(0, 4, 1, 2, 3))
+    assert rel_err(to_ncthw(O3), want) < TOL3 and rel_err(to_ncthw(O4), want) < TOL3, "three-term fprop"
+    assert torch.equal(Op3.cpu(), planes_of(O3.cpu().reshape(Mo, Cout), 2))
     # DGRAD on the pre-split gradient (two terms); strided convs have no scalar tap cursor and keep the fp32 operand
     if not strided:
         DX = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=torch.float32)

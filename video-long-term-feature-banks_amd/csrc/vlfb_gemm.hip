@@ -1230,6 +1230,22 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       g.tiles_m = 4 * g.s2_tpc;
       pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), 1, 1);
     }
+    // The split-bf16 form of the same walk (gemm_nt_sp_kernel<.., S2>): a scalar tap cursor over the class's taps instead
+    // of the per-lane decode.  Measured in the step (8 clips): res3_0 2b 502 -> 321 us, res4_0 2b 486 -> 240 us.  The 1x1x1
+    // shortcuts stay on the plain walk here too (VLFB_SPLIT_S2_1X1=1 to try: 466 -> 513 us, 386 -> 380 us).
+    static const bool s2_sp_off = getenv("VLFB_SPLIT_S2") && atoi(getenv("VLFB_SPLIT_S2")) == 0;
+    static const bool s2_sp_1x1_off = !(getenv("VLFB_SPLIT_S2_1X1") && atoi(getenv("VLFB_SPLIT_S2_1X1")) == 1);
+    const bool s2_sp_want = d->algo == VLFB_ALGO_CLASSES || (d->algo == VLFB_ALGO_AUTO && !s2_sp_off && (d->kh * d->kw > 1 || !s2_sp_1x1_off));
+    if (d->mode == VLFB_CONV_DGRAD && s2_sp_want && pl->sp == 2 && !pl->sp_pl && !pl->ident && !pl->packw &&
+        batch == 1 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->dt == 1 && d->dh == 1 &&
+        d->dw == 1 && d->Hr % 2 == 0 && d->Wr % 2 == 0 && d->Cs % 32 == 0 && d->bias_mode == VLFB_BIAS_NONE) {
+      g.s2 = 1;
+      g.s2_mq = (int)(M / 4);
+      g.s2_tpc = (g.s2_mq + pl->bm - 1) / pl->bm;
+      g.tiles_m = 4 * g.s2_tpc;
+      pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), 1, 1);
+    }
+    VLFB_REQUIRE(d->algo != VLFB_ALGO_CLASSES || g.s2, "conv: algo = CLASSES is the split-math DGRAD of a (1, 2, 2)-strided conv (even H, W; Cs % 32 == 0)");
   } else {
     pl->bm = d->Cn > 64 ? 128 : 64;             // P tile (output rows)
     pl->bn = K > 64 ? 128 : 64;                 // Q tile (output columns)
@@ -1482,6 +1498,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
         pl->ut = 1;
         pl->sp_kind = 1;
       }
+      if (g.s2) { pl->ut = 1; pl->sp_kind = 2; }
       VLFB_REQUIRE(!pl->sp_pl || ((pl->ident || pl->ut) && d->a_pstride % 8 == 0 && (g.lda % 8 == 0 || pl->packw)),
                    "conv: a pre-split activation operand needs plain rows or taps that span whole 32-element k-tiles");
       VLFB_REQUIRE(!d->o_planes || (d->o_pstride % 4 == 0 && batch == 1), "conv: o_planes needs batch 1 and an aligned o_pstride");

@@ -88,10 +88,22 @@ __device__ __forceinline__ f32x4_v mma_bf16(bf16x8_v a, bf16x8_v b, f32x4_v c) {
 // the first two bf16 terms of v as planes [plane][row][ldo]: the operand format a later split launch reads without
 // spending VALU on the expansion (vlfb_conv_desc.o_planes).
 // =============================================================================================
-template <int BN, int FN, int FM>
+// S2 (class-major rows of a (1, 2, 2)-strided DGRAD, see gemm_nt_sp_kernel): tile row m of class (ph, pw) is the input
+// position (n, t, 2 h2 + ph, 2 w2 + pw); the residual / mask / output rows are addressed through that map.
+__device__ __forceinline__ long long s2_row_pos(const GP& p, int m, int ph, int pw) {
+  const int w2n = p.Wr >> 1, h2n = p.Hr >> 1;
+  const int w2 = m % w2n;
+  int q = m / w2n;
+  const int h2 = q % h2n;
+  q /= h2n;                                        // n * Tr + t
+  return ((long long)q * p.Hr + 2 * h2 + ph) * p.Wr + 2 * w2 + pw;
+}
+
+template <int BN, int FN, int FM, bool S2 = false>
 __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN][FM], char* smem, int m0, int n0, int z, int tid,
-                                            int wm, int wn, int l15, int g) {
+                                            int wm, int wn, int l15, int g, int s2_ph = 0, int s2_pw = 0) {
   constexpr int BM = 128, NTHR = 256, WM = 64, WN = BN / 2;
+  const int mrows = S2 ? p.s2_mq : p.M;
   char* Ob = p.O + (long long)z * p.o_bs * 4;
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 4 : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 4 : nullptr;
@@ -105,8 +117,9 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
 #pragma unroll
   for (int gp = 0; gp < NPASS; ++gp) {
     const int m = m0 + gp * RPP + tr;
-    const bool ok = m < p.M && ncol < p.Ncols;
-    const long long ridx = (long long)(ok ? m : 0) * p.ldr + (ok ? ncol : 0);
+    const bool ok = m < mrows && ncol < p.Ncols;
+    const long long mo = S2 ? s2_row_pos(p, ok ? m : 0, s2_ph, s2_pw) : (long long)(ok ? m : 0);
+    const long long ridx = mo * p.ldr + (ok ? ncol : 0);
     rv[gp] = (Rb && ok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Rb) + ridx) : make_float4(0.f, 0.f, 0.f, 0.f);
     mv[gp] = (Mb && ok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Mb) + ridx) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
@@ -128,11 +141,12 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
   for (int gp = 0; gp < NPASS; ++gp) {
     const int row = gp * RPP + tr;
     const int m = m0 + row;
-    if (m < p.M && ncol < p.Ncols) {
+    if (m < mrows && ncol < p.Ncols) {
+      const long long mo = S2 ? s2_row_pos(p, m, s2_ph, s2_pw) : (long long)m;
       const float4 t = *reinterpret_cast<const float4*>(smem + ((row * CPR + (tc ^ (row & 7))) << 4));
       float v[4] = {t.x + bc.x, t.y + bc.y, t.z + bc.z, t.w + bc.w};
       if (p.bias_mode == VLFB_BIAS_ROW) {
-        const float b = p.bias[m];
+        const float b = p.bias[mo];
         v[0] += b; v[1] += b; v[2] += b; v[3] += b;
       }
       v[0] += rv[gp].x; v[1] += rv[gp].y; v[2] += rv[gp].z; v[3] += rv[gp].w;
@@ -142,7 +156,7 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
       }
       v[0] = mv[gp].x > 0.f ? v[0] : 0.f; v[1] = mv[gp].y > 0.f ? v[1] : 0.f;
       v[2] = mv[gp].z > 0.f ? v[2] : 0.f; v[3] = mv[gp].w > 0.f ? v[3] : 0.f;
-      const long long oidx = (long long)m * p.ldo + ncol;
+      const long long oidx = mo * p.ldo + ncol;
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ob) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
       if (planes) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.OP) + oidx;
@@ -157,9 +171,10 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
 // =============================================================================================
 // NT: O[m][n] = sum_k X[m][k] * W[n][k];  X fp32 (gathered), W = NPL bf16 planes, O / R / Mask fp32
 // =============================================================================================
-template <int NPL, int BN, bool IDENT, bool DGRAD, bool PACKW, bool UT>
+template <int NPL, int BN, bool IDENT, bool DGRAD, bool PACKW, bool UT, bool S2 = false>
 __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
   static_assert(!UT || (!IDENT && !PACKW), "UT is for gathered, unpacked operands");
+  static_assert(!S2 || (UT && DGRAD), "S2 is the scalar-cursor DGRAD over the parity classes of a (1, 2, 2)-strided conv");
   typedef float T;
   constexpr int BM = 128, NTHR = 256, NWN = 2;
   constexpr int EPC = 4;                          // fp32 elements per 16-byte chunk of the activation operand
@@ -178,8 +193,24 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = xcd_remap(blockIdx.x, nwg);
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
   const int z = blockIdx.z;
+  // S2: DGRAD of a (1, 2, 2)-strided conv.  An input position only meets the taps of its own (h, w) parity, so the rows
+  // are enumerated class by class ((n, t, h / 2, w / 2) order inside a class, GP::s2_mq rows and s2_tpc tiles each) and a
+  // tile walks the nb x nc taps of its class -- 9 -> 4 / 2 / 2 / 1, 1 -> 1 / 0 / 0 / 0 -- as a unit-stride scalar cursor
+  // over the conv OUTPUT grid: position (h2, w2) of the class reads source (h2 + oh - ib, w2 + ow - ic).  A class
+  // without taps is an epilogue-only tile (zero accumulators: residual / mask pass through).
+  int s2_ph = 0, s2_pw = 0, s2_b0 = 0, s2_c0 = 0, s2_nb = 1, s2_nc = 1;
+  if constexpr (S2) {
+    const int cls = tile_m / p.s2_tpc;
+    m0 = (tile_m - cls * p.s2_tpc) * BM;
+    s2_ph = cls >> 1; s2_pw = cls & 1;
+    s2_b0 = (s2_ph + p.ph) & 1; s2_c0 = (s2_pw + p.pw) & 1;
+    s2_nb = p.kh > s2_b0 ? (p.kh - s2_b0 + 1) >> 1 : 0;
+    s2_nc = p.kw > s2_c0 ? (p.kw - s2_c0 + 1) >> 1 : 0;
+  }
+  const int mrows = S2 ? p.s2_mq : p.M;
 
   const char* Ab = p.A + (long long)z * p.a_bs * 4;
   const char* Bb = p.B + (long long)z * p.b_bs * 2;
@@ -197,12 +228,25 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int m = m0 + r0 + RPPS_A * i;
-    aok[i] = m < p.M;
-    if (!IDENT) arow[i] = decode_row(p, aok[i] ? m : 0);
+    aok[i] = m < mrows;
+    if constexpr (S2) {
+      const int w2n = p.Wr >> 1, h2n = p.Hr >> 1;
+      const int mm = aok[i] ? m : 0;
+      RowC& r = arow[i];
+      const int w2 = mm % w2n;
+      int q = mm / w2n;
+      const int h2 = q % h2n;
+      q /= h2n;
+      r.t = q % p.Tr + p.pt; r.n = q / p.Tr;
+      r.h = h2 + ((s2_ph + p.ph - s2_b0) >> 1);         // source coordinates at the class's first tap
+      r.w = w2 + ((s2_pw + p.pw - s2_c0) >> 1);
+    } else if (!IDENT) arow[i] = decode_row(p, aok[i] ? m : 0);
     if (UT) {
       RowC& r = arow[i];
-      if (!DGRAD) { r.t = r.t * p.st - p.pt; r.h = r.h * p.sh - p.ph; r.w = r.w * p.sw - p.pw; }
-      else { r.t += p.pt; r.h += p.ph; r.w += p.pw; }
+      if constexpr (!S2) {
+        if (!DGRAD) { r.t = r.t * p.st - p.pt; r.h = r.h * p.sh - p.ph; r.w = r.w * p.sw - p.pw; }
+        else { r.t += p.pt; r.h += p.ph; r.w += p.pw; }
+      }
       upix[i] = ((r.n * p.Ts + r.t) * p.Hs + r.h) * p.Ws + r.w;
     }
   }
@@ -223,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
   const unsigned plane_bytes = (unsigned)p.b_ps * 2u;
   int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;       // UT: scalar tap cursor of the next tile to fetch
 
-  const int ktiles = (p.K + 31) >> 5;
+  const int ktiles = S2 ? p.kt * s2_nb * s2_nc * (p.Cs >> 5) : (p.K + 31) >> 5;
 
   // The DMA of a k-tile is split into its address phase (prep_tile: per-lane offsets of the ND pieces, tap cursor)
   // and ND issue slots (issue_piece) that the k-loop places between MFMAs.
@@ -236,6 +280,8 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
     else tap = decode_tap<T, PACKW>(p, kc);
     const bool kok = kc * EPC < p.K;
     const unsigned kbyte = (unsigned)kt * 128u;
+    int ktb = kt;                                  // k-tile of the weight rows (S2: the cursor's tap in the full tap order)
+    if constexpr (S2) ktb = ((u_a * p.kh + s2_b0 + 2 * u_b) * p.kw + s2_c0 + 2 * u_c) * (p.Cs >> 5) + (u_ci >> 5);
     if (UT) {
       const int sgn = DGRAD ? -1 : 1;
       const int da = sgn * u_a * p.dt, db = sgn * u_b * p.dh, dc = sgn * u_c * p.dw;
@@ -252,10 +298,10 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
       const int w0 = u_ci >= p.Cs;
       u_ci = w0 ? 0 : u_ci;
       u_c += w0;
-      const int w1 = u_c == p.kw;
+      const int w1 = u_c == (S2 ? s2_nc : p.kw);
       u_c = w1 ? 0 : u_c;
       u_b += w1;
-      const int w2 = u_b == p.kh;
+      const int w2 = u_b == (S2 ? s2_nb : p.kh);
       u_b = w2 ? 0 : u_b;
       u_a += w2;
     } else if (IDENT) {
@@ -282,13 +328,13 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
       }
     }
     // weight planes: 32 k = 64 bytes per row and plane
-    const bool kokb = (kt * 4 + cbg) * 8 < p.K;
+    const bool kokb = (ktb * 4 + cbg) * 8 < p.K;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int i = 0; i < B_ITP; ++i) {
         dvo[A_IT + pl * B_ITP + i] = kokb ? boff[i] : kOOB;
-        dso[A_IT + pl * B_ITP + i] = (unsigned)kt * 64u + (unsigned)pl * plane_bytes;
+        dso[A_IT + pl * B_ITP + i] = (unsigned)ktb * 64u + (unsigned)pl * plane_bytes;
       }
   };
   // past the last tile the fetch still runs (one basic block, see the k-loop) but through descriptors of ZERO
@@ -385,7 +431,7 @@ __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
   }
   __syncthreads();
 
-  nt_epilogue<BN, FN, FM>(p, acc, smem, m0, n0, z, tid, wm, wn, l15, g);
+  nt_epilogue<BN, FN, FM, S2>(p, acc, smem, m0, n0, z, tid, wm, wn, l15, g, s2_ph, s2_pw);
 }
 
 // =============================================================================================
@@ -790,8 +836,13 @@ int launch_nt_sp_shape(const GP& gp, int kind, bool ut, dim3 grid, size_t lds, h
     case 0: return launch_sp(gemm_nt_sp_kernel<NPL, BN, true, false, false, false>, grid, lds, gp, s);
     case 1: return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, true>, grid, lds, gp, s)
                       : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, false>, grid, lds, gp, s);
-    case 2: return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true>, grid, lds, gp, s)
-                      : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, false>, grid, lds, gp, s);
+    case 2:
+      if constexpr (NPL == 2) {
+        if (gp.s2) return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true, true>, grid, lds, gp, s);
+      }
+      if (gp.s2) return set_error(VLFB_ERR_UNSUPPORTED, "conv: class-major strided DGRAD exists for three-term products only");
+      return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true>, grid, lds, gp, s)
+                : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, false>, grid, lds, gp, s);
     default: return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, true, false>, grid, lds, gp, s);
   }
 }
