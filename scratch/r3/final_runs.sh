@@ -19,6 +19,7 @@ python bench.py $B --workload charades_r50_lfb_nl --set MODEL.FREEZE_BACKBONE Fa
 python bench.py $B --workload ava_r101_lfb_nl_3l --frames 64 --steps 30 > $O/bench_c5_bf16.json 2>/dev/null
 python bench.py $B --workload ava_r101_lfb_nl_3l --frames 64 --steps 30 --dtype fp16 > $O/bench_c5_fp16.json 2>/dev/null
 python bench.py $B --workload ava_r101_lfb_nl_3l --frames 64 --steps 8 --dtype split > $O/bench_c5_split.json 2>/dev/null
+VLFB_SPLIT_MATH=6,3 python bench.py $B --dtype split --steps 20 > $O/bench_c4_split_x6_forward.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-line --no-split-line > $R/$O/prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/$O/prof_split -o stats -- python $R/bench.py --dtype split --steps 10 --warmup 2 --no-cpu-baseline > $R/$O/prof_split.log 2>&1

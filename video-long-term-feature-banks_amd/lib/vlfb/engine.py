@@ -347,8 +347,7 @@ class ConvStep(Step):
         if self.d_w is not None or (self.cbname and eng.is_trainable(self.cbname)):
             # weight / bias gradients are leaves of the backward graph: they run on the side stream
             # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
-            with eng.on_side_stream():
-                self._param_grads(g, gp)
+            eng.issue_param_grads(lambda: self._param_grads(g, gp))
         if self.d_d is not None:
             # the gradient operand as planes when it has them and this launch can take them (plain rows or taps that
             # span whole k-tiles at unit stride); the input gradient's planes when this is its last contribution
@@ -1339,6 +1338,8 @@ class Engine(object):
         self._graph_stream = None
         self._eager_steps = 0
         self._trace = None             # recorded step (STEP_TRACE)
+        self._wq = []                  # parameter-gradient launches waiting for their lag (WGRAD_LAG)
+        self._bwd_index = 0
         self._trace_key = None
         model.engine = self
 
@@ -1381,6 +1382,27 @@ class Engine(object):
 
     def on_side_stream(self):
         return Engine._Side(self)
+
+    # Parameter gradients are leaves of the backward graph: when they run does not matter as long as it is after their
+    # output gradient exists (event) and before the all-reduce / solver.  WGRAD_LAG = k issues the parameter gradients of
+    # backward step i only after the dgrad chain has advanced to step i + k, so that the (MFMA-bound) res5 / res4 wgrads run
+    # beside the (HBM-bound) dgrads of the stages below instead of beside their own stage's dgrads.  0: issue at once.
+    WGRAD_LAG = 0
+
+    def issue_param_grads(self, fn):
+        if self.side is None or not self.WGRAD_LAG or self.comm is not None or self._eager_lr is not None:
+            with self.on_side_stream():
+                fn()
+            return
+        self._wq.append((self._bwd_index, self.record_event(), fn))
+
+    def _flush_param_grads(self, upto):
+        while self._wq and self._wq[0][0] <= upto:
+            _, ev, fn = self._wq.pop(0)
+            self.wait_event(self.side, ev)
+            with torch.cuda.stream(self.side):
+                fn()
+            self.side_dirty = True
 
     # stream-ordering primitives of a step: like the kernel launches (hip.call) they append themselves to hip.TRACE
     # while a step is being recorded, so that a replay re-issues the same edges between the same streams
@@ -1928,7 +1950,9 @@ class Engine(object):
         self._eager_next = 0
         buckets = self.sol_buckets
         for i, st in enumerate(self.bwd_steps):
+            self._bwd_index = i
             st.bwd()
+            self._flush_param_grads(i - self.WGRAD_LAG)
             if (self.comm is not None and self.comm.due(i)) or \
                     (eager and self._eager_next < len(buckets) and buckets[self._eager_next]["ready"] <= i and
                      (self.EAGER_SOLVER != "tail" or i >= len(self.bwd_steps) - 2)):
@@ -1936,6 +1960,7 @@ class Engine(object):
         if eager and self._eager_next < len(buckets):
             self._bucket_ready(1 << 60)
         self._eager_done = eager
+        self._flush_param_grads(1 << 60)
         self.join_side_stream()
 
     def _bucket_ready(self, i):
@@ -2166,7 +2191,7 @@ class Engine(object):
         if self._operand_version != self._pstate[0]:
             self.refresh_operands(all_params=True)
         key = (torch.cuda.current_stream().cuda_stream, self.side is None, self.EAGER_SOLVER, self.FORWARD_BRANCHES,
-               self.BUCKET_HANDOFF)
+               self.BUCKET_HANDOFF, self.WGRAD_LAG)
         self._store_step_scalars()
         if self._trace is None or self._trace_key != key:
             self._trace, self._trace_key = None, None
