@@ -154,6 +154,16 @@ typedef struct vlfb_conv_desc {
 void vlfb_conv_desc_init(vlfb_conv_desc* d);
 /* bytes of fp32 workspace vlfb_conv_run needs for this desc (0 unless a split WGRAD) */
 int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d);
+
+/* One scratch query for every entry point that takes caller-owned scratch (the caller owns every
+ * buffer, the library never allocates).  `arg` is the op's descriptor or dimension list; returns bytes, < 0 on error.
+ *   VLFB_WS_CONV           arg = const vlfb_conv_desc*            `workspace` of vlfb_conv_run (= vlfb_conv_workspace_bytes)
+ *   VLFB_WS_MAXPOOL_ARGMAX arg = const vlfb_pool_desc*            the whole `argmax` tensor of vlfb_maxpool_fwd / _bwd
+ *   VLFB_WS_FBO_ATTN_BWD   arg = const int64_t[2] {r, k}          `ds_ws` of vlfb_fbo_attn_bwd (r RoIs x k bank rows, fp32)
+ *   VLFB_WS_ATTN_SCORES    arg = const int64_t[3] {b, l1, l2}     fp32 score matrix between the scores GEMM and
+ *                                                                vlfb_softmax_fwd / _bwd when the fused kernels are not used */
+enum { VLFB_WS_CONV = 0, VLFB_WS_MAXPOOL_ARGMAX = 1, VLFB_WS_FBO_ATTN_BWD = 2, VLFB_WS_ATTN_SCORES = 3 };
+int64_t vlfb_query_workspace(int op, const void* arg);
 /* A: activation / gradient operand; B: weight operand (FPROP/DGRAD) or unused (WGRAD);
  * P: WGRAD output-gradient operand; O: output; bias/rowscale: fp32 vectors or NULL;
  * R, Mask: optional, dtype elements. */

@@ -50,5 +50,13 @@ def test_host_side_argument_checks_need_no_gpu():
     d = hip.conv_desc(mode=hip.WGRAD, dtype=hip.BF16, out_dtype=hip.F32, N=1, Tr=4, Hr=8, Wr=8, Ts=4, Hs=8,
                       Ws=8, Cs=64, Cn=64, kh=3, kw=3, ph=1, pw=1, splits=4)
     assert hip.conv_workspace_bytes(d) == 4 * 64 * 9 * 64 * 4
+    # one query for every caller-owned scratch buffer (vlfb_query_workspace)
+    assert hip.query_workspace(hip.WS_CONV, d) == hip.conv_workspace_bytes(d)
+    pd = hip.pool_desc(hip.BF16, 2, 4, 16, 16, 64, 4, 8, 8, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    assert hip.query_workspace(hip.WS_MAXPOOL_ARGMAX, pd) == 2 * 4 * 8 * 8 * 64 * hip.lib().vlfb_pool_argmax_bytes(pd)
+    assert hip.query_workspace(hip.WS_FBO_ATTN_BWD, (33, 60)) == 33 * 60 * 4
+    assert hip.query_workspace(hip.WS_ATTN_SCORES, (8, 3136, 784)) == 8 * 3136 * 784 * 4
+    with pytest.raises(hip.VlfbError, match="unknown op"):
+        hip.query_workspace(17, (1,))
     assert hip.lib().vlfb_dtype_size(hip.BF16) == 2 and hip.lib().vlfb_dtype_size(hip.F32) == 4
     assert hip.conv_flops(d) == 2.0 * 4 * 8 * 8 * 64 * 9 * 64

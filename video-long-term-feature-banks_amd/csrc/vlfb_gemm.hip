@@ -1648,6 +1648,30 @@ extern "C" int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d) {
   return pl.ws_elems * 4;
 }
 
+extern "C" int64_t vlfb_query_workspace(int op, const void* arg) {
+  if (!arg) { set_error(VLFB_ERR_ARG, "query_workspace: arg is required"); return -1; }
+  switch (op) {
+    case VLFB_WS_CONV: return vlfb_conv_workspace_bytes(static_cast<const vlfb_conv_desc*>(arg));
+    case VLFB_WS_MAXPOOL_ARGMAX: {
+      const vlfb_pool_desc* d = static_cast<const vlfb_pool_desc*>(arg);
+      const int es = vlfb_pool_argmax_bytes(d);
+      if (es <= 0) return -1;
+      return (int64_t)d->N * d->To * d->Ho * d->Wo * d->C * es;
+    }
+    case VLFB_WS_FBO_ATTN_BWD: {
+      const int64_t* v = static_cast<const int64_t*>(arg);
+      if (v[0] <= 0 || v[1] <= 0) { set_error(VLFB_ERR_ARG, "query_workspace: r, k must be positive"); return -1; }
+      return v[0] * v[1] * 4;
+    }
+    case VLFB_WS_ATTN_SCORES: {
+      const int64_t* v = static_cast<const int64_t*>(arg);
+      if (v[0] <= 0 || v[1] <= 0 || v[2] <= 0) { set_error(VLFB_ERR_ARG, "query_workspace: b, l1, l2 must be positive"); return -1; }
+      return v[0] * v[1] * v[2] * 4;
+    }
+    default: set_error(VLFB_ERR_ARG, "query_workspace: unknown op %d", op); return -1;
+  }
+}
+
 extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
                              void* O, const float* bias, const float* rowscale, const void* R,
                              const void* Mask, void* workspace, int64_t workspace_bytes,

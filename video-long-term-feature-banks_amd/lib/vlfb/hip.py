@@ -92,6 +92,7 @@ _SIGS = {
     "vlfb_affine_nd_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "vlfb_conv_desc_init": (None, [C.POINTER(ConvDesc)]),
     "vlfb_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
+    "vlfb_query_workspace": (_I64, [C.c_int, C.c_void_p]),
     "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_conv_run_planes": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
@@ -226,6 +227,19 @@ def conv_workspace_bytes(d):
     n = lib().vlfb_conv_workspace_bytes(C.byref(d))
     if n < 0:
         raise VlfbError("conv_workspace_bytes: %s" % lib().vlfb_last_error().decode())
+    return n
+
+
+WS_CONV, WS_MAXPOOL_ARGMAX, WS_FBO_ATTN_BWD, WS_ATTN_SCORES = 0, 1, 2, 3
+
+
+def query_workspace(op, arg):
+    """bytes of caller-owned scratch for an entry point: arg = a ConvDesc / PoolDesc or a tuple of dimensions"""
+    if isinstance(arg, (tuple, list)):
+        arg = (C.c_int64 * len(arg))(*arg)
+    n = lib().vlfb_query_workspace(op, C.cast(C.pointer(arg) if not isinstance(arg, C.Array) else arg, C.c_void_p))
+    if n < 0:
+        raise VlfbError("query_workspace: %s" % lib().vlfb_last_error().decode())
     return n
 
 
