@@ -161,8 +161,9 @@ int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d);
  *   VLFB_WS_MAXPOOL_ARGMAX arg = const vlfb_pool_desc*            the whole `argmax` tensor of vlfb_maxpool_fwd / _bwd
  *   VLFB_WS_FBO_ATTN_BWD   arg = const int64_t[2] {r, k}          `ds_ws` of vlfb_fbo_attn_bwd (r RoIs x k bank rows, fp32)
  *   VLFB_WS_ATTN_SCORES    arg = const int64_t[3] {b, l1, l2}     fp32 score matrix between the scores GEMM and
- *                                                                vlfb_softmax_fwd / _bwd when the fused kernels are not used */
-enum { VLFB_WS_CONV = 0, VLFB_WS_MAXPOOL_ARGMAX = 1, VLFB_WS_FBO_ATTN_BWD = 2, VLFB_WS_ATTN_SCORES = 3 };
+ *                                                                vlfb_softmax_fwd / _bwd when the fused kernels are not used
+ *   VLFB_WS_BN             arg = const int64_t[3] {dtype, rows, C} `workspace` of vlfb_bn_fwd / _bwd (= vlfb_bn_workspace_bytes) */
+enum { VLFB_WS_CONV = 0, VLFB_WS_MAXPOOL_ARGMAX = 1, VLFB_WS_FBO_ATTN_BWD = 2, VLFB_WS_ATTN_SCORES = 3, VLFB_WS_BN = 4 };
 int64_t vlfb_query_workspace(int op, const void* arg);
 /* A: activation / gradient operand; B: weight operand (FPROP/DGRAD) or unused (WGRAD);
  * P: WGRAD output-gradient operand; O: output; bias/rowscale: fp32 vectors or NULL;
@@ -300,6 +301,30 @@ int vlfb_relu_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n,
  * (nonlocal_helper.py:36-77, lfb_helper.py:175-200, resnet_video.py:327) */
 int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out,
                 int accumulate, vlfb_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * SpatialBN over channels-last rows x[rows][C] -- the graphs built with MODEL.USE_AFFINE False / NONLOCAL.USE_BN True
+ * (model_builder_video.py:176-197 Conv3dBN, resnet_video.py:185-188, nonlocal_helper.py:146-155).  The operator is
+ * Caffe2's spatial_batch_norm_op (a dependency, not in the reference tree); its algorithm:
+ *   train (is_test = 0): mu / var = biased row moments; y = (x - mu) / sqrt(var + eps) * gamma + beta;
+ *          running_mean = momentum * running_mean + (1 - momentum) * mu,
+ *          running_var  = momentum * running_var  + (1 - momentum) * var * rows / (rows - 1);
+ *          save_mean / save_inv_std [C] are kept for the backward pass
+ *   test  (is_test = 1): y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta; nothing else is written
+ *   bwd:   dbeta = sum dy, dgamma = sum dy * xhat (each times grad_scale; either may be NULL),
+ *          dx = gamma * inv_std * (dy - dbeta / rows - xhat * dgamma / rows)   (NULL: parameter gradients only)
+ * Per-GPU statistics, as in the reference's data-parallel model.  Reductions are two-stage and ordered (no atomics).
+ * x may alias y, dy may alias dx.  workspace: vlfb_bn_workspace_bytes (fp32 slab partials + coefficient rows).
+ * ------------------------------------------------------------------------------------------ */
+int64_t vlfb_bn_workspace_bytes(int dtype, int64_t rows, int64_t C);
+int vlfb_bn_fwd(const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, float* save_mean, float* save_inv_std, void* workspace,
+                int64_t workspace_bytes, int dtype, int64_t rows, int64_t C, float eps, float momentum,
+                int is_test, vlfb_stream_t stream);
+int vlfb_bn_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean,
+                const float* save_inv_std, void* dx, float* dgamma, float* dbeta, void* workspace,
+                int64_t workspace_bytes, int dtype, int64_t rows, int64_t C, float grad_scale,
+                vlfb_stream_t stream);
+
 /* LayerNorm over each row, no learnable scale/bias, eps inside sqrt (lfb_helper.py:160-166,
  * 252-256; Caffe2 LayerNorm axis=1).  rstd[r] = 1/sqrt(var+eps) saved for backward. */
 int vlfb_layernorm_fwd(const void* x, void* y, float* rstd, int dtype, int64_t rows, int64_t cols,

@@ -45,7 +45,6 @@ def batch_per_gpu(cfg, split):
 def param_spec(cfg, lfb_infer_only=False):
     """OrderedDict name -> dict(shape, kind, fan_out, std, trainable)."""
     spec = OrderedDict()
-    assert cfg.MODEL.USE_AFFINE, "only the shipped USE_AFFINE=True graphs are restated"
 
     def conv(name, cout, cin, k, bias, kind, std=None):
         spec[name + "_w"] = dict(shape=(cout, cin) + tuple(k), kind=kind, std=std, trainable=True)
@@ -56,9 +55,17 @@ def param_spec(cfg, lfb_infer_only=False):
         spec[name + "_s"] = dict(shape=(c,), kind="affine_s", trainable=False)
         spec[name + "_b"] = dict(shape=(c,), kind="affine_b", trainable=False)
 
+    def bn(name, c):
+        """CNNModelHelper.SpatialBN: scale / bias trained, running statistics computed (not parameters of the solver)"""
+        spec[name + "_s"] = dict(shape=(c,), kind="bn_s", trainable=True)
+        spec[name + "_b"] = dict(shape=(c,), kind="bn_b", trainable=True)
+        spec[name + "_rm"] = dict(shape=(c,), kind="bn_rm", trainable=False)
+        spec[name + "_riv"] = dict(shape=(c,), kind="bn_riv", trainable=False)
+
     def conv_affine(prefix, cout, cin, k):
+        """Conv3dAffine, or Conv3dBN when MODEL.USE_AFFINE is off (resnet_helper.py:28-32)"""
         conv(prefix, cout, cin, k, False, "msra")
-        affine(prefix + "_bn", cout)
+        (affine if cfg.MODEL.USE_AFFINE else bn)(prefix + "_bn", cout)
 
     def nonlocal_block(prefix, c, ci):
         std = cfg.NONLOCAL.CONV_INIT_STD
@@ -67,13 +74,13 @@ def param_spec(cfg, lfb_infer_only=False):
         conv(prefix + "_phi", ci, c, (1, 1, 1), has_b, "gauss", std)
         conv(prefix + "_g", ci, c, (1, 1, 1), has_b, "gauss", std)
         conv(prefix + "_out", c, ci, (1, 1, 1), has_b, "nl_out", std)
-        assert cfg.NONLOCAL.USE_AFFINE and not cfg.NONLOCAL.USE_BN
-        affine(prefix + "_bn", c)
+        assert bool(cfg.NONLOCAL.USE_AFFINE) != bool(cfg.NONLOCAL.USE_BN), "one of NONLOCAL.USE_BN / USE_AFFINE"
+        (bn if cfg.NONLOCAL.USE_BN else affine)(prefix + "_bn", c)
 
     arc = temporal_arc(cfg)
     n1, n2, n3, n4 = BLOCK_CONFIG[cfg.MODEL.DEPTH]
     conv("conv1", 64, 3, (1 + 2 * arc[0][0], 7, 7), False, "msra")
-    affine("res_conv1_bn", 64)
+    (affine if cfg.MODEL.USE_AFFINE else bn)("res_conv1_bn", 64)
     w = cfg.RESNETS.NUM_GROUPS * cfg.RESNETS.WIDTH_PER_GROUP
     mod3 = cfg.NONLOCAL.LAYER_MOD
     if cfg.MODEL.DEPTH == 101:
@@ -155,8 +162,16 @@ def synth_params(cfg, seed=2, lfb_infer_only=False):
                 v = gen.uniform(0.15, 0.35, shape)
             else:
                 v = gen.uniform(0.5, 1.5, shape)
-        elif kind == "affine_b":
+        elif kind in ("affine_b", "bn_b"):
             v = gen.standard_normal(shape) * 0.1
+        elif kind == "bn_s":
+            # normalised activations: O(1) gains, small ones at the residual-branch exits (BN_INIT_GAMMA = 0 grown a little)
+            small = "_branch2c_bn" in name or name.startswith("nonlocal")
+            v = gen.uniform(0.15, 0.35, shape) if small else gen.uniform(0.5, 1.5, shape)
+        elif kind == "bn_rm":
+            v = gen.standard_normal(shape) * 0.1
+        elif kind == "bn_riv":
+            v = gen.uniform(0.5, 1.5, shape)
         else:
             raise ValueError(kind)
         out[name] = v.astype(np.float32)
@@ -269,14 +284,46 @@ def _affine(x, P, prefix):
     return x * P[prefix + "_s"].view(shp) + P[prefix + "_b"].view(shp)
 
 
+def _bn(cx, x, prefix, eps, momentum):
+    """SpatialBN (Caffe2 spatial_batch_norm_op, a dependency outside the reference tree; call sites
+    model_builder_video.py:186-190, resnet_video.py:185-188, nonlocal_helper.py:147-151).  Train nets normalise by the
+    biased moments of the batch THIS GPU holds and move the running statistics (unbiased variance), test / val nets use
+    the running statistics.  The new running statistics go to cx.B as `<prefix>_rm` / `<prefix>_riv`."""
+    P = cx.P
+    shp = (1, -1) + (1,) * (x.dim() - 2)
+    s, b, rm, rv = (P[prefix + k] for k in ("_s", "_b", "_rm", "_riv"))
+    if cx.test:
+        return (x - rm.view(shp)) / torch.sqrt(rv.view(shp) + eps) * s.view(shp) + b.view(shp)
+    dims = [0] + list(range(2, x.dim()))
+    n = x.numel() // x.shape[1]
+    mu = x.mean(dims)
+    var = ((x - mu.view(shp)) ** 2).mean(dims)
+    with torch.no_grad():
+        cx.B[prefix + "_rm"] = momentum * rm + (1.0 - momentum) * mu
+        cx.B[prefix + "_riv"] = momentum * rv + (1.0 - momentum) * var * (n / max(n - 1, 1))
+    return (x - mu.view(shp)) / torch.sqrt(var.view(shp) + eps) * s.view(shp) + b.view(shp)
+
+
+def _norm(cx, x, prefix, nonlocal_block=False):
+    """the layer after a conv: AffineNd (frozen BN, every shipped config) or SpatialBN"""
+    cfg = cx.cfg
+    if nonlocal_block:
+        if cfg.NONLOCAL.USE_BN:
+            return _bn(cx, x, prefix, cfg.NONLOCAL.BN_EPSILON, cfg.NONLOCAL.BN_MOMENTUM)
+        return _affine(x, cx.P, prefix)
+    if cfg.MODEL.USE_AFFINE:
+        return _affine(x, cx.P, prefix)
+    return _bn(cx, x, prefix, cfg.MODEL.BN_EPSILON, cfg.MODEL.BN_MOMENTUM)
+
+
 def _conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
     """ConvNd, NCTHW cross-correlation; bias iff `<name>_b` exists"""
     return F.conv3d(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil)
 
 
 def _conv_affine(cx, x, prefix, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
-    """ModelBuilder.Conv3dAffine (lib/models/model_builder_video.py:200-221)"""
-    return _affine(_conv(x, cx.P, prefix, stride, pad, dil), cx.P, prefix + "_bn")
+    """ModelBuilder.Conv3dAffine / Conv3dBN (lib/models/model_builder_video.py:176-221)"""
+    return _norm(cx, _conv(x, cx.P, prefix, stride, pad, dil), prefix + "_bn")
 
 
 def _bottleneck(cx, x, prefix, dim_in, dim_out, stride, utc, dilation):
@@ -313,7 +360,7 @@ def _spacetime_nonlocal(cx, x, prefix, dim_inner):
     cx.B[prefix + "_affinity_prob"] = p
     t = torch.bmm(g, p.transpose(1, 2)).reshape(shp5)               # BatchMatMul(trans_b=1)
     out = _conv(t, P, prefix + "_out")
-    return _affine(out, P, prefix + "_bn")
+    return _norm(cx, out, prefix + "_bn", nonlocal_block=True)
 
 
 def _add_nonlocal(cx, x, prefix, dim_inner, group_size=None, pool_stride=None):
@@ -443,7 +490,7 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
     pool_stride = int(frames / 2)
     utc1 = arc[0][0]
     x = F.conv3d(x, params["conv1_w"], None, (1, 2, 2), (utc1, 3, 3))
-    x = _relu(cx, _affine(x, params, "res_conv1_bn"), "res_conv1_bn")
+    x = _relu(cx, _norm(cx, x, "res_conv1_bn"), "res_conv1_bn")
     B["res_conv1_bn"] = x
     x = _max_pool(cx, x, "pool1", (1, 3, 3), (1, 2, 2), (0, 1, 1))
     B["pool1"] = x
@@ -470,7 +517,8 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
     x = stage(x, "res2", n1, 64, 256, 1, arc[1], 1, 1000, None, False)
     x = _max_pool(cx, x, "pool2", (2, 1, 1), (2, 1, 1))
     B["pool2"] = x
-    x = stage(x, "res3", n2, 256, 512, 2, arc[2], 1, mod3, "nonlocal_conv3", True)  # USE_AFFINE branch: grouped
+    # res3 non-local blocks are grouped only when BN is frozen (resnet_video.py:248-272)
+    x = stage(x, "res3", n2, 256, 512, 2, arc[2], 1, mod3, "nonlocal_conv3", bool(cfg.MODEL.USE_AFFINE))
     x = stage(x, "res4", n3, 512, 1024, 2, arc[3], 1, mod4, "nonlocal_conv4", False)
     dil5 = 2 if cfg.MODEL.DILATIONS_AFTER_CONV5 else 1
     x = stage(x, "res5", n4, 1024, 2048, 1, arc[4], dil5, 1000, None, False)

@@ -103,10 +103,27 @@ def test_test_split_and_lfb_inference_plans():
 def test_unsupported_graphs_fail_loudly():
     from vlfb.presets import load_preset
     from models.model_builder_video import ModelBuilder
-    load_preset("charades_r50_baseline", ["MODEL.USE_AFFINE", "False"])
+    load_preset("charades_r50_baseline", ["NONLOCAL.USE_SOFTMAX", "False"])
     m = ModelBuilder(train=True, split="train", name="t")
     with pytest.raises(NotImplementedError):
         m.build_model(suffix="_train")
+
+
+def test_spatial_bn_graph_lowers_to_bn_steps():
+    """MODEL.USE_AFFINE False / NONLOCAL.USE_BN True (Conv3dBN, model_builder_video.py:176-197): one BNStep per conv of the
+    backbone and per non-local block, scale / bias trainable, running statistics computed parameters outside the solver's
+    bucket; res3 non-local blocks are not grouped in this graph (resnet_video.py:248-272)"""
+    ov = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64,
+          "MODEL.USE_AFFINE", False, "NONLOCAL.USE_BN", True, "NONLOCAL.USE_AFFINE", False]
+    cfg, m, eng = plan("ava_r50_lfb_nl", ov)
+    k = kinds(eng)
+    assert k["BNStep"] == 1 + 16 * 3 + 4 + 5
+    assert len(m.computed_params) == 2 * k["BNStep"] and not set(m.computed_params) & set(m.params)
+    assert all(n in eng.trainable for n in ("res_conv1_bn_s", "res_conv1_bn_b", "nonlocal_conv4_1_bn_s"))
+    assert "res_conv1_bn_rm" in eng.frozen_layout and "res_conv1_bn_riv" not in eng.train_layout
+    assert m.param_init_net.fills["nonlocal_conv3_1_bn_s"].kwargs["value"] == cfg.NONLOCAL.BN_INIT_GAMMA
+    cfg, m, eng = plan("ava_r50_lfb_nl", ov, split="test")
+    assert all(st.is_test for st in eng.steps if type(st).__name__ == "BNStep")
 
 
 def test_product_code_never_imports_the_oracle():

@@ -195,3 +195,37 @@ def test_oracle_evaluates_the_branches_it_is_given():
     flat[on[: max(1, len(on) // 50)]] = False
     b3, g3 = om.run(cfg, params, inputs, "train", torch.float64, True, lambda n: 5, decisions=dec)
     assert float((g3["conv1_w"] - grads["conv1_w"]).norm()) > 1e-6 * float(grads["conv1_w"].norm())
+
+
+def test_spatial_bn_graph_matches_torch_batch_norm_and_moves_the_running_statistics():
+    """MODEL.USE_AFFINE False / NONLOCAL.USE_BN True (the code's defaults; no shipped yaml uses them): the oracle's
+    SpatialBN restatement against torch.nn.functional.batch_norm on the stem, the parameter catalogue, and a backward
+    pass that reaches every scale / bias"""
+    import torch.nn.functional as F
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from oracle import model as om
+    load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 32,
+                                          "MODEL.USE_AFFINE", False, "NONLOCAL.USE_BN", True, "NONLOCAL.USE_AFFINE", False])
+    spec = om.param_spec(cfg)
+    assert spec["res_conv1_bn_s"]["trainable"] and spec["res_conv1_bn_b"]["trainable"]
+    assert not spec["res_conv1_bn_rm"]["trainable"] and not spec["nonlocal_conv4_1_bn_riv"]["trainable"]
+    params = om.synth_params(cfg, seed=3)
+    inputs = om.synth_inputs(cfg, 2, "train", seed=3, crop=32, frames=8)
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda name: 0)
+    x = F.conv3d(torch.from_numpy(inputs["data"]).double(), torch.from_numpy(params["conv1_w"]).double(), None, (1, 2, 2), (2, 3, 3))
+    rm, rv = (torch.from_numpy(params["res_conv1_bn_" + k]).double().clone() for k in ("rm", "riv"))
+    want = F.batch_norm(x, rm, rv, torch.from_numpy(params["res_conv1_bn_s"]).double(),
+                        torch.from_numpy(params["res_conv1_bn_b"]).double(), True, 1.0 - cfg.MODEL.BN_MOMENTUM, cfg.MODEL.BN_EPSILON)
+    assert torch.allclose(blobs["res_conv1_bn"], torch.relu(want), rtol=1e-10, atol=1e-12)
+    assert torch.allclose(blobs["res_conv1_bn_rm"], rm, rtol=1e-10, atol=1e-12)        # torch moved its copies in place
+    assert torch.allclose(blobs["res_conv1_bn_riv"], rv, rtol=1e-10, atol=1e-12)
+    bn = [k for k in spec if k.endswith(("_bn_s", "_bn_b"))]
+    assert len(bn) >= 100 and all(k in grads and float(grads[k].abs().sum()) > 0 for k in bn)
+    # test nets normalise by the running statistics
+    blobs_t, _ = om.run(cfg, params, inputs, "test", torch.float64, False, lambda name: 0)
+    shp = (1, -1, 1, 1, 1)
+    P = {k: torch.from_numpy(v).double() for k, v in params.items()}
+    want_t = (x - P["res_conv1_bn_rm"].view(shp)) / torch.sqrt(P["res_conv1_bn_riv"].view(shp) + cfg.MODEL.BN_EPSILON) * \
+        P["res_conv1_bn_s"].view(shp) + P["res_conv1_bn_b"].view(shp)
+    assert torch.allclose(blobs_t["res_conv1_bn"], torch.relu(want_t), rtol=1e-10, atol=1e-12)

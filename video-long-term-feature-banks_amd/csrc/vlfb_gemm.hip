@@ -1668,6 +1668,12 @@ extern "C" int64_t vlfb_query_workspace(int op, const void* arg) {
       if (v[0] <= 0 || v[1] <= 0 || v[2] <= 0) { set_error(VLFB_ERR_ARG, "query_workspace: b, l1, l2 must be positive"); return -1; }
       return v[0] * v[1] * v[2] * 4;
     }
+    case VLFB_WS_BN: {
+      const int64_t* v = static_cast<const int64_t*>(arg);
+      const int64_t n = vlfb_bn_workspace_bytes((int)v[0], v[1], v[2]);
+      if (n < 0) set_error(VLFB_ERR_ARG, "query_workspace: bad dtype / rows / C for SpatialBN");
+      return n;
+    }
     default: set_error(VLFB_ERR_ARG, "query_workspace: unknown op %d", op); return -1;
   }
 }

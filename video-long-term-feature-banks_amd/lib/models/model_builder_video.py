@@ -10,7 +10,7 @@ Differences that are deliberate (MI355X-first):
     FetchBlob match (reference :142-157).
   * Conv -> AffineNd -> ReLU -> Sum chains are fused at lowering time; the frozen affine scale is
     folded into the MFMA weight operand.
-  * SpatialBN graphs (USE_AFFINE False) are not part of the shipped configs and raise.
+  * SpatialBN graphs (USE_AFFINE False / NONLOCAL.USE_BN): per-GPU statistics, vlfb_bn_{fwd,bwd}.
 """
 import logging
 
@@ -122,13 +122,31 @@ class ModelBuilder(object):
                            dilations=dilations if dilations is not None else [1, 1, 1])
         return self.AffineNd(conv, prefix + suffix, dim_out, inplace=inplace_affine)
 
-    def Conv3dBN(self, *args, **kwargs):
-        raise NotImplementedError(
-            "SpatialBN graphs (MODEL.USE_AFFINE False) are not on the hot path: every shipped "
-            "config freezes BN into AffineNd")
+    def Conv3dBN(self, blob_in, prefix, dim_in, dim_out, kernels, strides, pads, group=1, bn_init=None,
+                 dilations=None, **kwargs):
+        """bias-free MSRA conv followed by SpatialBN (model_builder_video.py:176-197); bn_init != 1 re-fills the scale
+        (the zero-initialised last BN of a bottleneck, resnet_helper.py:70)"""
+        conv = self.ConvNd(blob_in, prefix, dim_in, dim_out, kernels, strides=strides, pads=pads,
+                           group=group, weight_init=("MSRAFill", {}),
+                           bias_init=("ConstantFill", {"value": 0.0}), no_bias=1,
+                           dilations=dilations if dilations is not None else [1, 1, 1])
+        out = self.SpatialBN(conv, prefix + "_bn", dim_out, epsilon=cfg.MODEL.BN_EPSILON,
+                             momentum=cfg.MODEL.BN_MOMENTUM, is_test=self.split in ["test", "val"])
+        if bn_init is not None and bn_init != 1.0:
+            self.param_init_net.ConstantFill([prefix + "_bn_s"], prefix + "_bn_s", value=bn_init)
+        return out
 
-    def SpatialBN(self, *args, **kwargs):
-        raise NotImplementedError("SpatialBN is not on the hot path (all configs use AffineNd)")
+    def SpatialBN(self, blob_in, blob_out, dim_in, epsilon=1e-5, momentum=0.9, is_test=False, **kwargs):
+        """CNNModelHelper.SpatialBN: scale `<name>_s` = 1 and bias `<name>_b` = 0 are trained, the running statistics
+        `<name>_rm` = 0 / `<name>_riv` = 1 are computed parameters (saved with the model, never handed to the solver)"""
+        s = self._new_param(blob_out + "_s", [dim_in], ("ConstantFill", {"value": 1.0}), True)
+        b = self._new_param(blob_out + "_b", [dim_in], ("ConstantFill", {"value": 0.0}), False)
+        rm, riv = blob_out + "_rm", blob_out + "_riv"
+        self.param_init_net.ConstantFill([], rm, shape=[dim_in], value=0.0)
+        self.param_init_net.ConstantFill([], riv, shape=[dim_in], value=1.0)
+        self.computed_params += [rm, riv]
+        return self.net.add("SpatialBN", [blob_in, s, b, rm, riv], [blob_out], epsilon=float(epsilon),
+                            momentum=float(momentum), is_test=int(bool(is_test)))
 
     def Relu(self, blob_in, blob_out, **kwargs):
         return self.net.add("Relu", [blob_in], [blob_out])

@@ -54,6 +54,7 @@ def spacetime_nonlocal(model, blob_in, dim_in, dim_out, batch_size, prefix, dim_
     if cfg.NONLOCAL.USE_BN:
         blob_out = model.SpatialBN(blob_out, prefix + "_bn", dim_out, epsilon=cfg.NONLOCAL.BN_EPSILON,
                                    momentum=cfg.NONLOCAL.BN_MOMENTUM, is_test=is_test)
+        model.param_init_net.ConstantFill([prefix + "_bn_s"], prefix + "_bn_s", value=cfg.NONLOCAL.BN_INIT_GAMMA)
     if cfg.NONLOCAL.USE_AFFINE is True:
         blob_out = model.AffineNd(blob_out, prefix + "_bn", dim_out)
     return blob_out

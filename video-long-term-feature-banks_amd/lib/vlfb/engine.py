@@ -622,6 +622,55 @@ class ReluStep(Step):
             self.x.root.slot.contribute_alias(self.out_grad())   # already masked by out > 0
 
 
+class BNStep(Step):
+    """SpatialBN (model_builder_video.py:186-190, resnet_video.py:185-188, nonlocal_helper.py:147-151): batch statistics of
+    THIS GPU's rows in a training net (and the running statistics updated), the running statistics in a test / val net.
+    vlfb_bn_fwd / vlfb_bn_bwd; scale and bias are trained, `_rm` / `_riv` are computed parameters."""
+
+    def __init__(self, eng, x, out, sname, bname, rmname, rvname, eps, momentum, is_test):
+        Step.__init__(self, eng)
+        self.x, self.out = x, out
+        self.sname, self.bname, self.rmname, self.rvname = sname, bname, rmname, rvname
+        self.eps, self.momentum, self.is_test = float(eps), float(momentum), int(bool(is_test))
+        self.inputs, self.outputs = [x], [out]
+
+    def name(self):
+        return "bn:" + self.out.name
+
+    def setup(self):
+        eng = self.eng
+        self.rows, self.C = self.x.rows, self.x.C
+        self.params = [n for n in (self.sname, self.bname) if eng.is_trainable(n)]
+        nbytes = hip.query_workspace(hip.WS_BN, (eng.code, self.rows, self.C))
+        self.ws = torch.empty(nbytes // 4, device=eng.device, dtype=torch.float32)
+        self.save = None if self.is_test else torch.empty(2 * self.C, device=eng.device, dtype=torch.float32)
+
+    def fwd(self):
+        eng = self.eng
+        P = eng.param_tensor
+        mean = hip.ptr(self.save) if self.save is not None else None
+        istd = hip.ptr(self.save) + 4 * self.C if self.save is not None else None
+        hip.call("vlfb_bn_fwd", self.x.ptr(), self.out.ptr(), hip.ptr(P(self.sname)), hip.ptr(P(self.bname)),
+                 hip.ptr(P(self.rmname)), hip.ptr(P(self.rvname)), mean, istd, hip.ptr(self.ws), self.ws.numel() * 4,
+                 eng.code, self.rows, self.C, self.eps, self.momentum, self.is_test)
+
+    def bwd(self):
+        eng = self.eng
+        assert self.save is not None, "backward through a test-mode SpatialBN"
+        g = self.out_grad()
+        dgamma = hip.ptr(eng.grad_tensor(self.sname)) if eng.is_trainable(self.sname) else None
+        dbeta = hip.ptr(eng.grad_tensor(self.bname)) if eng.is_trainable(self.bname) else None
+
+        def launch(out, add=None, mask=None):
+            hip.call("vlfb_bn_bwd", hip.ptr(g), self.x.ptr(), hip.ptr(eng.param_tensor(self.sname)), hip.ptr(self.save),
+                     hip.ptr(self.save) + 4 * self.C, hip.ptr(out), dgamma, dbeta, hip.ptr(self.ws), self.ws.numel() * 4,
+                     eng.code, self.rows, self.C, 1.0)
+        if self.grad_inputs():
+            self.x.root.slot.contribute(launch, supports_add=False, supports_mask=False)
+        elif dgamma is not None or dbeta is not None:
+            launch(None)
+
+
 class LayerNormStep(Step):
     def __init__(self, eng, x, out, eps):
         Step.__init__(self, eng)
@@ -1036,6 +1085,19 @@ class Lowering(object):
         out.relu = True
         out.needs_grad = x.needs_grad
         self.add_step(ReluStep(self.eng, x, out))
+        self.env[op.outputs[0]] = out
+        return i + 1
+
+    def lower_SpatialBN(self, i):
+        op, ins, outs = self.ssa[i]
+        x = self.get(op.inputs[0])
+        if x.caxis != 1:
+            raise NotImplementedError("SpatialBN input %s must be a channels-last blob" % x.name)
+        out = self.new_blob(op.outputs[0], x.shape, x.caxis)
+        out.needs_grad = True
+        a = op.args
+        self.add_step(BNStep(self.eng, x, out, op.inputs[1], op.inputs[2], op.inputs[3], op.inputs[4],
+                             a["epsilon"], a["momentum"], a["is_test"]))
         self.env[op.outputs[0]] = out
         return i + 1
 
@@ -1529,6 +1591,8 @@ class Engine(object):
                 names = [st.wname, st.cbname]
             elif isinstance(st, FCStep):
                 names = [st.wname, st.bname]
+            elif isinstance(st, BNStep):
+                names = [st.sname, st.bname]
             for n in names:
                 if n and self.is_trainable(n) and n not in seen:
                     seen.add(n)
@@ -1537,7 +1601,7 @@ class Engine(object):
         missing = [p for p in self.trainable if p not in seen]
         assert not missing, "trainable params without a producing step: %r" % missing
         self.train_order = order
-        frozen = [p for p in self.model.params if p not in seen]
+        frozen = [p for p in list(self.model.params) + list(self.model.computed_params) if p not in seen]
 
         def sizes(names):
             out, off = OrderedDict(), 0
@@ -1699,7 +1763,7 @@ class Engine(object):
         """run the recorded fillers (MSRAFill / GaussianFill / ConstantFill) deterministically"""
         gen = np.random.default_rng(self.base_seed if seed is None else seed)
         out = {}
-        for name in self.model.params:
+        for name in list(self.model.params) + list(self.model.computed_params):
             if name in getattr(self, "shared_params", ()):
                 continue                      # owned (and initialised / trained) by the engine we share with
             f = self.model.param_init_net.fills[name]

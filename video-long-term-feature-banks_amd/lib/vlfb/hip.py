@@ -120,6 +120,9 @@ _SIGS = {
     "vlfb_relu_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _P]),
     "vlfb_relu_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _P]),
     "vlfb_colsum": (C.c_int, [_P, C.c_int, _I64, _I64, _I64, _P, C.c_int, _P]),
+    "vlfb_bn_workspace_bytes": (_I64, [C.c_int, _I64, _I64]),
+    "vlfb_bn_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _I64, _I64, C.c_float, C.c_float, C.c_int, _P]),
+    "vlfb_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_layernorm_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _P]),
     "vlfb_dropout_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, _I64, C.c_float, C.c_uint64, _P]),
@@ -230,7 +233,7 @@ def conv_workspace_bytes(d):
     return n
 
 
-WS_CONV, WS_MAXPOOL_ARGMAX, WS_FBO_ATTN_BWD, WS_ATTN_SCORES = 0, 1, 2, 3
+WS_CONV, WS_MAXPOOL_ARGMAX, WS_FBO_ATTN_BWD, WS_ATTN_SCORES, WS_BN = 0, 1, 2, 3, 4
 
 
 def query_workspace(op, arg):

@@ -53,10 +53,16 @@ def params(model, seed=2):
     """{name: array in the reference layout} for every parameter of `model`"""
     gen = np.random.default_rng(seed)
     out = OrderedDict()
-    for name in model.params:
-        f = model.param_init_net.fills[name]
+    fills = model.param_init_net.fills
+    for name in list(model.params) + list(model.computed_params):
+        f = fills[name]
         shape = f.shape
-        if name in model.affine_params:
+        bn = name.rsplit("_", 1)[0] + "_riv" in fills        # scale / bias / running statistics of a SpatialBN
+        if bn and name.endswith("_rm"):
+            v = gen.standard_normal(shape) * 0.1
+        elif bn and name.endswith("_riv"):
+            v = gen.uniform(0.5, 1.5, shape)
+        elif name in model.affine_params or bn:
             if name.endswith("_s"):
                 small = "_branch2c_bn" in name or name.startswith("nonlocal")
                 v = gen.uniform(0.15, 0.35, shape) if small else gen.uniform(0.5, 1.5, shape)
