@@ -564,3 +564,38 @@ def test_roi_align_max_head(dtype):
     hip.call("vlfb_roi_align_max_bwd", gp(dout, dtype), code, gp(rois), hip.ptr(AB), hip.ptr(DF),
              N, H, W, Cc, R, 7, 1.0 / 16)
     assert rel_err(DF.permute(0, 3, 1, 2), gf) < 1e-5
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,Nc", [(33, 2048, 512), (33, 512, 512), (1, 512, 2048), (64, 1024, 520), (17, 128, 16)])
+def test_skinny_row_products_of_the_fbo_head(M, K, Nc, tdt):
+    """1x1x1 convs on a handful of rows (lfb_helper.py:170-263 on one row per RoI): the 16-column kernel whose waves split
+    K (csrc/vlfb_gemm_skinny.hip) -- FPROP with bias / residual / ReLU, DGRAD-shaped launches with a residual and a mask,
+    fp32 output -- against fp64 and against the 128 x 128 tile family (algo = TILE128) on the same operands"""
+    code = hip.dtype_code(tdt)
+    tol = {torch.bfloat16: 6e-3, torch.float16: 8e-4}[tdt]
+    gen = torch.Generator().manual_seed(M * 7 + K + Nc)
+    a = q(torch.randn(M, K, generator=gen), tdt)
+    w = q(torch.randn(Nc, K, generator=gen) / math.sqrt(K), tdt)
+    bias = torch.randn(Nc, generator=gen)
+    res = q(torch.randn(M, Nc, generator=gen), tdt)
+    msk = q(torch.randn(M, Nc, generator=gen), tdt)
+    A, Wd, R, Mk, Bs = gpu(a, tdt), gpu(w, tdt), gpu(res, tdt), gpu(msk, tdt), gpu(bias)
+    lin = a.double() @ w.double().t()
+    cases = [
+        (dict(relu=1, bias_mode=hip.BIAS_COL), dict(bias=Bs, R=R), tdt, torch.relu(lin + bias.double() + res.double())),
+        (dict(alpha=0.5), dict(R=R, mask=Mk), tdt, torch.where(msk.double() > 0, 0.5 * lin + res.double(), torch.zeros_like(lin))),
+        (dict(), dict(), torch.float32, lin),
+    ]
+    for dk, rk, odt, want in cases:
+        outs = []
+        for algo in (hip.ALGO_AUTO, hip.ALGO_TILE128):
+            O = torch.full((M, Nc), float("nan"), device=dev(), dtype=odt)
+            desc = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=hip.dtype_code(odt), N=1, Tr=1, Hr=1, Wr=M, Ts=1, Hs=1, Ws=M,
+                                 Cs=K, Cn=Nc, algo=algo, **dk)
+            hip.conv_run(desc, A, Wd, None, O, **rk)
+            torch.cuda.synchronize()
+            outs.append(O)
+        assert not torch.isnan(outs[0].float()).any()
+        assert rel_err(outs[0].float(), want) < (tol if odt != torch.float32 else 2e-6 * math.sqrt(K) + 1e-6)
+        assert rel_err(outs[0].float(), outs[1].float()) < (tol if odt != torch.float32 else 1e-5)

@@ -1119,6 +1119,7 @@ struct Plan {
   int stemf;      // FPROP of the packed stem: direct-convolution kernel (vlfb_stem.hip) when the call has no residual / mask
   int nts_mode;
   int sp;         // split-bf16 math (vlfb_gemm_split.hip): bf16 terms per operand (2 | 3), 0 = native MFMA of the dtype
+  int skinny;     // NT: at most 64 plain rows (vlfb_gemm_skinny.hip)
   int sp_kind;    //   NT: 0 plain rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem
   int sp_pl;      //   operands arrive as bf16 term planes (WGRAD: both; FPROP / DGRAD: the activation operand)
   size_t stem_lds;
@@ -1448,6 +1449,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->rows64 = d->mode != VLFB_CONV_WGRAD && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO &&
                (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
                conv_rows64_ok(g, d->mode, d->dtype, d->out_dtype, batch);
+  // a handful of plain rows (the FBO head on one row per RoI): 16-column workgroups whose waves split K
+  static const bool skinny_off = getenv("VLFB_SKINNY") && atoi(getenv("VLFB_SKINNY")) == 0;      // (A/B switch)
+  pl->skinny = d->mode != VLFB_CONV_WGRAD && d->algo == VLFB_ALGO_AUTO && !skinny_off && !pl->sp && !pl->rows64 &&
+               (d->out_dtype == d->dtype || d->out_dtype == VLFB_F32) && skinny_nt_ok(g, d->dtype, batch, pl->ident);
   pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
   pl->pre = 0;
   pl->threads = kThreads;
@@ -1588,6 +1593,7 @@ int dispatch(const vlfb_conv_desc* d, const Plan& pl, hipStream_t s) {
       else launch_tn_tr<T, OutT, false, false>(pl, s);
       return check_launch("conv wgrad (tr) kernel");
     }
+    if (d->mode != VLFB_CONV_WGRAD && pl.skinny) return launch_skinny_nt(pl.gp, d->dtype, sizeof(OutT) == 4, s);
     if (d->mode == VLFB_CONV_FPROP && pl.stemf && !pl.gp.R && !pl.gp.Mask) return launch_stem_fprop(pl.gp, d->dtype, s);
     if (d->mode != VLFB_CONV_WGRAD && pl.rows64) return launch_conv_rows64(pl.gp, d->mode, d->dtype, s);
     if (d->mode != VLFB_CONV_WGRAD && pl.nts) return launch_nts(pl.gp, pl.nts_mode, d->dtype, s);

@@ -67,6 +67,10 @@ int launch_wgrad_rows(const GP& gp, int splits, size_t lds, int dtype, hipStream
 // fat-input variant: 256 -> 64 channels, 3x1x1 (the gradient rows are shifted, the 512-byte input rows read once)
 int launch_wgrad_rows_fat(const GP& gp, int splits, int dtype, hipStream_t s);
 
+// vlfb_gemm_skinny.hip: plain-row NT products with at most 64 rows (the FBO head's 1x1x1 convs on one row per RoI)
+bool skinny_nt_ok(const GP& gp, int dtype, long long batch, bool ident);
+int launch_skinny_nt(const GP& gp, int dtype, bool out_f32, hipStream_t s);
+
 // vlfb_stem.hip: direct-convolution FPROP of the packed stem (whole output rows per wave, raw input rows in LDS)
 bool stem_fprop_ok(const GP& gp, int pack_w, int dtype, int out_dtype, long long batch);
 int launch_stem_fprop(const GP& gp, int dtype, hipStream_t s);
