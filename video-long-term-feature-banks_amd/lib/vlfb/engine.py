@@ -1555,6 +1555,8 @@ class Engine(object):
         """input_shapes: {blob name: shape in the REFERENCE layout} for data/labels/proposals/lfb."""
         if not self.dry_run:
             torch.cuda.set_device(self.device)
+        self._trace = self._graph = None       # a recorded / captured step belongs to the buffers of ONE plan
+        self._eager_steps = 0
         low = Lowering(self, self.model, OrderedDict(input_shapes))
         self.steps = low.run()
         self.env = low.env
