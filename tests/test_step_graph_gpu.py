@@ -160,11 +160,9 @@ def test_trace_is_recorded_again_on_another_stream_and_with_the_third_stream_sol
 @pytest.mark.parametrize("dtype", ["bf16", "split"])
 def test_parameter_gradient_placement_does_not_change_the_step(dtype):
     """Engine.WGRAD_LAG moves the parameter-gradient launches of a backward step behind later dgrads (or, at infinity, behind
-    the whole chain), Engine.SHARE_COLSUMS takes the column sums of a block's output gradient once for the two convs that
-    see it: the same kernels on the same operands, so parameters, momentum and losses stay bit-identical -- on the
-    step-object path and on the recorded one"""
+    the whole chain): the same kernels on the same operands, so parameters, momentum and losses stay bit-identical -- on
+    the step-object path and on the recorded one"""
     ref = _engine(False, dtype, name="lag0")
-    ref.SHARE_COLSUMS = False
     variants = []
     for lag, trace in ((3, False), (1 << 20, False), (7, True)):
         e = _engine(False, dtype, name="lag%d%d" % (lag, trace))

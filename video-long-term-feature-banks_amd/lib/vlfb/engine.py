@@ -387,15 +387,8 @@ class ConvStep(Step):
             Cout = self.out.shape[1]
             gb = eng.grad_tensor(self.cbname)
             if self.sname:
-                # the last conv of a bottleneck and the projection shortcut beside it see the SAME output gradient (the
-                # Sum passes it through): its column sums are taken once per backward pass (both launches are on the
-                # parameter-gradient stream, in order)
-                key = (hip.ptr(g), self.out.rows, Cout)
-                sums = eng._colsums.get(key) if eng.SHARE_COLSUMS else None
-                if sums is None:
-                    hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
-                    sums = eng._colsums[key] = self.cb_tmp
-                hip.call("vlfb_affine_nd_bwd", hip.ptr(sums), hip.ptr(eng.param_tensor(self.sname)),
+                hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
+                hip.call("vlfb_affine_nd_bwd", hip.ptr(self.cb_tmp), hip.ptr(eng.param_tensor(self.sname)),
                          hip.ptr(gb), 1, Cout, 1)
             else:
                 hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
@@ -1407,7 +1400,6 @@ class Engine(object):
         self._graph_stream = None
         self._eager_steps = 0
         self._trace = None             # recorded step (STEP_TRACE)
-        self._colsums = {}             # column sums of output gradients taken in this backward pass (ConvStep._param_grads)
         self._wq = []                  # parameter-gradient launches waiting for their lag (WGRAD_LAG)
         self._bwd_index = 0
         self._trace_key = None
@@ -1458,7 +1450,6 @@ class Engine(object):
     # backward step i only after the dgrad chain has advanced to step i + k, so that the (MFMA-bound) res5 / res4 wgrads run
     # beside the (HBM-bound) dgrads of the stages below instead of beside their own stage's dgrads.  0: issue at once.
     WGRAD_LAG = 0
-    SHARE_COLSUMS = True
 
     def issue_param_grads(self, fn):
         if self.side is None or not self.WGRAD_LAG or self.comm is not None or self._eager_lr is not None:
@@ -2021,7 +2012,6 @@ class Engine(object):
                 b.slot.reset()
         if self.comm is not None:
             self.comm.begin()
-        self._colsums = {}
         eager = self._eager_lr is not None
         self._eager_next = 0
         buckets = self.sol_buckets
