@@ -28,7 +28,7 @@ for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT)
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "split": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "split": 2500.0, "mix": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                           # HBM3E spec peak (same guide; ~6.3 TB/s measured copy)
 
 
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ava_r50_lfb_nl",
                     help="ava_r50_lfb_nl (metric config) | charades_r50_baseline | charades_r50_lfb_nl | ava_r101_lfb_nl_3l")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "split"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "split", "mix"])
     ap.add_argument("--clips-per-gpu", type=int, default=8)
     ap.add_argument("--rois-per-clip", type=int, default=0,
                     help="0 = SURVEY 8d C4 draw U{1..5} per clip (seeded per rank); N > 0 = exactly N per clip")

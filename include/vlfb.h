@@ -36,6 +36,15 @@ enum { VLFB_F32 = 0, VLFB_BF16 = 1, VLFB_F16 = 2 };
  * FPROP copy is THREE bf16 planes [3][Cout][taps][Cin] (h = bf16(w), m = bf16(w - h), l = bf16(w - h - m)), the DGRAD
  * copy TWO planes [2][Cin][taps][Cout] (h, m). */
 enum { VLFB_SPLIT = 3 };
+/* Weight-operand formats of the "mix" path (split-bf16 FORWARD products on fp32 storage, fp16 BACKWARD; accepted by
+ * vlfb_weight_prep* only): the FPROP copy as VLFB_SPLIT's three bf16 planes; the DGRAD copy
+ *   VLFB_MIX     plain fp16 [Cin][taps][Cout]
+ *   VLFB_MIX_W2  two fp16 terms of (w * s) * VLFB_MIX_W2_SCALE, [Cin][term][taps][Cout]: the weight of the same
+ *                convolution with a doubled OUTERMOST tap dimension of dilation 0 (vlfb_conv_desc: kt' = 2 kt... with
+ *                dt = 0; alpha carries 1 / VLFB_MIX_W2_SCALE), so that the plain fp16 DGRAD kernels contract the fp16
+ *                gradient with 22 significant bits of W: dX = dY . Wh + dY . Wl */
+enum { VLFB_MIX = 4, VLFB_MIX_W2 = 5 };
+#define VLFB_MIX_W2_SCALE 1024.0f
 /* vlfb_conv_desc.math: how the contraction is evaluated when dtype == VLFB_F32.
  *   VLFB_MATH_NATIVE  v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 vector rate)
  *   VLFB_MATH_BF16X6  operands expanded into three bf16 terms each, six bf16 MFMAs per product (hh hm mh mm hl lh):
@@ -144,8 +153,10 @@ typedef struct vlfb_conv_desc {
    * values (o_planes below) can be handed in pre-split -- the kernel then spends no VALU on the expansion:
    *   a_planes  0 = A is fp32; 2 (BF16X3) = A points at [plane][position][lda] bf16 planes, a_pstride elements apart
    *   p_planes  WGRAD only: the same for P (ldp); WGRAD takes both operands as planes or neither
-   *   o_planes  FPROP / DGRAD: additionally write the first o_planes (2) bf16 terms of every output value to the
-   *             O_planes argument of vlfb_conv_run_planes, [plane][row][ldo], o_pstride elements apart */
+   *   o_planes  FPROP / DGRAD: 2 = additionally write the first two bf16 terms of every output value to the
+   *             O_planes argument of vlfb_conv_run_planes, [plane][row][ldo], o_pstride elements apart;
+   *             1 = additionally write an fp16 COPY of the output to O_planes, [row][ldo] (batch stride o_bstride): what
+   *             the fp16 backward of the "mix" path reads (positive values stay positive in the copy) */
   int32_t a_planes, p_planes, o_planes, reserved0;
   int64_t a_pstride, p_pstride, o_pstride;
 } vlfb_conv_desc;
@@ -195,6 +206,9 @@ int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64_t n, int64
 /* generic cast fp32 <-> dtype, n elements */
 int vlfb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
               vlfb_stream_t stream);
+/* fp32 -> fp16 copy whose sign pattern equals the source's (a positive value below the fp16 subnormal range becomes the
+ * smallest subnormal, not +0): the activations the "mix" path's fp16 backward reads as WGRAD operands and ReLU masks */
+int vlfb_half_copy(const float* src, void* dst_f16, int64_t n, vlfb_stream_t stream);
 /* batched 2-D transpose of dtype elements: dst[b][j][i] = src[b][i][j], src is rows x cols */
 int vlfb_transpose2d(const void* src, void* dst, int dtype, int64_t batch, int64_t rows,
                      int64_t cols, vlfb_stream_t stream);

@@ -1,0 +1,132 @@
+"""CPU error-budget experiment for the HYBRID path (test infrastructure, not product): exact forward (the split-bf16
+forward is within 7e-6 of fp64), backward with fp16 roundings where the hybrid engine rounds: stored activation
+gradients (branch / residual stream), the saved-activation operand of WGRAD, the weight operand of DGRAD.
+Usage: python scratch/r4/emu_hybrid.py [preset] [bits]"""
+import sys, collections
+sys.path.insert(0, 'video-long-term-feature-banks_amd/lib'); sys.path.insert(0, '.')
+import numpy as np, torch
+import torch.nn.functional as F
+from vlfb.presets import load_preset
+from core.config import config as cfg
+from oracle import model as om
+
+import os
+NCLIP = int(os.environ.get("EMU_CLIPS", 2)); FR = int(os.environ.get("EMU_FRAMES", 16)); CROP = int(os.environ.get("EMU_CROP", 64))
+SMALL = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", NCLIP, "TRAIN.VIDEO_LENGTH", FR, "TRAIN.CROP_SIZE", CROP]
+BITS = 11
+QG = [False]
+
+
+def rq(t, bits=None):
+    bits = bits or BITS
+    m, e = torch.frexp(t)
+    s = float(1 << bits)
+    return torch.ldexp(torch.round(m * s) / s, e)
+
+
+class Store(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bwd_r):
+        ctx.bwd_r = bwd_r
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (rq(g) if ctx.bwd_r else g), None
+
+
+class ConvQ(torch.autograd.Function):
+    """exact forward; backward contracts ROUNDED operands: dgrad with q(w), wgrad with q(x)"""
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, dil, qx, qw):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, dil, qx, qw, b is not None)
+        return F.conv3d(x, w, b, stride, pad, dil)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, qx, qw, has_b = ctx.cfg
+        if QG[0]:
+            g = rq(g)
+        gi = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gi = torch.nn.grad.conv3d_input(x.shape, rq(w) if qw else w, g, stride, pad, dil)
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv3d_weight(rq(x) if qx else x, w.shape, g, stride, pad, dil)
+        if has_b and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3, 4))
+        return gi, gw, gb, None, None, None, None, None
+
+
+def rel(a, b):
+    d = float(b.norm())
+    return float((a - b).norm()) / (d if d > 0 else 1.0)
+
+
+def run(preset, variant):
+    load_preset(preset, SMALL)
+    inputs = om.synth_inputs(cfg, NCLIP, "train", seed=cfg.RNG_SEED, rois_per_clip=([2, 3] * NCLIP)[:NCLIP] if cfg.DATASET == "ava" else None,
+                             crop=CROP, frames=FR)
+    params = om.synth_params(cfg, seed=cfg.RNG_SEED)
+    B_ACT, B_RES = variant.get("bwd", False), variant.get("bwd_res", False)
+    QX, QW = variant.get("qx", False), variant.get("qw", False)
+    QG[0] = variant.get("qg", False)
+    orig_conv, orig_ca, orig_bott, orig_nl = om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal
+    orig_fconv = F.conv3d
+
+    def conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
+        y = ConvQ.apply(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil, QX, QW)
+        if "_branch" not in name and name != "conv1":
+            y = Store.apply(y, B_ACT)
+        return y
+
+    def conv_affine(cx, x, prefix, *a, **k):
+        y = orig_ca(cx, x, prefix, *a, **k)
+        if prefix.endswith("_branch2c"):
+            return y
+        return Store.apply(y, B_ACT)
+
+    def bott(cx, x, prefix, *a, **k):
+        return Store.apply(orig_bott(cx, x, prefix, *a, **k), B_RES)
+
+    def add_nl(cx, x, prefix, *a, **k):
+        return Store.apply(orig_nl(cx, x, prefix, *a, **k), B_RES)
+
+    om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = conv, conv_affine, bott, add_nl
+    try:
+        blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda name: 7)
+    finally:
+        om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = orig_conv, orig_ca, orig_bott, orig_nl
+    return blobs, grads
+
+
+VARIANTS = collections.OrderedDict([
+    ("all", dict(bwd=True, bwd_res=True, qx=True, qw=True)),
+    ("grads_only", dict(bwd=True, bwd_res=True)),
+    ("branch_grads+ops", dict(bwd=True, qx=True, qw=True)),
+    ("res_grads_only", dict(bwd_res=True)),
+    ("ops_only", dict(qx=True, qw=True)),
+    ("qx_only", dict(qx=True)),
+    ("qw_only", dict(qw=True)),
+    ("e_fp32store_qg_qx", dict(qg=True, qx=True)),
+    ("h1_grads+qx", dict(bwd=True, bwd_res=True, qx=True)),
+    ("h1_branch+qx", dict(bwd=True, qx=True)),
+])
+
+if __name__ == "__main__":
+    preset = sys.argv[1] if len(sys.argv) > 1 else "ava_r50_lfb_nl"
+    if len(sys.argv) > 2:
+        BITS = int(sys.argv[2])
+    torch.set_num_threads(8)
+    ref_b, ref_g = run(preset, {})
+    only = os.environ.get("EMU_ONLY")
+    for v, var in VARIANTS.items():
+        if only and v not in only.split(","):
+            continue
+        b, g = run(preset, var)
+        errs = sorted(((rel(g[n], ref_g[n]), n) for n in ref_g if float(ref_g[n].norm()) > 1e-12), reverse=True)
+        e = np.array([x for x, _ in errs])
+        print("%-18s grads median %.2e p90 %.2e max %.2e (%s) 2nd %.2e (%s) | conv1_w %.2e" % (
+            v, np.median(e), np.sort(e)[int(0.9 * (len(e) - 1))], e[0], errs[0][1], e[1], errs[1][1],
+            rel(g["conv1_w"], ref_g["conv1_w"]) if "conv1_w" in g else -1), flush=True)

@@ -44,6 +44,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.
 __device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // round-nearest-even
 
+// fp32 -> fp16 for the COPIES the "mix" engine's fp16 backward reads as ReLU masks: a positive value below the fp16
+// subnormal range must stay positive (sign(copy) == sign(value) is what `mask > 0` tests), so it becomes the smallest
+// subnormal instead of +0 (an absolute change of < 6e-8)
+__device__ __forceinline__ unsigned short f2h_pos(float f) {
+  const unsigned short h = f2h(f);
+  return (f > 0.f && (h & 0x7fffu) == 0) ? (unsigned short)1 : h;
+}
+__device__ __forceinline__ uint32_t pack_h2_pos(float lo, float hi) { return (uint32_t)f2h_pos(lo) | ((uint32_t)f2h_pos(hi) << 16); }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int EPC = 4;  // elements per 16-byte chunk

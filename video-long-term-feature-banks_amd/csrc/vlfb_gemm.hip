@@ -1142,7 +1142,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->sp_kind = 0;
   VLFB_REQUIRE(pl->sp || (!d->a_planes && !d->p_planes && !d->o_planes), "conv: term planes belong to split-bf16 math");
   VLFB_REQUIRE(d->mode == VLFB_CONV_WGRAD ? (d->a_planes ? d->a_planes >= 2 && d->p_planes == 2 : d->p_planes == 0) && !d->o_planes
-                                         : (d->a_planes == 0 || d->a_planes >= pl->sp) && !d->p_planes && (d->o_planes == 0 || d->o_planes == 2),
+                                         : (d->a_planes == 0 || d->a_planes >= pl->sp) && !d->p_planes && (d->o_planes >= 0 && d->o_planes <= 2),
                "conv: bad a_planes / p_planes / o_planes for this mode");
   pl->sp_pl = d->a_planes > 0;
   // operands handed in as bf16 term planes are 2-byte elements for all address arithmetic below
@@ -1506,7 +1506,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       if (g.s2) { pl->ut = 1; pl->sp_kind = 2; }
       VLFB_REQUIRE(!pl->sp_pl || ((pl->ident || pl->ut) && d->a_pstride % 8 == 0 && (g.lda % 8 == 0 || pl->packw)),
                    "conv: a pre-split activation operand needs plain rows or taps that span whole 32-element k-tiles");
-      VLFB_REQUIRE(!d->o_planes || (d->o_pstride % 4 == 0 && batch == 1), "conv: o_planes needs batch 1 and an aligned o_pstride");
+      VLFB_REQUIRE(d->o_planes != 2 || (d->o_pstride % 4 == 0 && batch == 1), "conv: o_planes = 2 needs batch 1 and an aligned o_pstride");
       const size_t sbuf = (pl->sp_pl ? (size_t)pl->sp * 128 * 64 : (size_t)128 * 128) + (size_t)pl->sp * pl->bn * 64;
       pl->lds = 2 * sbuf;
       if (pl->lds < (size_t)128 * pl->bn * 4) pl->lds = (size_t)128 * pl->bn * 4;

@@ -134,7 +134,7 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
     }
   }
   __syncthreads();
-  const bool planes = p.op_n == 2;
+  const bool planes = p.op_n == 2, half_copy = p.op_n == 1;
   float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias_mode == VLFB_BIAS_COL && ncol < p.Ncols) bc = *reinterpret_cast<const float4*>(p.bias + ncol);
 #pragma unroll
@@ -163,6 +163,9 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
         const uint32_t h01 = peel(v[0], v[1]), h23 = peel(v[2], v[3]);
         *reinterpret_cast<uint2*>(op) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(op + p.o_ps) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      } else if (half_copy) {
+        // "mix" engine: the fp16 copy of the output that the fp16 backward reads (WGRAD operand, ReLU mask)
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.OP) + (long long)z * p.o_bs + oidx) = make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2], v[3]));
       }
     }
   }

@@ -2,6 +2,7 @@
 // pools, row softmax, residual add / ReLU, column sums.  All are one-pass, 16-byte-per-lane
 // vectorised kernels; the roofline that bounds them is HBM bandwidth.
 #include "vlfb_common.h"
+#include <type_traits>
 #include <math.h>
 
 namespace vlfb {
@@ -147,6 +148,33 @@ template <> struct WStore<SplitW> {
   __device__ static __forceinline__ void dgrad(void* base, long long idx, long long plane, float v) { store_terms<2>(reinterpret_cast<bf16_t*>(base), idx, plane, v); }
 };
 
+// "mix" engine (VLFB_MIX): split-bf16 forward, fp16 backward -- the FPROP copy as the three bf16 term planes of VLFB_SPLIT,
+// the DGRAD copy as plain fp16 elements [Cin][taps][Cout]
+struct MixW {};
+template <> struct WStore<MixW> {
+  __device__ static __forceinline__ void fprop(void* base, long long idx, long long plane, float v) { store_terms<3>(reinterpret_cast<bf16_t*>(base), idx, plane, v); }
+  __device__ static __forceinline__ void dgrad(void* base, long long idx, long long, float v) { reinterpret_cast<unsigned short*>(base)[idx] = f2h(v); }
+};
+
+// VLFB_MIX_W2: the DGRAD copy as TWO fp16 terms of (w * s) * VLFB_MIX_W2_SCALE, [Cin][term][taps][Cout] -- the weight of
+// a convolution with a doubled outermost tap dimension of dilation 0 (every tap is visited once per term), which the
+// plain fp16 DGRAD kernels contract with the fp16 gradient: dX = dY . (Wh + Wl), 22 significant bits of W
+struct MixW2 {};
+template <> struct WStore<MixW2> : WStore<MixW> {};
+
+template <typename T>
+__device__ __forceinline__ void wstore_dgrad(void* base, int ci, int tap, int co, int taps, int cout, long long plane, float v) {
+  if constexpr (std::is_same<T, MixW2>::value) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(base) + ((long long)ci * 2 * taps + tap) * cout + co;
+    const float sv = v * VLFB_MIX_W2_SCALE;
+    const unsigned short h = f2h(sv);
+    o[0] = h;
+    o[(long long)taps * cout] = f2h(sv - h2f(h));
+  } else {
+    WStore<T>::dgrad(base, ((long long)ci * taps + tap) * cout + co, plane, v);
+  }
+}
+
 // w[Cout][taps][Cin] fp32 (+ scale[Cout]) -> fprop copy (same order) in T
 template <typename T>
 __global__ void weight_prep_fprop_kernel(const float* __restrict__ w, const float* __restrict__ scale,
@@ -173,7 +201,7 @@ __global__ void weight_prep_dgrad_kernel(const float* __restrict__ w, const floa
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     int ci = ci0 + j, co = co0 + threadIdx.x;
     if (co < cout && ci < cin)
-      WStore<T>::dgrad(out, ((long long)ci * taps + tap) * cout + co, (long long)cout * taps * cin, tile[threadIdx.x][j]);
+      wstore_dgrad<T>(out, ci, tap, co, taps, cout, (long long)cout * taps * cin, tile[threadIdx.x][j]);
   }
 }
 
@@ -214,7 +242,7 @@ __global__ void weight_prep_batched_kernel(const vlfb_wprep_item* __restrict__ i
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int ci = ci0 + j, co = co0 + threadIdx.x;
     if (co < it.cout && ci < it.cin)
-      WStore<T>::dgrad(wd, ((long long)ci * it.taps + tap) * it.cout + co, plane, tile[threadIdx.x][j]);
+      wstore_dgrad<T>(wd, ci, tap, co, it.taps, it.cout, plane, tile[threadIdx.x][j]);
   }
 }
 
@@ -1036,6 +1064,22 @@ extern "C" int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64
   else return set_error(VLFB_ERR_ARG, "nthwc_to_ncthw: bad dtype");
   return check_launch("nthwc_to_ncthw");
 }
+// fp32 -> fp16 copy for the "mix" engine's backward (16 bytes read, 8 written per lane and step; positive values stay
+// positive, f2h_pos)
+__global__ void half_copy_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n4, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_h2_pos(v.x, v.y), pack_h2_pos(v.z, v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = f2h_pos(src[(n4 << 2) + threadIdx.x]);
+}
+extern "C" int vlfb_half_copy(const float* src, void* dst, int64_t n, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst && n >= 0, "half_copy: bad args");
+  if (n == 0) return VLFB_OK;
+  hipLaunchKernelGGL(half_copy_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (unsigned short*)dst, (long long)(n / 4), (long long)n);
+  return check_launch("half_copy");
+}
 extern "C" int vlfb_cast(const void* src, int sd, void* dst, int dd, int64_t n, vlfb_stream_t stream) {
   VLFB_REQUIRE(src && dst && n >= 0, "cast: bad args");
   if (n == 0) return VLFB_OK;
@@ -1069,7 +1113,7 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
                                 int dtype, int64_t cout, int64_t taps, int64_t cin,
                                 vlfb_stream_t stream) {
   VLFB_REQUIRE(w && (w_fprop || w_dgrad) && cout > 0 && taps > 0 && cin > 0, "weight_prep: bad args");
-  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype) || dtype == VLFB_SPLIT, "weight_prep: bad dtype");
+  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype) || dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2, "weight_prep: bad dtype");
   VLFB_REQUIRE(taps < 65536, "weight_prep: too many taps");
   hipStream_t s = (hipStream_t)stream;
   const long long total = cout * taps * cin;
@@ -1077,7 +1121,7 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
     int grid = grid_for(total, 256);
     if (dtype == VLFB_F32)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
-    else if (dtype == VLFB_SPLIT)
+    else if (dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<SplitW>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
     else
       VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_fprop_kernel<T16>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total));
@@ -1088,6 +1132,10 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<float>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else if (dtype == VLFB_SPLIT)
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<SplitW>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
+    else if (dtype == VLFB_MIX)
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
+    else if (dtype == VLFB_MIX_W2)
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW2>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else
       VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_dgrad_kernel<T16>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin));
   }
@@ -1329,6 +1377,10 @@ extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_
     VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_batched_kernel<T16>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items));
   else if (dtype == VLFB_SPLIT)
     hipLaunchKernelGGL(weight_prep_batched_kernel<SplitW>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_MIX)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<MixW>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_MIX_W2)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<MixW2>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
   return check_launch("weight_prep_batched");
 }

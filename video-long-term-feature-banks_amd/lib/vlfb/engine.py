@@ -63,6 +63,8 @@ class Blob(object):
         self.producer = None
         self.grad_scale = 1.0         # the stored gradient is the true one times this power of two (fp16 range)
         self.planes = None            # "split" dtype: bf16 term planes [2][numel] of the values, written by the producing conv
+        self.half = None              # "mix" dtype: fp16 copy of the values for the fp16 backward (root only; Engine.want_half)
+        self.need_half = False
 
     @property
     def numel(self):
@@ -78,6 +80,14 @@ class Blob(object):
 
     def storage(self):
         return self.root.tensor
+
+    def bstorage(self):
+        """the values as the BACKWARD pass reads them: the fp16 copy on the "mix" path, else the values themselves"""
+        r = self.root
+        return r.half if r.half is not None else r.tensor
+
+    def bptr(self):
+        return self.bstorage().data_ptr()
 
     def ptr(self):
         return self.root.tensor.data_ptr()
@@ -118,7 +128,7 @@ class GradSlot(object):
         if self.count > self.expected:
             raise RuntimeError("too many gradient contributions for %s" % self.blob.name)
         last = self.count == self.expected
-        mask = self.blob.tensor if (last and self.blob.relu) else None
+        mask = self.blob.bstorage() if (last and self.blob.relu) else None
         return self.cur, mask
 
     def contribute(self, fn, supports_add=True, supports_mask=True, writes_planes=False):
@@ -211,8 +221,8 @@ class ConvStep(Step):
         _, Cout, To, Ho, Wo = self.out.shape
         self.Cin_k = 4 if self.stem else Cin          # channels as the kernel sees them
         self.pack = 8 if self.stem else 0
-        code = eng.code
-        common = dict(dtype=code, **self._geom())
+        code, bcode = eng.code, eng.bcode
+        geom = self._geom()
         # the gradient arriving at `out` may be stored scaled (fp16 attention logits): divide it out in the
         # epilogues of the kernels that consume it
         self.gscale = float(self.out.root.grad_scale)
@@ -221,26 +231,47 @@ class ConvStep(Step):
             wpad = getattr(self.x.root, "pad_w", 0) or getattr(self.x, "pad_w", 0)
             assert wpad >= self.p[2] and wpad >= self.pack - self.k[2] + self.p[2], "stem needs a W-padded input"
             W = W + 2 * wpad
-            common["pw"] = self.p[2] - wpad
+            geom["pw"] = self.p[2] - wpad
         # split-bf16 math on fp32 storage (Engine dtype "split"): the weight operand copies are bf16 term planes
         wshape = eng.kernel_shape(self.wname)
         mf, mb = eng.math_fwd, eng.math_bwd
         planes = dict(b_pstride=_prod(wshape)) if eng.split else {}
-        self.d_f = hip.conv_desc(mode=hip.FPROP, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
+        bplanes = planes if mb != hip.MATH_NATIVE else {}          # ("mix": split forward, native fp16 backward)
+        self.d_f = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
                                  Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, relu=int(self.relu),
                                  bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, math=mf,
-                                 **planes, **common)
+                                 **planes, **geom)
         self.d_d = None
+        self.w2 = False
         if self.x.needs_grad and not self.x.detached:
             assert not self.stem
-            self.d_d = hip.conv_desc(mode=hip.DGRAD, out_dtype=code, N=N, Tr=T, Hr=H, Wr=W, Ts=To,
-                                     Hs=Ho, Ws=Wo, Cs=Cout, Cn=Cin, alpha=1.0 / self.gscale, math=mb, **planes, **common)
+            dg = dict(geom)
+            alpha = 1.0 / self.gscale
+            rows = dict(N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo)
+            if eng.mix and eng.MIX_W2:
+                # two-term fp16 weights (hip.MIX_W2): the same convolution with a doubled OUTERMOST tap dimension of
+                # dilation 0, i.e. every tap is contracted with Wh and with Wl by the plain fp16 DGRAD kernels
+                k_, s_, p_, d_ = self.k, self.s, self.p, self.d
+                if k_[0] == 1:
+                    dg.update(kt=2, dt=0)
+                else:
+                    # k x 1 x 1 (the first conv of a bottleneck): T plays the role of H, H x W are one pointwise axis,
+                    # and the (size-1) T axis carries the term dimension
+                    assert k_[1] == 1 and k_[2] == 1 and tuple(s_) == (1, 1, 1) and p_[1] == 0 and p_[2] == 0, \
+                        "MIX_W2: unexpected conv geometry %r / %r / %r" % (k_, s_, p_)
+                    dg.update(kt=2, kh=k_[0], kw=1, st=1, sh=1, sw=1, pt=0, ph=p_[0], pw=0, dt=0, dh=d_[0], dw=1)
+                    rows = dict(N=N, Tr=1, Hr=T, Wr=H * W, Ts=1, Hs=To, Ws=Ho * Wo)
+                alpha /= hip.MIX_W2_SCALE
+                self.w2 = True
+            self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=bcode, Cs=Cout, Cn=Cin, alpha=alpha, math=mb,
+                                     **rows, **bplanes, **dg)
         self.d_w = None
         if eng.is_trainable(self.wname):
-            self.d_w = hip.conv_desc(mode=hip.WGRAD, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
+            self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
                                      Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
-                                     math=mb, **common)
+                                     math=mb, **geom)
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
+            eng.want_half(self.x)
         # Pre-split operands ("split" dtype, Engine.PLANES): a conv epilogue can write the bf16 term planes of its output
         # next to the fp32 values (o_planes), and DGRAD / WGRAD launches that find their activation / gradient operands in
         # that form spend no VALU on the expansion (a_planes / p_planes).  Variants are built lazily (_pl_desc).
@@ -248,11 +279,11 @@ class ConvStep(Step):
         # the stem reads the clip: its term planes are made once per forward pass by a split pass (3 planes for the
         # six-product FPROP, of which the WGRAD reads the first two next to a split pass over its output gradient)
         self.x_planes = self.g_planes = None
-        if self.stem and eng.split and eng.PLANES and eng.STEM_PLANES:
+        if self.stem and eng.split and (eng.PLANES or eng.mix) and eng.STEM_PLANES:
             n_in = self.x.root.numel // self.x.root.C // self.x.root.shape[-1] * W * self.Cin_k     # W is the padded width here
             self.x_npl = 3 if mf == hip.MATH_BF16X6 else 2
             self.x_planes = torch.empty(self.x_npl * n_in, device=eng.device, dtype=torch.bfloat16)
-            if eng.is_trainable(self.wname):
+            if eng.is_trainable(self.wname) and not eng.mix:
                 self.g_planes = torch.empty(2 * self.out.numel, device=eng.device, dtype=torch.bfloat16)
         unit = tuple(self.s) == (1, 1, 1)
         plain = unit and tuple(self.k) == (1, 1, 1) and tuple(self.p) == (0, 0, 0)
@@ -268,8 +299,11 @@ class ConvStep(Step):
             self.w_f = torch.empty(wshape, device=eng.device, dtype=eng.tdtype)
         self.w_d = None
         if self.d_d is not None:
-            self.w_d = (torch.empty(2 * _prod(wshape), device=eng.device, dtype=torch.bfloat16) if eng.split else
-                        torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype))
+            if eng.mix:
+                self.w_d = torch.empty((2 if self.w2 else 1) * _prod(wshape), device=eng.device, dtype=torch.float16)
+            else:
+                self.w_d = (torch.empty(2 * _prod(wshape), device=eng.device, dtype=torch.bfloat16) if eng.split else
+                            torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype))
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
@@ -326,8 +360,12 @@ class ConvStep(Step):
         if self.x_planes is not None:
             n = self.x_planes.numel() // self.x_npl
             hip.call("vlfb_split_planes", self.x.ptr(), hip.ptr(self.x_planes), self.x_npl, 1, n // 8, 8, 0)
-            hip.conv_run(self._pl_desc(self.d_f, a_planes=self.x_npl, a_pstride=n), self.x_planes, self.w_f, None, self.out.storage(),
-                         bias=self.bias_tensor(), R=R)
+            kw = dict(a_planes=self.x_npl, a_pstride=n)
+            oh = self.out.root.half
+            if oh is not None:
+                kw.update(o_planes=1)
+            hip.conv_run(self._pl_desc(self.d_f, **kw), self.x_planes, self.w_f, None, self.out.storage(),
+                         bias=self.bias_tensor(), R=R, O_planes=oh)
             return
         xp = self.x.root.planes if self.fprop_takes_planes else None
         kw = {}
@@ -335,6 +373,9 @@ class ConvStep(Step):
             kw.update(a_planes=2, a_pstride=xp.numel() // 2)
         if op is not None:
             kw.update(o_planes=2, o_pstride=op.numel() // 2)
+        elif self.out.root.half is not None:       # "mix": the fp16 copy the backward reads, written by this epilogue
+            op = self.out.root.half
+            kw.update(o_planes=1)
         hip.conv_run(self._pl_desc(self.d_f, **kw) if kw else self.d_f, self.x.storage() if xp is None else xp, self.w_f, None,
                      self.out.storage(), bias=self.bias_tensor(), R=R, O_planes=op)
 
@@ -377,7 +418,7 @@ class ConvStep(Step):
                 d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2)
                 hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
             else:
-                hip.conv_run(self.d_w, self.x.storage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
+                hip.conv_run(self.d_w, self.x.bstorage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
                              workspace=eng.workspace)
             if self.stem:   # keep the zero padding of the packed stem weight exactly zero
                 gw = eng.grad_tensor(self.wname)
@@ -387,11 +428,11 @@ class ConvStep(Step):
             Cout = self.out.shape[1]
             gb = eng.grad_tensor(self.cbname)
             if self.sname:
-                hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
+                hip.call("vlfb_colsum", hip.ptr(g), eng.bcode, self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
                 hip.call("vlfb_affine_nd_bwd", hip.ptr(self.cb_tmp), hip.ptr(eng.param_tensor(self.sname)),
                          hip.ptr(gb), 1, Cout, 1)
             else:
-                hip.call("vlfb_colsum", hip.ptr(g), eng.code, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
+                hip.call("vlfb_colsum", hip.ptr(g), eng.bcode, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
             if self.gscale != 1.0:
                 hip.call("vlfb_scale_inplace", hip.ptr(gb), gb.numel(), 1.0 / self.gscale)
 
@@ -411,6 +452,9 @@ class PoolStep(Step):
         N, Cc, T, H, W = self.x.shape
         _, _, To, Ho, Wo = self.out.shape
         self.desc = hip.pool_desc(eng.code, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
+        self.desc_b = self.desc if eng.bcode == eng.code else hip.pool_desc(eng.bcode, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
+        if self.is_max and eng.train and self.x.relu:
+            eng.want_half(self.out)               # vlfb_maxpool_relu_bwd reads the pooled values as the ReLU mask
         self.argmax = None
         if self.is_max and eng.train:
             nbytes = hip.lib().vlfb_pool_argmax_bytes(C.byref(self.desc))
@@ -430,13 +474,13 @@ class PoolStep(Step):
             def fn(out, add, mask):
                 if mask is not None and add is None:
                     # sole consumer of a ReLU output: the mask is `pooled value > 0` (see vlfb_maxpool_relu_bwd)
-                    hip.call("vlfb_maxpool_relu_bwd", C.byref(self.desc), hip.ptr(g), hip.ptr(self.argmax),
-                             self.out.ptr(), hip.ptr(out))
+                    hip.call("vlfb_maxpool_relu_bwd", C.byref(self.desc_b), hip.ptr(g), hip.ptr(self.argmax),
+                             self.out.bptr(), hip.ptr(out))
                 else:
-                    hip.call("vlfb_maxpool_bwd", C.byref(self.desc), hip.ptr(g), hip.ptr(self.argmax), hip.ptr(out),
+                    hip.call("vlfb_maxpool_bwd", C.byref(self.desc_b), hip.ptr(g), hip.ptr(self.argmax), hip.ptr(out),
                              hip.ptr(add), hip.ptr(mask))
         else:
-            fn = lambda out, add, mask: hip.call("vlfb_avgpool_bwd", C.byref(self.desc), hip.ptr(g),
+            fn = lambda out, add, mask: hip.call("vlfb_avgpool_bwd", C.byref(self.desc_b), hip.ptr(g),
                                                  hip.ptr(out), hip.ptr(add), hip.ptr(mask))
         self.x.root.slot.contribute(fn)
 
@@ -449,6 +493,7 @@ class AttentionStep(Step):
         Step.__init__(self, eng)
         self.theta, self.phi, self.g, self.prob, self.out, self.scale = theta, phi, g, prob, out, scale
         self.inputs, self.outputs = [theta, phi, g], [out]
+        self.aux_outputs = [prob]
 
     def name(self):
         return "attention:" + self.out.name
@@ -458,8 +503,11 @@ class AttentionStep(Step):
         B, Ci, L1 = self.theta.shape
         L2 = self.phi.shape[2]
         self.B, self.Ci, self.L1, self.L2 = B, Ci, L1, L2
-        code = eng.code
+        code, bcode = eng.code, eng.bcode
         self.single = (L1 == 1)
+        if eng.train:
+            for t in (self.theta, self.phi, self.g) + (() if self.single else (self.prob,)):
+                eng.want_half(t)
         if self.single:
             self.ds_ws = torch.empty(B * L2, device=eng.device, dtype=torch.float32)
             return
@@ -467,35 +515,36 @@ class AttentionStep(Step):
         # vlfb_split_planes right before the product that reads them (3 planes forward, 2 backward)
         mf, mb = eng.math_fwd, eng.math_bwd
         pl = dict(b_pstride=B * L2 * Ci) if eng.split else {}
-        gemm = lambda **kw: hip.conv_desc(mode=hip.FPROP, dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
-                                          Ws=L1, batch=B, **kw)
+        bpl = pl if mb != hip.MATH_NATIVE else {}                  # ("mix": split forward products, native fp16 backward)
+        self.bsplit = bool(bpl)
+        gemm = lambda dtype=code, **kw: hip.conv_desc(mode=hip.FPROP, dtype=dtype, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
+                                                      Ws=L1, batch=B, **kw)
         self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mf, **pl)
         self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci, math=mf, **pl)
-        self.d_dp = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mb, **pl)
+        self.d_dp = gemm(dtype=bcode, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mb, **bpl)
         if eng.split:
             eng.need_scratch_planes(3 * B * L2 * Ci)
         # fp16: dS = scale * P o (dP - <dP, P>) is ~ 1 / L2 of an activation gradient and would leave the fp16
         # range (6e-8) for long key axes (1568 keys in 64-frame clips); it is stored times a power of two, which
         # the two products that consume it divide out again in their epilogues (alpha).  Exact; 1 elsewhere.
-        self.ds_scale = float(16 << max(L2 - 1, 1).bit_length()) if eng.tdtype == torch.float16 else 1.0
+        self.ds_scale = float(16 << max(L2 - 1, 1).bit_length()) if eng.btdtype == torch.float16 else 1.0
         # ... and the gradients of theta / phi themselves (again ~ 1 / L2 of an activation gradient) are stored
         # times Blob.grad_scale (set at lowering), which the theta / phi convs divide out (ConvStep.gscale)
         gs_th, gs_ph = float(self.theta.root.grad_scale), float(self.phi.root.grad_scale)
-        self.d_dth = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
-                          alpha=gs_th / self.ds_scale, math=mb, **pl)
+        self.d_dth = gemm(dtype=bcode, out_dtype=bcode, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
+                          alpha=gs_th / self.ds_scale, math=mb, **bpl)
         # contract over L1: out[L2][Ci] = sum_l P[l][L2] * A[l][Ci]
-        self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
+        self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=bcode, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                   Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
                                   o_bstride=L2 * Ci, splits=1, math=mb)
-        self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=code, out_dtype=code, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
+        self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=bcode, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                       Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
                                       o_bstride=L2 * Ci, splits=1, alpha=gs_ph / self.ds_scale, math=mb)
         # 16-bit paths: scores + row softmax (and their backward) in one kernel each, the fp32 score matrix never
         # exists (csrc/vlfb_attn.hip) -- per direction, and only where the library reports the fused kernel as
         # measured faster; otherwise GEMM -> fp32 scratch -> softmax kernels
-        can = hip.lib().vlfb_attn_scores_supported(code, L1, L2, Ci)
-        self.fused_fwd = bool(can & hip.ATTN_FWD_FASTER)
-        self.fused_bwd = bool(can & hip.ATTN_BWD_FASTER)
+        self.fused_fwd = bool(hip.lib().vlfb_attn_scores_supported(code, L1, L2, Ci) & hip.ATTN_FWD_FASTER)
+        self.fused_bwd = bool(hip.lib().vlfb_attn_scores_supported(bcode, L1, L2, Ci) & hip.ATTN_BWD_FASTER)
         if not (self.fused_fwd and self.fused_bwd):
             eng.need_scratch_f32(B * L1 * L2)
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
@@ -542,32 +591,32 @@ class AttentionStep(Step):
             for s in (th, ph, gg):
                 s._flags()
                 s.cur = s.buf
-            hip.call("vlfb_fbo_attn_bwd", hip.ptr(dY), self.theta.ptr(), self.phi.ptr(), self.g.ptr(),
+            hip.call("vlfb_fbo_attn_bwd", hip.ptr(dY), self.theta.bptr(), self.phi.bptr(), self.g.bptr(),
                      self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), hip.ptr(self.ds_ws),
-                     eng.code, B, L2, Ci, Ci, self.scale)
+                     eng.bcode, B, L2, Ci, Ci, self.scale)
             return
-        P = self.prob.storage()
+        P = self.prob.bstorage()
         if not self.fused_bwd:
             dP = eng.scratch_f32(B * L1 * L2)
-            hip.conv_run(self.d_dp, dY, self._planes(self.g.storage(), 2, False) if eng.split else self.g.storage(), None, dP)
+            hip.conv_run(self.d_dp, dY, self._planes(self.g.storage(), 2, False) if self.bsplit else self.g.bstorage(), None, dP)
         gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
                       supports_add=False, supports_mask=False)
         act = eng.scratch_act(B * L1 * L2 + B * Ci * L2)
         dS = act[:B * L1 * L2]
         phT = act[B * L1 * L2:]
         if self.fused_bwd:
-            hip.call("vlfb_attn_scores_bwd", hip.ptr(dY), self.g.ptr(), hip.ptr(P), hip.ptr(dS), eng.code, B, L1, L2, Ci,
+            hip.call("vlfb_attn_scores_bwd", hip.ptr(dY), self.g.bptr(), hip.ptr(P), hip.ptr(dS), eng.bcode, B, L1, L2, Ci,
                      self.scale * self.ds_scale)
         else:
-            hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.code, B * L1, L2,
+            hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.bcode, B * L1, L2,
                      self.scale * self.ds_scale)
-        if eng.split:
+        if self.bsplit:
             phT = self._planes(self.phi.storage(), 2, True)
         else:
-            hip.call("vlfb_transpose2d", self.phi.ptr(), hip.ptr(phT), eng.code, B, L2, Ci)
+            hip.call("vlfb_transpose2d", self.phi.bptr(), hip.ptr(phT), eng.bcode, B, L2, Ci)
         th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
                       supports_add=False, supports_mask=False)
-        ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.storage(), None, dS, out),
+        ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.bstorage(), None, dS, out),
                       supports_add=False, supports_mask=False)
 
 
@@ -632,6 +681,8 @@ class BNStep(Step):
 
     def setup(self):
         eng = self.eng
+        if eng.mix:
+            raise NotImplementedError("SpatialBN graphs are not built for the 'mix' dtype (use 'split' / 'fp32' / 16-bit)")
         self.rows, self.C = self.x.rows, self.x.C
         self.params = [n for n in (self.sname, self.bname) if eng.is_trainable(n)]
         nbytes = hip.query_workspace(hip.WS_BN, (eng.code, self.rows, self.C))
@@ -677,6 +728,8 @@ class LayerNormStep(Step):
         self.rows = self.x.shape[0]
         self.cols = self.x.numel // self.rows
         self.rstd = torch.empty(self.rows, device=self.eng.device, dtype=torch.float32)
+        if self.eng.train:
+            self.eng.want_half(self.out)      # the backward reads the normalised values
 
     def fwd(self):
         hip.call("vlfb_layernorm_fwd", self.x.ptr(), self.out.ptr(), hip.ptr(self.rstd), self.eng.code,
@@ -687,8 +740,8 @@ class LayerNormStep(Step):
             return
         g = self.out_grad()
         self.x.root.slot.contribute(
-            lambda out, add, mask: hip.call("vlfb_layernorm_bwd", hip.ptr(g), self.out.ptr(), hip.ptr(self.rstd),
-                                            hip.ptr(out), self.eng.code, self.rows, self.cols),
+            lambda out, add, mask: hip.call("vlfb_layernorm_bwd", hip.ptr(g), self.out.bptr(), hip.ptr(self.rstd),
+                                            hip.ptr(out), self.eng.bcode, self.rows, self.cols),
             supports_add=False, supports_mask=False)
 
 
@@ -722,7 +775,7 @@ class DropoutStep(Step):
         g = self.out_grad()
         self.x.root.slot.contribute(
             lambda out, add, mask: hip.call("vlfb_dropout_bwd", hip.ptr(g), hip.ptr(self.mask), hip.ptr(out),
-                                            self.eng.code, self.out.numel, self.ratio),
+                                            self.eng.bcode, self.out.numel, self.ratio),
             supports_add=False, supports_mask=False)
 
 
@@ -761,10 +814,10 @@ class RoiAlignMaxStep(Step):
         eng = self.eng
         g = self.out_grad()
         hip.call("vlfb_zero_f32", hip.ptr(self.dfeat), self.dfeat.numel())
-        hip.call("vlfb_roi_align_max_bwd", hip.ptr(g), eng.code, self.rois.ptr(), hip.ptr(self.argbin),
+        hip.call("vlfb_roi_align_max_bwd", hip.ptr(g), eng.bcode, self.rois.ptr(), hip.ptr(self.argbin),
                  hip.ptr(self.dfeat), self.N, self.H, self.W, self.Cc, self.R, self.pooled, self.spatial_scale)
         self.feat.root.slot.contribute(
-            lambda out, add, mask: hip.call("vlfb_cast", hip.ptr(self.dfeat), hip.F32, hip.ptr(out), eng.code,
+            lambda out, add, mask: hip.call("vlfb_cast", hip.ptr(self.dfeat), hip.F32, hip.ptr(out), eng.bcode,
                                             self.dfeat.numel()),
             supports_add=False, supports_mask=False)
 
@@ -794,14 +847,14 @@ class ConcatStep(Step):
 
     def bwd(self):
         g = self.out_grad()
-        es = self.eng.esize
+        es = self.eng.besize
         off = 0
         for p in self.parts:
             if p.needs_grad and not p.detached:
                 o = off
                 p.root.slot.contribute(
                     lambda out, add, mask, o=o, p=p: hip.call("vlfb_copy2d", hip.ptr(g) + o * es, self.total,
-                                                              hip.ptr(out), p.C, self.eng.code, self.rows, p.C),
+                                                              hip.ptr(out), p.C, self.eng.bcode, self.rows, p.C),
                     supports_add=False, supports_mask=False)
             off += p.C
 
@@ -820,6 +873,8 @@ class FCStep(Step):
         self.cin = self.x.numel // self.rows
         self.cout = self.out.shape[1]
         self.params = [n for n in (self.wname, self.bname) if self.eng.is_trainable(n)]
+        if self.eng.train:
+            self.eng.want_half(self.x)
 
     def fwd(self):
         eng = self.eng
@@ -834,11 +889,11 @@ class FCStep(Step):
         dw = eng.grad_tensor(self.wname) if train else None
         db = eng.grad_tensor(self.bname) if train else None
         if dw is not None:
-            hip.call("vlfb_fc_bwd", self.x.ptr(), eng.code, hip.ptr(w), hip.ptr(dl), None, hip.ptr(dw), hip.ptr(db),
+            hip.call("vlfb_fc_bwd", self.x.bptr(), eng.bcode, hip.ptr(w), hip.ptr(dl), None, hip.ptr(dw), hip.ptr(db),
                      self.rows, self.cin, self.cout, 0)
         if self.grad_inputs():
             self.x.root.slot.contribute(
-                lambda out, add, mask: hip.call("vlfb_fc_bwd", self.x.ptr(), eng.code, hip.ptr(w), hip.ptr(dl),
+                lambda out, add, mask: hip.call("vlfb_fc_bwd", self.x.bptr(), eng.bcode, hip.ptr(w), hip.ptr(dl),
                                                 hip.ptr(out), None, None, self.rows, self.cin, self.cout, 0),
                 supports_add=False, supports_mask=False)
 
@@ -1192,7 +1247,7 @@ class Lowering(object):
         B, Ci, L1 = theta.shape
         L2 = phi.shape[2]
         single = (L1 == 1)
-        if not single and self.eng.tdtype == torch.float16:
+        if not single and self.eng.btdtype == torch.float16:
             # fp16: d theta and d phi are about 1 / L2 of a normal activation gradient (they pass the softmax
             # Jacobian): keep them times a power of two so that they stay in the fp16 normal range
             for t in (theta, phi):
@@ -1355,21 +1410,34 @@ class Engine(object):
             raise hip.VlfbError("vlfb.engine needs a GPU: there is no CPU fallback for the hot path")
         self.model = model
         self.tdtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "fp32": torch.float32,
-                       "f32": torch.float32, "split": torch.float32}[dtype]
+                       "f32": torch.float32, "split": torch.float32, "mix": torch.float32}[dtype]
         self.code = hip.dtype_code(self.tdtype)
+        # "mix": the FORWARD of "split" (fp32 storage, three bf16 products per product: activations within ~1e-5 of fp64, so
+        # the ReLU / max-pool decisions are the parity path's) and the BACKWARD of "fp16" (fp16 gradient storage with the
+        # static loss scale, one fp16 MFMA per product), joined by fp16 COPIES of the forward values the backward reads
+        # (WGRAD operands, ReLU masks, attention operands: Blob.half, written by the producing conv epilogue or a copy
+        # pass).  MIX_W2: the DGRAD weight operand as two fp16 terms (the rounding of W to 11 bits is the largest single
+        # error class of an fp16 backward, scratch/r4/emu_hybrid.py).
+        self.mix = dtype == "mix"
+        self.btdtype = torch.float16 if self.mix else self.tdtype      # element type of the backward pass
+        self.bcode = hip.dtype_code(self.btdtype)
         # "split": fp32 storage everywhere (as "fp32"), every contraction on the bf16 matrix cores with the operands
         # expanded into bf16 terms (csrc/vlfb_gemm_split.hip): six MFMAs per product forward (fp32-grade: ReLU / max-pool
         # decisions must match the oracle's), three backward.  The parity-grade path at several times the fp32-MFMA rate.
-        self.split = dtype == "split"
+        self.split = dtype in ("split", "mix")
         self.math_fwd = self.SPLIT_MATH[0] if self.split else hip.MATH_NATIVE
-        self.math_bwd = self.SPLIT_MATH[1] if self.split else hip.MATH_NATIVE
-        self.wcode = hip.SPLIT if self.split else self.code      # format of the MFMA weight operand copies
+        self.math_bwd = self.SPLIT_MATH[1] if (self.split and not self.mix) else hip.MATH_NATIVE
+        if self.mix and self.math_fwd != hip.MATH_BF16X3:
+            raise hip.VlfbError("the 'mix' dtype uses three-term forward products (VLFB_SPLIT_MATH=3,3)")
+        # format of the MFMA weight operand copies
+        self.wcode = (hip.MIX_W2 if self.MIX_W2 else hip.MIX) if self.mix else hip.SPLIT if self.split else self.code
         self.esize = 4 if self.tdtype == torch.float32 else 2
+        self.besize = 4 if self.btdtype == torch.float32 else 2
         # fp16 storage (v_mfma_f32_16x16x32_f16; BASELINE.json configs[4]): 10 mantissa bits instead of bf16's 7,
         # but gradients of 1e-6 fall below the fp16 normal range, so the loss gradient is scaled by a power of two
         # (exact) and every parameter gradient carries that factor until the solver divides it out again
         # (lr / S, weight decay * S: lr/S * (S g + S wd p) = lr * (g + wd p)).  1 on the other paths.
-        self.auto_loss_scale = loss_scale is None and self.tdtype == torch.float16   # set by LossStep.setup from the shapes
+        self.auto_loss_scale = loss_scale is None and self.btdtype == torch.float16   # set by LossStep.setup from the shapes
         self.loss_scale = float(loss_scale if loss_scale is not None else 1.0)
         self.device = torch.device("meta") if self.dry_run else torch.device(device or ("cuda:%d" % dist.local_rank()))
         self.train = bool(model.train and not model.force_fw_only and model.loss_blob is not None)
@@ -1412,6 +1480,11 @@ class Engine(object):
     # the raw comparison to ~1e-3, both settings measure the same raw table (median 1.5e-3 / 1.6e-3)
     # and 1.9e-5 / 3.8e-5 max on identical decisions -- at 151 against 171 clips/s on the same box.
     SPLIT_MATH = tuple(int(x) for x in os.environ.get("VLFB_SPLIT_MATH", "3,3").split(","))
+    if len(SPLIT_MATH) != 2 or SPLIT_MATH[0] not in (3, 6) or SPLIT_MATH[1] != 3:
+        raise ValueError("VLFB_SPLIT_MATH must be '3,3' or '6,3' (forward, backward terms), got %r"
+                         % os.environ.get("VLFB_SPLIT_MATH"))
+    # "mix" dtype: DGRAD contracts the fp16 gradient with TWO fp16 terms of the weight (22 bits; hip.MIX_W2) instead of one
+    MIX_W2 = os.environ.get("VLFB_MIX_W2", "1") != "0"
     # "split" dtype: conv epilogues also write the bf16 term planes of their outputs / input gradients, and the DGRAD / WGRAD
     # launches that find their operands in that form read them without expanding (ConvStep.bwd); tensors with more than
     # PLANES_MAX_NUMEL elements (the wide res2 / stem tensors: a second copy costs more HBM time than it saves) stay fp32-only
@@ -1501,6 +1574,11 @@ class Engine(object):
     def is_trainable(self, name):
         return name in self._trainable_set
 
+    def want_half(self, blob):
+        """the backward pass reads the VALUES of this blob: on the "mix" path it needs their fp16 copy"""
+        if self.mix and self.train and blob.root.kind == "act":
+            blob.root.need_half = True
+
     def need_workspace(self, nbytes):
         self._ws_bytes = max(self._ws_bytes, int(nbytes))
 
@@ -1522,7 +1600,7 @@ class Engine(object):
         return self._scratch_f32[:n]
 
     def scratch_act(self, n, dtype=None):
-        if dtype is not None and dtype != self.tdtype:
+        if dtype is not None and dtype != self._scratch_act.dtype:
             assert dtype == torch.float32
             return self.scratch_f32(n)
         assert n <= self._scratch_act.numel(), "scratch too small: %d > %d" % (n, self._scratch_act.numel())
@@ -1565,6 +1643,7 @@ class Engine(object):
         if self.train:
             self._plan_solver_buckets()
         self._plan_forward_branches()
+        self._plan_half_copies()
         self._drop_steps = [st for st in self.steps if isinstance(st, DropoutStep)]
         for k, st in enumerate(self._drop_steps):
             st.seed_slot = 1 + k
@@ -1700,10 +1779,15 @@ class Engine(object):
             else:
                 b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.int32)
             if self.train and b.slot.expected > 0:
-                b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=b.tensor.dtype)
+                gdt = self.btdtype if b.kind == "act" else b.tensor.dtype
+                b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=gdt)
+                if b.relu:
+                    self.want_half(b)             # the finished gradient is masked by the sign of the values
+            if b.need_half:
+                b.half = torch.zeros(b.tensor.numel(), device=dev, dtype=torch.float16)
             # "split" dtype: bf16 term planes next to the fp32 values of conv-produced tensors whose consumers are
             # MFMA-bound convs (the large res2 / stem tensors are HBM-bound: a second copy would only cost traffic)
-            if self.split and self.PLANES and self.train and b.kind == "act" and isinstance(b.producer, ConvStep) and \
+            if self.split and not self.mix and self.PLANES and self.train and b.kind == "act" and isinstance(b.producer, ConvStep) and \
                     not getattr(b, "pad_c", None) and b.numel <= self.PLANES_MAX_NUMEL and b.C % 8 == 0:
                 # ... and only around the gathered convs (3x3, 3x1x1): their WGRAD / DGRAD gain 1.4-1.7x from pre-split
                 # operands, the 1x1x1 layers gain nothing that pays for writing a second copy of their (wide) tensors
@@ -1718,7 +1802,7 @@ class Engine(object):
         self._scratch_f32 = torch.empty(max(self._sf32, 4), device=dev, dtype=torch.float32)
         biggest = max([b.tensor.numel() for b in self.all_blobs
                        if b.root is b and b.kind == "act" and b.tensor is not None] + [4])
-        self._scratch_act = torch.empty(max(self._sact, biggest), device=dev, dtype=self.tdtype)
+        self._scratch_act = torch.empty(max(self._sact, biggest), device=dev, dtype=self.btdtype)
         self._scratch_pl = torch.empty(max(self._spl, 8), device=dev, dtype=torch.bfloat16)
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -1936,9 +2020,11 @@ class Engine(object):
         if self._operand_version != self._pstate[0]:
             # parameters were changed through another engine that shares them (the train net's solver)
             self.refresh_operands(all_params=True)
+        for b in self._half_inputs:                 # "mix": fp16 copies of the fed blobs the backward reads (clip, bank)
+            hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
         if self.side is None or not self.FORWARD_BRANCHES or not self._fwd_side:
             for st in self.steps:
-                st.fwd()
+                self._fwd_step(st)
             return
         # The parameter-gradient stream is idle during forward: the projection shortcut of a stage's first block and
         # the pooled phi / g branch of a non-local block run on it, beside the bottleneck chain / the theta conv they
@@ -1953,11 +2039,34 @@ class Engine(object):
                 self.wait_event(stream, done[j])
             if on_side:
                 with torch.cuda.stream(self.side):
-                    st.fwd()
+                    self._fwd_step(st)
             else:
-                st.fwd()
+                self._fwd_step(st)
             if i in self._fwd_signal:
                 done[i] = self.record_event(stream)
+
+    def _fwd_step(self, st):
+        st.fwd()
+        for b in st._half_post:                     # "mix": outputs whose fp16 copy no conv epilogue wrote
+            hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
+
+    def _plan_half_copies(self):
+        """which fp16 copies (Blob.half, "mix" dtype) are made by a copy pass: behind the step that produced the values
+        (ConvStep writes them in its epilogue), or at the start of forward() for fed blobs"""
+        seen = set()
+        for st in self.steps:
+            st._half_post = []
+            if isinstance(st, ConvStep):
+                seen.update(id(o.root) for o in st.outputs)
+                continue
+            for o in list(st.outputs) + list(getattr(st, "aux_outputs", ())):
+                r = o.root
+                if r.half is not None and id(r) not in seen:
+                    seen.add(id(r))
+                    st._half_post.append(r)
+        self._half_inputs = [b for b in self.all_blobs if b.root is b and b.half is not None and id(b) not in seen]
+        for b in self._half_inputs:
+            assert getattr(b, "is_input", False), "blob %s has an fp16 copy that nothing writes" % b.name
 
     # independent forward branches on the second stream (Engine.forward)
     FORWARD_BRANCHES = True

@@ -12,6 +12,8 @@ import torch
 
 F32, BF16, F16 = 0, 1, 2
 SPLIT = 3                                           # weight-operand format of the split-bf16 path (vlfb.h VLFB_SPLIT)
+MIX, MIX_W2 = 4, 5                                  # ... of the "mix" path (split FPROP copy, fp16 DGRAD copy: plain / two terms)
+MIX_W2_SCALE = 1024.0                               # vlfb.h VLFB_MIX_W2_SCALE
 MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6     # vlfb_conv_desc.math
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
@@ -99,6 +101,7 @@ _SIGS = {
     "vlfb_ncthw_to_nthwc_wpad": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "vlfb_nthwc_to_ncthw": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_cast": (C.c_int, [_P, C.c_int, _P, C.c_int, _I64, _P]),
+    "vlfb_half_copy": (C.c_int, [_P, _P, _I64, _P]),
     "vlfb_transpose2d": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_copy2d": (C.c_int, [_P, _I64, _P, _I64, C.c_int, _I64, _I64, _P]),
     "vlfb_zero_f32": (C.c_int, [_P, _I64, _P]),
@@ -250,6 +253,8 @@ def conv_flops(d):
     """ALGORITHMIC flops (2*MAC of the convolution / GEMM the launch stands for; padding of the
     packed stem and masked-out taps of strided dgrads do not count)"""
     taps = d.kt * d.kh * d.kw
+    if d.dt == 0:            # "mix" DGRAD with two-term weights: the doubled tap dimension is not algorithmic work
+        taps //= 2
     batch = max(d.batch, 1)
     if d.mode == DGRAD:      # rows = conv input positions; source = conv output (N,Ts,Hs,Ws,Cs=Cout)
         return 2.0 * d.N * d.Ts * d.Hs * d.Ws * d.Cs * taps * d.Cn * batch
