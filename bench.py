@@ -68,8 +68,10 @@ def parse():
                     help="start the ranks through torch.distributed.run even for --gpus 1 (with VLFB_DIST_FORCE=1 the "
                          "one-rank job then runs the RCCL leg: communicator, bucketed all-reduce, stream hand-over)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched job (0 = pick a free one)")
-    ap.add_argument("--split-steps", type=int, default=5, help="timed steps of the extra split-bf16 parity-path measurement")
+    ap.add_argument("--split-steps", type=int, default=20, help="timed steps of the extra split-bf16 parity-path measurement")
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 parity-path measurement")
+    ap.add_argument("--mix-steps", type=int, default=20, help="timed steps of the extra 'mix' (split forward + fp16 backward) measurement")
+    ap.add_argument("--no-mix-line", action="store_true", help="skip the extra 'mix' path measurement")
     return ap.parse_args()
 
 
@@ -103,6 +105,22 @@ def kernel_source_hash():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()
+
+
+def parity_record(workload, dtype):
+    """measured gradient / output error of a path at the benchmarked clip size: the committed summary of
+    tests/test_model_gpu.py::test_full_size_clip_matches_oracle (profiles/parity_fullsize_<workload>.json), quoted only while
+    it was measured on the current kernel sources"""
+    path = os.path.join(ROOT, "profiles", "parity_fullsize_%s.json" % workload)
+    if not os.path.exists(path):
+        return {"source": "none: no committed full-size parity summary for this workload"}
+    rec = json.load(open(path))
+    if rec.get("csrc_sha256") != kernel_source_hash():
+        return {"source": "none: %s was measured on other kernel sources (csrc hash differs)" % os.path.relpath(path, ROOT)}
+    out = dict(rec["paths"].get(dtype, {}))
+    out["source"] = "%s (%s, %s; tests/test_model_gpu.py::test_full_size_clip_matches_oracle on these kernel sources)" % (
+        os.path.relpath(path, ROOT), rec["size"], rec["metric"])
+    return out
 
 
 def cpu_baseline(workload, frames, crop, rois_per_clip):
@@ -319,12 +337,17 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t2) / max(steps, 1)
         return {"value": round(clips / dt, 3), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": what,
-                "model_flops_utilisation": round(step_flops / dt / 1e12 / peak_tf, 4), "peak_tflops": peak_tf}
+                "model_flops_utilisation": round(step_flops / dt / 1e12 / peak_tf, 4), "peak_tflops": peak_tf,
+                "parity": parity_record(args.workload, dtype)}
 
-    if world == 1 and args.dtype not in ("fp32", "split"):
+    out["parity"] = parity_record(args.workload, args.dtype)
+    if world == 1 and args.dtype not in ("fp32", "split", "mix"):
         del eng
         torch.cuda.empty_cache()
         for key, dtype, steps, skip, what, peak_tf in (
+                ("mix_path", "mix", args.mix_steps, args.no_mix_line,
+                 "fp32 storage + split-bf16 forward products (3 MFMAs per product), fp16 backward (fp16 gradient storage, two-term "
+                 "fp16 weights in DGRAD, fp32 / split products around the non-local softmax)", 2500.0 * 3.0 / (3 + 2 + 1)),
                 ("split_path", "split", args.split_steps, args.no_split_line,
                  "fp32 storage + split-bf16 products on v_mfma_f32_16x16x32_bf16 (%d per product forward, %d backward)" % Engine.SPLIT_MATH,
                  2500.0 * 3.0 / (Engine.SPLIT_MATH[0] + 2 * Engine.SPLIT_MATH[1])),   # 1/3 of a step's FLOP are forward

@@ -284,6 +284,9 @@ int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows, int64_t c
                      vlfb_stream_t stream);
 int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dtype, int64_t rows,
                      int64_t cols, float scale, vlfb_stream_t stream);
+/* bwd with the probabilities in fp32 and ds in a 16-bit type (cols % 4 == 0, cols <= 2048): the "mix" path */
+int vlfb_softmax_bwd_p32(const float* dp, const float* p, void* ds, int ds_dtype, int64_t rows, int64_t cols,
+                         float scale, vlfb_stream_t stream);
 /* The same two operators FUSED with the batched product that feeds them (nonlocal_helper.py:94-121), so the fp32
  * score matrix never exists in memory:
  *   fwd:  prob[b][l1][l2] = softmax_l2(scale * sum_c theta[b][l1][c] * phi[b][l2][c])

@@ -70,7 +70,7 @@ CHECK_BLOBS = ["res_conv1_bn", "pool1", "res2_2_branch2c_bn", "pool2", "nonlocal
                "pool5", "pred", "prob"]
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "split", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "split", "mix", "bf16"])
 @pytest.mark.parametrize("preset", ["charades_r50_baseline", "ava_r50_lfb_nl", "charades_r50_lfb_nl"])
 def test_forward_backward_matches_oracle(preset, dtype):
     from oracle import model as om
@@ -79,7 +79,7 @@ def test_forward_backward_matches_oracle(preset, dtype):
     eng.backward()
     torch.cuda.synchronize()
     blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
-    tol_act = 1e-3 if dtype in ("fp32", "split") else 2e-2
+    tol_act = 1e-3 if dtype in ("fp32", "split", "mix") else 2e-2
     report = []
     for name in CHECK_BLOBS:
         if name not in blobs:
@@ -110,10 +110,10 @@ def test_forward_backward_matches_oracle(preset, dtype):
     assert worst_act < tol_act, report
     out_err = dict(report)
     assert out_err["prob"] < 1e-3 and out_err["loss"] < 1e-3, report
-    if dtype in ("fp32", "split"):
+    if dtype in ("fp32", "split", "mix"):
         # raw comparison: one ReLU / max-pool tie decided differently in fp32 and fp64 shifts every gradient upstream of
         # it (module docstring) -- regression gate only
-        assert med < 1e-3 and worst[0][1] < 5e-3, (med, worst)
+        assert med < (2e-3 if dtype == "mix" else 1e-3) and worst[0][1] < (1e-2 if dtype == "mix" else 5e-3), (med, worst)
         # the parity claim: on the SAME branches (oracle re-evaluated with this engine's discrete decisions) every
         # parameter gradient is inside the north-star bar
         dec = eng.discrete_decisions()
@@ -122,7 +122,16 @@ def test_forward_backward_matches_oracle(preset, dtype):
         cond = sorted(((rel(eng.fetch_grad(n), g2[n].numpy()), n) for n, _ in greport), reverse=True)
         print("[%s %s] gradients on identical ReLU / max-pool decisions: median %.2e worst %s"
               % (preset, dtype, float(np.median([x for x, _ in cond])), ["%s=%.2e" % (n, x) for x, n in cond[:4]]))
-        assert cond[0][0] < 1e-3, cond[:5]
+        if dtype == "mix":
+            # "mix" = the split forward (same decisions, same saved activations) + an fp16 backward: fp16 gradient storage,
+            # 11-bit MFMA operands (two-term weights in DGRAD, fp32 / split products around the non-local softmax).  Measured
+            # at this size: median 2.4e-4 .. 3.4e-4, p90 5.8e-4 .. 6.4e-4, max 1.1e-3 .. 1.2e-3 (conv1_w: sixteen fp16 roundings of
+            # the residual-stream gradient, scratch/r4/emu_hybrid.py).  The bar for EVERY tensor is the split path's; this path
+            # is held to: nine tensors in ten inside 1e-3, none beyond 2e-3.
+            ce = np.sort([x for x, _ in cond])
+            assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 1e-3 and cond[0][0] < 2e-3, cond[:5]
+        else:
+            assert cond[0][0] < 1e-3, cond[:5]
     else:
         assert p90 < 0.12 and worst[0][1] < 0.30, (p90, worst)
 
@@ -258,7 +267,8 @@ def test_full_size_clip_matches_oracle(preset):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     ref = None
     lines = []
-    for dtype in ("fp32", "split", "bf16"):
+    summary = {}
+    for dtype in ("fp32", "split", "mix", "fp16", "bf16"):
         cfg, model, eng, inputs, params, seed_fn = build(preset, dtype, FULL)
         eng.forward()
         eng.backward()
@@ -282,8 +292,10 @@ def test_full_size_clip_matches_oracle(preset):
         lines.append("== %s %s, 1 clip 32x224x224: activations/outputs (relative L2 vs fp64 oracle)" % (preset, dtype))
         lines += ["  %-28s %.3e" % x for x in acts]
         lines.append("   parameter gradients: median %.3e  p90 %.3e  max %.3e (%d tensors)" % (med, p90, mx, len(gerr)))
+        summary[dtype] = {"activations_max": max(v for k, v in acts if k not in ("loss",)), "prob": dict(acts)["prob"],
+                          "loss": dict(acts)["loss"], "grad_raw": {"median": med, "p90": p90, "max": mx}}
         cond = None
-        if dtype != "bf16":
+        if dtype not in ("bf16", "fp16"):
             # The same comparison on IDENTICAL BRANCHES: the fp64 oracle re-evaluated with this engine's ReLU sign patterns
             # and max-pool selections (a pre-activation within fp32 rounding of zero is decided either way; ONE such unit of
             # res5 under AVA's sparse loss gradient moves every upstream gradient by ~1e-3)
@@ -297,12 +309,22 @@ def test_full_size_clip_matches_oracle(preset):
                          "(%d ReLU units of the checked blobs decided differently): median %.3e  p90 %.3e  max %.3e"
                          % (nflip, float(np.median(ce)), float(ce[int(0.9 * (len(ce) - 1))]), float(ce[-1])))
             cd = dict(cond)
+            summary[dtype]["grad_identical_decisions"] = {"median": float(np.median(ce)), "p90": float(ce[int(0.9 * (len(ce) - 1))]),
+                                                          "max": float(ce[-1]), "worst": max(cond, key=lambda x: x[1])[0],
+                                                          "relu_units_decided_differently": nflip}
             lines += ["  %-44s %.3e   (same decisions: %.3e)" % (n, x, cd[n]) for n, x in sorted(gerr, key=lambda x: -x[1])]
         else:
             lines += ["  %-44s %.3e" % x for x in sorted(gerr, key=lambda x: -x[1])]
         print("\n".join(lines[-(len(gerr) + len(acts) + 3):][:len(acts) + 9]))
         a = dict(acts)
-        if dtype in ("fp32", "split"):
+        if dtype == "mix":
+            assert max(a.values()) < 1e-3, acts
+            # split forward + fp16 backward: measured median 3.7e-4 / 4.1e-4, p90 5.3e-4 / 6.2e-4, max 7.4e-4 (Charades) /
+            # 1.19e-3 (AVA: conv1_w and one non-local theta weight); raw median 1.7e-3 (AVA), as the split path's
+            assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 1e-3 and float(ce[-1]) < 2e-3, \
+                sorted(cond, key=lambda x: -x[1])[:5]
+            assert med < 5e-3 and mx < 3e-2, (med, mx)
+        elif dtype in ("fp32", "split"):
             assert max(a.values()) < 1e-3, acts
             # arithmetic parity (identical branches): EVERY gradient inside the north-star bar
             assert float(ce[-1]) < 1e-3, sorted(cond, key=lambda x: -x[1])[:5]
@@ -319,9 +341,20 @@ def test_full_size_clip_matches_oracle(preset):
         torch.cuda.empty_cache()
     out = os.environ.get("VLFB_PARITY_DIR")
     if out:
+        import hashlib, glob, json
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_fullsize_%s.txt" % preset), "w") as fh:
             fh.write("\n".join(lines) + "\n")
+        # machine-readable summary, stamped with the hash of the kernel sources it was measured on (bench.py quotes it
+        # next to each path's clips/s only while that hash is the current one)
+        h = hashlib.sha256()
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-long-term-feature-banks_amd", "csrc")
+        for f in sorted(glob.glob(os.path.join(csrc, "*.h*"))):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+        with open(os.path.join(out, "parity_fullsize_%s.json" % preset), "w") as fh:
+            json.dump({"preset": preset, "size": "1 clip 32x224x224", "metric": "relative L2 vs the fp64 oracle, per tensor",
+                       "csrc_sha256": h.hexdigest(), "paths": summary}, fh, indent=1)
 
 
 @pytest.mark.parametrize("preset", ["epic_verb_r50_lfb_nl", "epic_noun_r50_lfb_nl", "epic_verb_r50_baseline"])

@@ -861,9 +861,9 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ dp, const T* __rest
 }
 
 // backward with the row resident in registers (same conditions as softmax_fwd_rowreg_kernel)
-template <typename T, int NV>
+template <typename T, int NV, typename TD = T>
 __global__ void softmax_bwd_rowreg_kernel(const float* __restrict__ dp, const T* __restrict__ p,
-                                          T* __restrict__ ds, long long rows, int cols, float scale) {
+                                          TD* __restrict__ ds, long long rows, int cols, float scale) {
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -885,15 +885,15 @@ __global__ void softmax_bwd_rowreg_kernel(const float* __restrict__ dp, const T*
       }
     }
     dot = wave_sum(dot);
-    T* o = ds + r * cols;
+    TD* o = ds + r * cols;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
         const float a = scale * q[i].x * (d[i].x - dot), b = scale * q[i].y * (d[i].y - dot);
         const float e = scale * q[i].z * (d[i].z - dot), f = scale * q[i].w * (d[i].w - dot);
-        if (sizeof(T) == 4) *reinterpret_cast<float4*>(o + 4 * c) = make_float4(a, b, e, f);
-        else *reinterpret_cast<uint2*>(o + 4 * c) = make_uint2(Elem<T>::pack2(a, b), Elem<T>::pack2(e, f));
+        if (sizeof(TD) == 4) *reinterpret_cast<float4*>(o + 4 * c) = make_float4(a, b, e, f);
+        else *reinterpret_cast<uint2*>(o + 4 * c) = make_uint2(Elem<TD>::pack2(a, b), Elem<TD>::pack2(e, f));
       }
     }
   }
@@ -1281,6 +1281,20 @@ extern "C" int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows
     VLFB_WITH_T16(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (T16*)p, (long long)rows, (int)cols, scale));
   else return set_error(VLFB_ERR_ARG, "softmax_fwd: bad dtype");
   return check_launch("softmax_fwd");
+}
+// probabilities in fp32, ds in a 16-bit type (the "mix" path: the softmax Jacobian cancels the common part of dP, so P
+// is read at full precision and only the result is rounded)
+extern "C" int vlfb_softmax_bwd_p32(const float* dp, const float* p, void* ds, int ds_dtype, int64_t rows,
+                                    int64_t cols, float scale, vlfb_stream_t stream) {
+  VLFB_REQUIRE(dp && p && ds && rows > 0 && cols > 0, "softmax_bwd_p32: bad args");
+  VLFB_REQUIRE(is16(ds_dtype) && cols % 4 == 0 && cols <= 64 * 4 * 8, "softmax_bwd_p32: 16-bit ds and cols %% 4 == 0, cols <= 2048");
+  const int grid = grid_for(rows * 64, 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cols <= 64 * 4 * 4)
+    VLFB_WITH_T16(ds_dtype, hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<float, 4, T16>), dim3(grid), dim3(256), 0, st, dp, p, (T16*)ds, (long long)rows, (int)cols, scale));
+  else
+    VLFB_WITH_T16(ds_dtype, hipLaunchKernelGGL((softmax_bwd_rowreg_kernel<float, 8, T16>), dim3(grid), dim3(256), 0, st, dp, p, (T16*)ds, (long long)rows, (int)cols, scale));
+  return check_launch("softmax_bwd_p32");
 }
 extern "C" int vlfb_softmax_bwd(const float* dp, const void* p, void* ds, int dtype, int64_t rows,
                                 int64_t cols, float scale, vlfb_stream_t stream) {

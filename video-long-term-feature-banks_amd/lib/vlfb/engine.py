@@ -65,6 +65,7 @@ class Blob(object):
         self.planes = None            # "split" dtype: bf16 term planes [2][numel] of the values, written by the producing conv
         self.half = None              # "mix" dtype: fp16 copy of the values for the fp16 backward (root only; Engine.want_half)
         self.need_half = False
+        self.grad_f32 = False         # "mix" dtype: the gradient of this blob is kept in fp32 (theta / phi / g of a non-local block)
 
     @property
     def numel(self):
@@ -243,6 +244,9 @@ class ConvStep(Step):
                                  **planes, **geom)
         self.d_d = None
         self.w2 = False
+        self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
+        if self.bwd_f32:
+            eng.need_scratch_act(self.out.numel)
         if self.x.needs_grad and not self.x.detached:
             assert not self.stem
             dg = dict(geom)
@@ -270,8 +274,15 @@ class ConvStep(Step):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
                                      Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
                                      math=mb, **geom)
+            # "mix": the gradient arriving at `out` is fp32 (Blob.grad_f32): WGRAD as split-bf16 products on the fp32 operands
+            self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
+            if self.bwd_f32:
+                self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
+                                         Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
+                                         math=hip.MATH_BF16X3, **geom)
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
-            eng.want_half(self.x)
+            if not self.bwd_f32:
+                eng.want_half(self.x)
         # Pre-split operands ("split" dtype, Engine.PLANES): a conv epilogue can write the bf16 term planes of its output
         # next to the fp32 values (o_planes), and DGRAD / WGRAD launches that find their activation / gradient operands in
         # that form spend no VALU on the expansion (a_planes / p_planes).  Variants are built lazily (_pl_desc).
@@ -381,14 +392,20 @@ class ConvStep(Step):
 
     def bwd(self):
         eng = self.eng
-        g = self.out_grad()
+        g = g_w = self.out_grad()
+        if self.bwd_f32:
+            # fp32 gradient ("mix", non-local theta / phi / g): WGRAD and the bias sum read it as it is, DGRAD its fp16 copy
+            g_w = g
+            if self.d_d is not None:
+                g = eng.scratch_act(self.out.numel)
+                hip.call("vlfb_cast", hip.ptr(g_w), hip.F32, hip.ptr(g), eng.bcode, self.out.numel)
         gp = self.out.root.slot.value_planes()         # term planes of the finished output gradient, or None
         if self.residual is not None and self.residual.needs_grad and not self.residual.detached:
             self.residual.root.slot.contribute_alias(g)
         if self.d_w is not None or (self.cbname and eng.is_trainable(self.cbname)):
             # weight / bias gradients are leaves of the backward graph: they run on the side stream
             # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
-            eng.issue_param_grads(lambda: self._param_grads(g, gp))
+            eng.issue_param_grads(lambda: self._param_grads(g_w, gp))
         if self.d_d is not None:
             # the gradient operand as planes when it has them and this launch can take them (plain rows or taps that
             # span whole k-tiles at unit stride); the input gradient's planes when this is its last contribution
@@ -418,8 +435,8 @@ class ConvStep(Step):
                 d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2)
                 hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
             else:
-                hip.conv_run(self.d_w, self.x.bstorage(), None, g, eng.grad_tensor(self.wname), rowscale=s,
-                             workspace=eng.workspace)
+                hip.conv_run(self.d_w, self.x.storage() if self.bwd_f32 else self.x.bstorage(), None, g,
+                             eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
             if self.stem:   # keep the zero padding of the packed stem weight exactly zero
                 gw = eng.grad_tensor(self.wname)
                 hip.call("vlfb_add", hip.ptr(gw), None, hip.ptr(gw), hip.ptr(eng.stem_mask), hip.F32,
@@ -428,11 +445,11 @@ class ConvStep(Step):
             Cout = self.out.shape[1]
             gb = eng.grad_tensor(self.cbname)
             if self.sname:
-                hip.call("vlfb_colsum", hip.ptr(g), eng.bcode, self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
+                hip.call("vlfb_colsum", hip.ptr(g), hip.dtype_code(g.dtype), self.out.rows, Cout, Cout, hip.ptr(self.cb_tmp), 0)
                 hip.call("vlfb_affine_nd_bwd", hip.ptr(self.cb_tmp), hip.ptr(eng.param_tensor(self.sname)),
                          hip.ptr(gb), 1, Cout, 1)
             else:
-                hip.call("vlfb_colsum", hip.ptr(g), eng.bcode, self.out.rows, Cout, Cout, hip.ptr(gb), 0)
+                hip.call("vlfb_colsum", hip.ptr(g), hip.dtype_code(g.dtype), self.out.rows, Cout, Cout, hip.ptr(gb), 0)
             if self.gscale != 1.0:
                 hip.call("vlfb_scale_inplace", hip.ptr(gb), gb.numel(), 1.0 / self.gscale)
 
@@ -522,6 +539,12 @@ class AttentionStep(Step):
         self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mf, **pl)
         self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci, math=mf, **pl)
         self.d_dp = gemm(dtype=bcode, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mb, **bpl)
+        # "mix": dP = dY . g^T as split-bf16 products on fp32 operands (dY through a cast) and the softmax backward on the
+        # fp32 probabilities -- what follows cancels the part of dP that is common to a row
+        self.precise = bool(eng.mix and eng.MIX_NL_F32)
+        if self.precise:
+            self.d_dp = gemm(dtype=hip.F32, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2,
+                             math=hip.MATH_BF16X3, **pl)
         if eng.split:
             eng.need_scratch_planes(3 * B * L2 * Ci)
         # fp16: dS = scale * P o (dP - <dP, P>) is ~ 1 / L2 of an activation gradient and would leave the fp16
@@ -531,22 +554,25 @@ class AttentionStep(Step):
         # ... and the gradients of theta / phi themselves (again ~ 1 / L2 of an activation gradient) are stored
         # times Blob.grad_scale (set at lowering), which the theta / phi convs divide out (ConvStep.gscale)
         gs_th, gs_ph = float(self.theta.root.grad_scale), float(self.phi.root.grad_scale)
-        self.d_dth = gemm(dtype=bcode, out_dtype=bcode, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
+        o_th = hip.F32 if self.theta.root.grad_f32 else bcode
+        o_ph = hip.F32 if self.phi.root.grad_f32 else bcode
+        o_g = hip.F32 if self.g.root.grad_f32 else bcode
+        self.d_dth = gemm(dtype=bcode, out_dtype=o_th, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
                           alpha=gs_th / self.ds_scale, math=mb, **bpl)
         # contract over L1: out[L2][Ci] = sum_l P[l][L2] * A[l][Ci]
-        self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=bcode, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
+        self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=o_g, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                   Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
                                   o_bstride=L2 * Ci, splits=1, math=mb)
-        self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=bcode, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
+        self.d_tn_phi = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=o_ph, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                       Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
                                       o_bstride=L2 * Ci, splits=1, alpha=gs_ph / self.ds_scale, math=mb)
         # 16-bit paths: scores + row softmax (and their backward) in one kernel each, the fp32 score matrix never
         # exists (csrc/vlfb_attn.hip) -- per direction, and only where the library reports the fused kernel as
         # measured faster; otherwise GEMM -> fp32 scratch -> softmax kernels
         self.fused_fwd = bool(hip.lib().vlfb_attn_scores_supported(code, L1, L2, Ci) & hip.ATTN_FWD_FASTER)
-        self.fused_bwd = bool(hip.lib().vlfb_attn_scores_supported(bcode, L1, L2, Ci) & hip.ATTN_BWD_FASTER)
+        self.fused_bwd = bool(hip.lib().vlfb_attn_scores_supported(bcode, L1, L2, Ci) & hip.ATTN_BWD_FASTER) and not self.precise
         if not (self.fused_fwd and self.fused_bwd):
-            eng.need_scratch_f32(B * L1 * L2)
+            eng.need_scratch_f32(B * L1 * L2 + (B * L1 * Ci if self.precise else 0))
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
 
     def _planes(self, src, nplanes, transpose):
@@ -596,7 +622,12 @@ class AttentionStep(Step):
                      eng.bcode, B, L2, Ci, Ci, self.scale)
             return
         P = self.prob.bstorage()
-        if not self.fused_bwd:
+        if self.precise:
+            f32 = eng.scratch_f32(B * L1 * L2 + B * L1 * Ci)
+            dP, dY32 = f32[:B * L1 * L2], f32[B * L1 * L2:]
+            hip.call("vlfb_cast", hip.ptr(dY), eng.bcode, hip.ptr(dY32), hip.F32, B * L1 * Ci)
+            hip.conv_run(self.d_dp, dY32, self._planes(self.g.storage(), 2, False), None, dP)
+        elif not self.fused_bwd:
             dP = eng.scratch_f32(B * L1 * L2)
             hip.conv_run(self.d_dp, dY, self._planes(self.g.storage(), 2, False) if self.bsplit else self.g.bstorage(), None, dP)
         gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
@@ -606,6 +637,9 @@ class AttentionStep(Step):
         phT = act[B * L1 * L2:]
         if self.fused_bwd:
             hip.call("vlfb_attn_scores_bwd", hip.ptr(dY), self.g.bptr(), hip.ptr(P), hip.ptr(dS), eng.bcode, B, L1, L2, Ci,
+                     self.scale * self.ds_scale)
+        elif self.precise:
+            hip.call("vlfb_softmax_bwd_p32", hip.ptr(dP), self.prob.ptr(), hip.ptr(dS), eng.bcode, B * L1, L2,
                      self.scale * self.ds_scale)
         else:
             hip.call("vlfb_softmax_bwd", hip.ptr(dP), hip.ptr(P), hip.ptr(dS), eng.bcode, B * L1, L2,
@@ -1247,7 +1281,14 @@ class Lowering(object):
         B, Ci, L1 = theta.shape
         L2 = phi.shape[2]
         single = (L1 == 1)
-        if not single and self.eng.btdtype == torch.float16:
+        if not single and self.eng.mix and self.eng.MIX_NL_F32:
+            # "mix": the softmax Jacobian cancels the common part of dP, and the weight gradients of theta / phi sum those
+            # differences over all positions -- the ill-conditioned tensors of the model (the worst of every path).  Their
+            # gradients stay in fp32 and their weight gradients use split-bf16 products (ConvStep.bwd_f32).
+            for t in (theta, phi, g):
+                if isinstance(t.root.producer, ConvStep) and t.root.producer.out is t.root:
+                    t.root.grad_f32 = True
+        elif not single and self.eng.btdtype == torch.float16:
             # fp16: d theta and d phi are about 1 / L2 of a normal activation gradient (they pass the softmax
             # Jacobian): keep them times a power of two so that they stay in the fp16 normal range
             for t in (theta, phi):
@@ -1485,6 +1526,9 @@ class Engine(object):
                          % os.environ.get("VLFB_SPLIT_MATH"))
     # "mix" dtype: DGRAD contracts the fp16 gradient with TWO fp16 terms of the weight (22 bits; hip.MIX_W2) instead of one
     MIX_W2 = os.environ.get("VLFB_MIX_W2", "1") != "0"
+    # "mix" dtype: gradients of theta / phi / g of the non-local blocks in fp32, their weight gradients and the dP product of
+    # the attention backward as split-bf16 products, the softmax backward on the fp32 probabilities
+    MIX_NL_F32 = os.environ.get("VLFB_MIX_NL_F32", "1") != "0"
     # "split" dtype: conv epilogues also write the bf16 term planes of their outputs / input gradients, and the DGRAD / WGRAD
     # launches that find their operands in that form read them without expanding (ConvStep.bwd); tensors with more than
     # PLANES_MAX_NUMEL elements (the wide res2 / stem tensors: a second copy costs more HBM time than it saves) stay fp32-only
@@ -1779,7 +1823,7 @@ class Engine(object):
             else:
                 b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.int32)
             if self.train and b.slot.expected > 0:
-                gdt = self.btdtype if b.kind == "act" else b.tensor.dtype
+                gdt = self.btdtype if (b.kind == "act" and not b.grad_f32) else b.tensor.dtype
                 b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=gdt)
                 if b.relu:
                     self.want_half(b)             # the finished gradient is masked by the sign of the values

@@ -116,6 +116,7 @@ _SIGS = {
     "vlfb_avgpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P]),
     "vlfb_softmax_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_softmax_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
+    "vlfb_softmax_bwd_p32": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_attn_scores_supported": (C.c_int, [C.c_int, _I64, _I64, _I64]),
     "vlfb_attn_scores_fwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
     "vlfb_attn_scores_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
