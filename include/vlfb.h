@@ -166,6 +166,11 @@ void vlfb_conv_desc_init(vlfb_conv_desc* d);
 /* bytes of fp32 workspace vlfb_conv_run needs for this desc (0 unless a split WGRAD) */
 int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d);
 
+/* Text description of what vlfb_conv_run launches for this descriptor -- kernel family, element type, tile, split count
+ * ("nt8 bf16 256x256", "tn_tr f16 128x128 splits=24", ...).  The planner is a pure function of the descriptor.  buf: at
+ * least 96 bytes. */
+int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64_t buf_bytes);
+
 /* One scratch query for every entry point that takes caller-owned scratch (the caller owns every
  * buffer, the library never allocates).  `arg` is the op's descriptor or dimension list; returns bytes, < 0 on error.
  *   VLFB_WS_CONV           arg = const vlfb_conv_desc*            `workspace` of vlfb_conv_run (= vlfb_conv_workspace_bytes)

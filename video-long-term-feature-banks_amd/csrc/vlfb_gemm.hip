@@ -1654,6 +1654,37 @@ extern "C" int64_t vlfb_conv_workspace_bytes(const vlfb_conv_desc* d) {
   return pl.ws_elems * 4;
 }
 
+// Which kernel family, tile shape and split count the library runs for a descriptor (the planner is a pure function
+// of the descriptor, so this IS what vlfb_conv_run launches; R / Mask only decide between the direct stem FPROP and the
+// tiled kernel).  Test / bench support: "the plan under test is the plan under the stopwatch".
+extern "C" int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64_t buf_bytes) {
+  VLFB_REQUIRE(d && buf && buf_bytes >= 96, "conv_plan_describe: buf of at least 96 bytes");
+  Plan pl;
+  const int rc = cached_plan(d, &pl);
+  if (rc != VLFB_OK) return rc;
+  const bool h16 = is16(d->dtype);
+  const char* dt = d->dtype == VLFB_F32 ? (pl.sp ? (pl.sp == 3 ? "f32x6" : "f32x3") : "f32") : d->dtype == VLFB_F16 ? "f16" : "bf16";
+  if (d->mode == VLFB_CONV_WGRAD) {
+    const char* fam = pl.sp ? (pl.sp_pl ? "tn_tr_planes" : "tn_split")
+                      : (h16 && pl.stem) ? "stem_wgrad" : (h16 && pl.rows == 2) ? "wgrad_rows_fat" : (h16 && pl.rows) ? "wgrad_rows"
+                      : (h16 && pl.tn8) ? "tn8" : (h16 && pl.tn_tr) ? "tn_tr" : "tn";
+    snprintf(buf, (size_t)buf_bytes, "%s %s %dx%d splits=%d", fam, dt, pl.bm, pl.bn, pl.splits);
+  } else {
+    const char* fam;
+    int bm = pl.bm, bn = pl.bn;
+    if (pl.sp) fam = pl.sp_pl ? "nt_planes" : "nt_split";
+    else if (h16 && pl.skinny) fam = "nt_skinny";
+    else if (h16 && d->mode == VLFB_CONV_FPROP && pl.stemf) fam = "stem_fprop";
+    else if (h16 && pl.rows64) fam = "conv_rows64";
+    else if (h16 && pl.nts) fam = "nt_stream";
+    else if (h16 && pl.nt8) { fam = "nt8"; bm = pl.nt8_bm; bn = pl.nt8; }
+    else fam = "nt";
+    snprintf(buf, (size_t)buf_bytes, "%s %s %dx%d%s%s%s", fam, dt, bm, bn, pl.ut ? " ut" : "", pl.gp.s2 ? " classes" : "",
+             pl.pre ? " pre" : "");
+  }
+  return VLFB_OK;
+}
+
 extern "C" int64_t vlfb_query_workspace(int op, const void* arg) {
   if (!arg) { set_error(VLFB_ERR_ARG, "query_workspace: arg is required"); return -1; }
   switch (op) {

@@ -2270,6 +2270,22 @@ class Engine(object):
                                      "wprep": None if self.dry_run else self._wprep_table(convs),
                                      "bias_steps": bias_steps})
 
+    def plan_table(self):
+        """[(step, role, launch tag, kernel family / tile / splits)] for every implicit-GEMM launch of a step, from the
+        library's planner (a pure function of the descriptor: what the table says is what runs).  Test / bench support."""
+        rows = []
+        for st in self.steps:
+            if isinstance(st, ConvStep):
+                descs = (("fprop", st.d_f), ("dgrad", st.d_d), ("wgrad", st.d_w))
+            elif isinstance(st, AttentionStep) and not st.single:
+                descs = (("scores", st.d_s), ("p.g", st.d_y), ("dP", st.d_dp), ("dtheta", st.d_dth), ("dg", st.d_tn), ("dphi", st.d_tn_phi))
+            else:
+                continue
+            for role, d in descs:
+                if d is not None and (self.train or role in ("fprop", "scores", "p.g")):
+                    rows.append((st.name(), role, hip.conv_tag(d), hip.conv_plan(d)))
+        return rows
+
     def set_lr(self, lr):
         self.lr = float(lr)
 

@@ -95,6 +95,7 @@ _SIGS = {
     "vlfb_conv_desc_init": (None, [C.POINTER(ConvDesc)]),
     "vlfb_conv_workspace_bytes": (_I64, [C.POINTER(ConvDesc)]),
     "vlfb_query_workspace": (_I64, [C.c_int, C.c_void_p]),
+    "vlfb_conv_plan_describe": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, _I64]),
     "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_conv_run_planes": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
@@ -235,6 +236,13 @@ def conv_workspace_bytes(d):
     if n < 0:
         raise VlfbError("conv_workspace_bytes: %s" % lib().vlfb_last_error().decode())
     return n
+
+
+def conv_plan(d):
+    """kernel family / tile / splits the library runs for this descriptor (vlfb_conv_plan_describe)"""
+    buf = C.create_string_buffer(128)
+    _check(lib().vlfb_conv_plan_describe(C.byref(d), buf, 128), "vlfb_conv_plan_describe")
+    return buf.value.decode()
 
 
 WS_CONV, WS_MAXPOOL_ARGMAX, WS_FBO_ATTN_BWD, WS_ATTN_SCORES, WS_BN = 0, 1, 2, 3, 4
