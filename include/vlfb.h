@@ -145,8 +145,11 @@ typedef struct vlfb_conv_desc {
   int32_t algo;       /* kernel family: 0 = library chooses, 1 = 128x128 tiles (one barrier per k-tile),
                          2 = 256-row phase-pipelined tiles (bf16, MFMA-bound shapes; error if the
                          problem is not eligible), 3 = weight-resident streaming kernel (FPROP / DGRAD of
-                         HBM-bound layers whose weight operand fits LDS; error if not eligible).  All
-                         families give bit-identical results. */
+                         HBM-bound layers whose weight operand fits LDS; error if not eligible).  The
+                         tile families (1, 2, 3, the direct-convolution kernels AUTO may pick) give bit-identical
+                         results; the one exception under AUTO is the skinny kernel for plain NT products of at
+                         most 64 rows (the FBO head on one row per RoI), whose four waves split K: same products,
+                         another fp32 summation order (VLFB_SKINNY=0 or algo = 1 restores the tile order). */
   int32_t math;       /* VLFB_MATH_* (dtype VLFB_F32 only) */
   int64_t b_pstride;  /* math != 0, FPROP / DGRAD: elements between the bf16 term planes of B (0 = batch * Cn * ldb) */
   /* math != 0: activations / gradients that some earlier launch already wrote as bf16 term planes next to their fp32

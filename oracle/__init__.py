@@ -11,7 +11,9 @@ in Caffe2 (pytorch/pytorch `caffe2/` tree, version unpinned by INSTALL.md:24-31)
 here from its published semantics with torch-CPU functional ops in fp64 /
 fp32 plus a hand-written RoIAlign and sigmoid cross-entropy.  What pins this oracle instead:
 structural checks against the reference's own builders (parameter names/shapes/counts, MAC
-counts: tests/test_oracle_structure.py), two independent RoIAlign implementations that must
-agree bit-exactly on every integer decision, and committed golden vectors produced by
-oracle/make_golden.py (tests/golden/).
+counts), two independent RoIAlign implementations that must agree bit-exactly on every integer
+decision, closed forms of the losses and committed golden vectors produced by oracle/make_golden.py
+(tests/golden/) -- all in tests/test_oracle.py; the one operator the reference ships itself, AffineNd,
+is held bit for bit to the reference's own .cu compiled in place (oracle/build_ref.py,
+tests/test_ref_affine_gpu.py).
 """

@@ -79,6 +79,7 @@ def test_eight_clip_step_equals_the_one_clip_steps(dtype):
     eng8.forward()
     eng8.backward()
     torch.cuda.synchronize()
+    launched8 = eng8.plan_table(launched=True)        # ("split": with the operand-plane variants the pass really used)
     fwd8 = {n: eng8.fetch(n) for n in BLOBS + ROW_BLOBS}
     grad8 = {n: eng8.fetch_grad(n) for n in eng8.trainable}
     loss8 = float(eng8.fetch("loss").reshape(-1)[0])
@@ -91,8 +92,8 @@ def test_eight_clip_step_equals_the_one_clip_steps(dtype):
     cfg, model_b = _model(CLIPS)
     bench_table = _engine(model_b, dtype, batch, None, dry_run=True).plan_table()
     assert [r[2:] for r in table8] == [r[2:] for r in bench_table], "the tested plan is not the benchmarked plan"
-    fams = collections.Counter(r[3].split()[0] for r in table8)
-    slabs = [int(r[3].split("splits=")[1]) for r in table8 if "splits=" in r[3]]
+    fams = collections.Counter(r[3].split()[0] for r in launched8)
+    slabs = [int(r[3].split("splits=")[1]) for r in launched8 if "splits=" in r[3]]
     print("\n[%s] kernel families of the 8-clip plan: %s; split-K launches: %d (up to %d slabs)"
           % (dtype, dict(fams), sum(1 for s_ in slabs if s_ > 1), max(slabs)))
     if dtype in ("fp16", "bf16"):
@@ -112,7 +113,7 @@ def test_eight_clip_step_equals_the_one_clip_steps(dtype):
         with open(os.path.join(out, "bench_plan_%s.txt" % dtype), "w") as fh:
             fh.write("# kernel family / tile / split count of every implicit-GEMM launch of the benchmarked step "
                      "(ava_r50_lfb_nl, 8 clips 32x224x224, %d RoIs, dtype %s): Engine.plan_table()\n" % (R, dtype))
-            for row in table8:
+            for row in launched8:
                 fh.write("%-44s %-7s %-64s %s\n" % row)
 
     # ---- one clip at a time -----------------------------------------------------------------------------------------
@@ -159,7 +160,13 @@ def test_eight_clip_step_equals_the_one_clip_steps(dtype):
             gsum[n] += eng.fetch_grad(n).astype(np.float64)
     assert abs(loss_sum - loss8) < 2e-6 * abs(loss8), (loss_sum, loss8)
     gmax = max(np.linalg.norm(g) for g in gsum.values())
-    errs = sorted(((rel(grad8[n], gsum[n]), n) for n in gsum if np.linalg.norm(gsum[n]) > 1e-9 * gmax), reverse=True)
+    # a bias on phi shifts every logit of a softmax row equally: its gradient is mathematically zero and what the engines
+    # hold is rounding noise (absolute check, as in test_model_gpu.py)
+    zero = [n for n in gsum if n.endswith("_phi_b")]
+    for n in zero:
+        assert np.linalg.norm(grad8[n]) < 1e-3 * gmax and np.linalg.norm(gsum[n]) < 1e-3 * gmax, n
+    errs = sorted(((rel(grad8[n], gsum[n]), n) for n in gsum if n not in zero and np.linalg.norm(gsum[n]) > 1e-9 * gmax),
+                  reverse=True)
     e = np.array([x for x, _ in errs])
     print("[%s] 8-clip gradients vs the sum of the 1-clip gradients: median %.2e p90 %.2e max %.2e (%s)"
           % (dtype, np.median(e), np.sort(e)[int(0.9 * (len(e) - 1))], e[0], errs[0][1]))

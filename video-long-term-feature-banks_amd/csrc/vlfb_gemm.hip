@@ -1138,6 +1138,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || (d->dtype == VLFB_F32 && d->out_dtype == VLFB_F32),
                "conv: split-bf16 math needs fp32 operands and an fp32 output");
   VLFB_REQUIRE(d->math != VLFB_MATH_BF16X6 || d->mode != VLFB_CONV_WGRAD, "conv: WGRAD has no BF16X6 form (use BF16X3)");
+  VLFB_REQUIRE(!d->accumulate || d->mode == VLFB_CONV_WGRAD, "conv: accumulate (O += ...) is a WGRAD epilogue");
   pl->sp = d->math == VLFB_MATH_BF16X6 ? 3 : d->math == VLFB_MATH_BF16X3 ? 2 : 0;
   pl->sp_kind = 0;
   VLFB_REQUIRE(pl->sp || (!d->a_planes && !d->p_planes && !d->o_planes), "conv: term planes belong to split-bf16 math");

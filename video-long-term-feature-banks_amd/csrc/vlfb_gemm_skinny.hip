@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(const GP p) {
 }  // namespace
 
 bool skinny_nt_ok(const GP& gp, int dtype, long long batch, bool ident) {
-  return ident && batch == 1 && is16(dtype) && gp.M <= 64 && gp.K % 32 == 0 && gp.K >= 128 && gp.lda % 8 == 0 && gp.ldb % 8 == 0;
+  // (accumulate is a WGRAD-only epilogue: the NT epilogue here never reads O, so a descriptor that asks for it is not taken)
+  return ident && batch == 1 && is16(dtype) && !gp.accumulate && gp.M <= 64 && gp.K % 32 == 0 && gp.K >= 128 && gp.lda % 8 == 0 && gp.ldb % 8 == 0;
 }
 
 int launch_skinny_nt(const GP& gp, int dtype, bool out_f32, hipStream_t s) {

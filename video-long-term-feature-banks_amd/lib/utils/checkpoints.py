@@ -162,9 +162,13 @@ def convert_model(model_path):
         raise error
     if not ok:
         raise RuntimeError("convert_model: rank 0 failed to convert %r" % (model_path,))
-    if not os.path.exists(out_path):
-        raise RuntimeError("convert_model: %s was written by rank 0 but is not visible on rank %d (the checkpoint "
-                           "directory must be shared by all ranks)" % (out_path, dist.rank()))
+    # ... and whether EVERY rank sees the file, again before anyone moves on: a rank that raised alone would leave the others
+    # in their next collective (broadcast_parameters) forever
+    seen = os.path.exists(out_path)
+    if not dist.all_ok(seen):
+        raise RuntimeError("convert_model: %s was written by rank 0 but is not visible on every rank (here, rank %d: %s); "
+                           "the checkpoint directory must be shared by all ranks"
+                           % (out_path, dist.rank(), "visible" if seen else "NOT visible"))
     return out_path
 
 

@@ -287,6 +287,7 @@ class ConvStep(Step):
         # next to the fp32 values (o_planes), and DGRAD / WGRAD launches that find their activation / gradient operands in
         # that form spend no VALU on the expansion (a_planes / p_planes).  Variants are built lazily (_pl_desc).
         self._pl = {}
+        self._ran = {}
         # the stem reads the clip: its term planes are made once per forward pass by a split pass (3 planes for the
         # six-product FPROP, of which the WGRAD reads the first two next to a split pass over its output gradient)
         self.x_planes = self.g_planes = None
@@ -363,6 +364,7 @@ class ConvStep(Step):
             for k, v in planes.items():
                 setattr(d, k, v)
             self._pl[key] = d
+        self._ran[id(base)] = d           # the variant of `base` that was launched last (Engine.plan_table(launched=True))
         return d
 
     def fwd(self):
@@ -1590,20 +1592,20 @@ class Engine(object):
         if stream is None:
             stream = torch.cuda.current_stream()
         ev.record(stream)
-        if hip.TRACE is not None:
-            hip.TRACE.append((ev.record, (stream,), "event record"))
+        if hip.tracing() is not None:
+            hip.tracing().append((ev.record, (stream,), "event record"))
         return ev
 
     def wait_event(self, stream, ev):
         stream.wait_event(ev)
-        if hip.TRACE is not None:
-            hip.TRACE.append((stream.wait_event, (ev,), "stream wait"))
+        if hip.tracing() is not None:
+            hip.tracing().append((stream.wait_event, (ev,), "stream wait"))
 
     def wait_stream(self, other):
         cur = torch.cuda.current_stream()
         cur.wait_stream(other)
-        if hip.TRACE is not None:
-            hip.TRACE.append((cur.wait_stream, (other,), "stream join"))
+        if hip.tracing() is not None:
+            hip.tracing().append((cur.wait_stream, (other,), "stream join"))
 
     def join_side_stream(self):
         """make the main stream wait for every parameter-gradient kernel issued so far"""
@@ -2163,6 +2165,8 @@ class Engine(object):
         for b in self.all_blobs:
             if b.root is b and b.slot is not None:
                 b.slot.reset()
+        del self._wq[:]               # (parameter-gradient launches a failed backward() left queued: WGRAD_LAG)
+        self._bwd_index = 0
         if self.comm is not None:
             self.comm.begin()
         eager = self._eager_lr is not None
@@ -2270,9 +2274,10 @@ class Engine(object):
                                      "wprep": None if self.dry_run else self._wprep_table(convs),
                                      "bias_steps": bias_steps})
 
-    def plan_table(self):
+    def plan_table(self, launched=False):
         """[(step, role, launch tag, kernel family / tile / splits)] for every implicit-GEMM launch of a step, from the
-        library's planner (a pure function of the descriptor: what the table says is what runs).  Test / bench support."""
+        library's planner (a pure function of the descriptor: what the table says is what runs).  launched=True: with the
+        operand-plane variants ("split" dtype) the last forward / backward pass actually used.  Test / bench support."""
         rows = []
         for st in self.steps:
             if isinstance(st, ConvStep):
@@ -2283,6 +2288,8 @@ class Engine(object):
                 continue
             for role, d in descs:
                 if d is not None and (self.train or role in ("fprop", "scores", "p.g")):
+                    if launched and isinstance(st, ConvStep):
+                        d = st._ran.get(id(d), d)
                     rows.append((st.name(), role, hip.conv_tag(d), hip.conv_plan(d)))
         return rows
 
@@ -2431,12 +2438,12 @@ class Engine(object):
         if self._trace is None or self._trace_key != key:
             self._trace, self._trace_key = None, None
             self._dev_scalars = True
-            hip.TRACE = rec = []
+            rec = hip.trace_begin()                  # (this thread's calls only)
             try:
                 self._train_step_streams()           # runs the step for real while recording it
             finally:
                 self._dev_scalars = False
-                hip.TRACE = None
+                hip.trace_end()
             self._trace_losses = [st for st in self.steps if isinstance(st, LossStep)]
             for st in self._trace_losses:
                 st.ring_push()

@@ -198,9 +198,36 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# When a list, every stream-ordered call is also appended to it as (function, arguments incl. the stream, name):
-# Engine.train_step records one step this way and replays the list (Engine.STEP_TRACE).
+# When a list, every stream-ordered call OF THE RECORDING THREAD is also appended to it as (function, arguments incl. the
+# stream, name): Engine.train_step records one step this way and replays the list (Engine.STEP_TRACE).  Calls of other
+# threads (a loader thread preprocessing the next clip, a bank sampler) are never recorded: replaying them with their frozen
+# pointers every step would corrupt memory silently.  Use trace_begin / trace_end.
 TRACE = None
+_TRACE_THREAD = None
+
+
+def trace_begin():
+    """start recording the calls of THIS thread; returns the list"""
+    global TRACE, _TRACE_THREAD
+    import threading
+    if TRACE is not None:
+        raise VlfbError("a step is already being recorded (hip.TRACE)")
+    _TRACE_THREAD = threading.get_ident()
+    TRACE = []
+    return TRACE
+
+
+def trace_end():
+    global TRACE, _TRACE_THREAD
+    TRACE, _TRACE_THREAD = None, None
+
+
+def tracing():
+    """the list being recorded if the CALLING thread is the one recording, else None"""
+    if TRACE is None:
+        return None
+    import threading
+    return TRACE if threading.get_ident() == _TRACE_THREAD else None
 
 
 def freeze_args(fn, args):
@@ -216,8 +243,9 @@ def call(name, *args):
     """Call a status-returning entry point, appending the current HIP stream."""
     fn = getattr(lib(), name)
     args = args + (stream(),)
-    if TRACE is not None:
-        TRACE.append((fn, freeze_args(fn, args), name))
+    rec = tracing()
+    if rec is not None:
+        rec.append((fn, freeze_args(fn, args), name))
     _check(fn(*args), name)
 
 
@@ -307,8 +335,9 @@ def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspa
     fn = lib().vlfb_conv_run_planes
     args = (C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale), ptr(R), ptr(mask), ptr(workspace),
             ws_bytes, ptr(O_planes), stream())
-    if TRACE is not None:
-        TRACE.append((fn, freeze_args(fn, args), "vlfb_conv_run_planes"))
+    rec = tracing()
+    if rec is not None:
+        rec.append((fn, freeze_args(fn, args), "vlfb_conv_run_planes"))
     rc = fn(*args)
     if prof is not None:
         e1.record()
