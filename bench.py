@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched job (0 = pick a free one)")
     ap.add_argument("--split-steps", type=int, default=20, help="timed steps of the extra split-bf16 parity-path measurement")
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 parity-path measurement")
+    ap.add_argument("--dp-steps", type=int, default=10,
+                    help="data-parallel jobs: timed steps of the same step WITHOUT the gradient exchange (exposed all-reduce time)")
     ap.add_argument("--mix-steps", type=int, default=20, help="timed steps of the extra 'mix' (split forward + fp16 backward) measurement")
     ap.add_argument("--no-mix-line", action="store_true", help="skip the extra 'mix' path measurement")
     return ap.parse_args()
@@ -121,6 +123,65 @@ def parity_record(workload, dtype):
     out["source"] = "%s (%s, %s; tests/test_model_gpu.py::test_full_size_clip_matches_oracle on these kernel sources)" % (
         os.path.relpath(path, ROOT), rec["size"], rec["metric"])
     return out
+
+
+def data_parallel_report(eng, args, lr, step_s, device):
+    """What a reader needs to judge the N > 1 line (create_data_parallel_model, model_builder_video.py:126-157): who took part
+    (ranks of the communicator, backend), that every rank holds the same weights after the timed steps (bit-equality of the
+    flat parameter buffer), how much of the gradient exchange the step does NOT hide (same step with and without the
+    all-reduce, same run, max over ranks) and what the exchange costs alone (the payload in the step's buckets)."""
+    import torch
+    import torch.distributed as td
+    from vlfb import dist
+    from vlfb.engine import Engine
+    world = td.get_world_size()
+    rep = {"backend": td.get_backend(), "ranks": world, "buckets": len(eng.comm.buckets), "bucket_mb": args.bucket_mb,
+           "payload_mb": round(eng.flat_grad.numel() * 4 / 1e6, 1), "handoff": Engine.BUCKET_HANDOFF}
+
+    def vmax(x):
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
+    # (a) identical weights on every rank after the timed steps (same sums, same solver arithmetic)
+    torch.cuda.synchronize()
+    words = eng.flat_param.view(torch.int32).to(torch.int64)
+    chk = torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=device) % 8191 + 1)).sum()])
+    both = torch.stack([chk, -chk])
+    td.all_reduce(both, op=td.ReduceOp.MAX)
+    rep["weights_bit_identical_across_ranks"] = bool((both[0] == chk).all().item() and (both[1] == -chk).all().item())
+    # (b) the payload alone, in the step's buckets (the figure scratch/rccl_allreduce_bench.py reports)
+    buf = torch.zeros_like(eng.flat_grad)
+    for it in range(3 + 10):
+        if it == 3:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+        works = [td.all_reduce(buf[s:e], op=td.ReduceOp.SUM, async_op=True) for s, e, _ in eng.comm.buckets]
+        for w in works:
+            w.wait()
+    torch.cuda.synchronize()
+    alone = vmax((time.perf_counter() - t0) / 10)
+    rep["allreduce_alone_ms"] = round(alone * 1e3, 3)
+    rep["allreduce_alone_busbw_GBps"] = round(2.0 * (world - 1) / world * buf.numel() * 4 / alone / 1e9, 1) if world > 1 else None
+    # (c) the same step without the exchange (LAST: the ranks' weights diverge from here on)
+    comm, eng.comm = eng.comm, None
+    try:
+        for _ in range(2):
+            eng.train_step(lr)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.dp_steps):
+            eng.train_step(lr)
+        torch.cuda.synchronize()
+        no_comm = vmax((time.perf_counter() - t0) / max(args.dp_steps, 1))
+    finally:
+        eng.comm = comm
+    rep["ms_per_step_without_allreduce"] = round(no_comm * 1e3, 3)
+    rep["exposed_allreduce_ms"] = round((step_s - no_comm) * 1e3, 3)
+    rep["hidden_fraction"] = round(max(0.0, min(1.0, 1.0 - (step_s - no_comm) / alone)), 3) if alone > 0 else None
+    return rep
 
 
 def cpu_baseline(workload, frames, crop, rois_per_clip):
@@ -312,9 +373,7 @@ def main():
         ("host_enqueue_path", "recorded call list (Engine.STEP_TRACE)" if eng._trace is not None else "step objects"),
     ])
     if eng.comm is not None:       # the gradient exchange of this job (None on a one-process run without a process group)
-        out["allreduce"] = {"backend": torch.distributed.get_backend(), "buckets": len(eng.comm.buckets),
-                            "bucket_mb": args.bucket_mb, "payload_mb": round(eng.flat_grad.numel() * 4 / 1e6, 1),
-                            "handoff": Engine.BUCKET_HANDOFF}
+        out["allreduce"] = data_parallel_report(eng, args, lr, elapsed / args.steps, device)
     # The parity-grade paths on the same workload, so that the numbers next to the parity claims exist:
     #   split_path: fp32 storage, every contraction as split-bf16 products on the bf16 matrix cores (three MFMAs per product,
     #               Engine.SPLIT_MATH; csrc/vlfb_gemm_split.hip) -- outputs AND every parameter gradient within 1e-3 of

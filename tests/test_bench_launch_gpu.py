@@ -31,7 +31,11 @@ def test_self_launched_one_rank_rccl_job_prints_one_json_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["allreduce"]["backend"] == "nccl" and out["allreduce"]["buckets"] >= 1, out.get("allreduce")
+    ar = out["allreduce"]
+    assert ar["backend"] == "nccl" and ar["buckets"] >= 1 and ar["ranks"] == 1, ar
+    # what makes an N > 1 line checkable: identical weights on every rank, the step without the exchange, the exchange alone
+    assert ar["weights_bit_identical_across_ranks"] is True, ar
+    assert ar["ms_per_step_without_allreduce"] > 0 and ar["allreduce_alone_ms"] > 0 and "exposed_allreduce_ms" in ar, ar
 
 
 def test_job_size_mismatch_is_an_error_not_a_hang():
