@@ -160,7 +160,9 @@ typedef struct vlfb_conv_desc {
    *             O_planes argument of vlfb_conv_run_planes, [plane][row][ldo], o_pstride elements apart;
    *             1 = additionally write an fp16 COPY of the output to O_planes, [row][ldo] (batch stride o_bstride): what
    *             the fp16 backward of the "mix" path reads (positive values stay positive in the copy) */
-  int32_t a_planes, p_planes, o_planes, reserved0;
+  int32_t a_planes, p_planes, o_planes;
+  int32_t wgrad_bias; /* WGRAD only: 1 = the launch also produces the bias gradient db[p] = alpha * rowscale[p] * sum_m P[m][p]
+                         (vlfb_conv_run_wgrad_bias); counted in vlfb_conv_workspace_bytes */
   int64_t a_pstride, p_pstride, o_pstride;
 } vlfb_conv_desc;
 
@@ -194,6 +196,13 @@ int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void* B, const v
 int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, const void* P, void* O,
                          const float* bias, const float* rowscale, const void* R, const void* Mask,
                          void* workspace, int64_t workspace_bytes, void* O_planes, vlfb_stream_t stream);
+
+/* WGRAD with desc.wgrad_bias = 1: weight gradient O and bias gradient dbias (fp32 [Cn]) of a conv that carries a bias
+ * (nonlocal_helper.py:36-77, lfb_helper.py:175-200) from ONE pass over the output gradient P: the 16-bit transposed-read
+ * kernel sums the P tiles it stages anyway (per-split partial rows, folded in split order: deterministic); for every other
+ * kernel family the library runs a column-sum pass behind the launch -- the caller does not have to know which. */
+int vlfb_conv_run_wgrad_bias(const vlfb_conv_desc* d, const void* A, const void* P, void* O, float* dbias,
+                             const float* rowscale, void* workspace, int64_t workspace_bytes, vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / dtype movers at the boundary.

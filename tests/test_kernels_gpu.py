@@ -599,3 +599,46 @@ def test_skinny_row_products_of_the_fbo_head(M, K, Nc, tdt):
         assert not torch.isnan(outs[0].float()).any()
         assert rel_err(outs[0].float(), want) < (tol if odt != torch.float32 else 2e-6 * math.sqrt(K) + 1e-6)
         assert rel_err(outs[0].float(), outs[1].float()) < (tol if odt != torch.float32 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cs,Cn,taps", [(25088, 512, 256, 1), (6272, 1024, 512, 1), (33, 512, 512, 1), (9900, 2048, 512, 1),
+                                         (3000, 64, 136, 1), (1568, 128, 128, 3)])
+def test_wgrad_with_bias_gradient(M, Cs, Cn, taps, dtype):
+    """vlfb_conv_run_wgrad_bias: weight gradient AND bias gradient db = alpha * s * colsum(dY) of a conv that carries a bias
+    (nonlocal_helper.py:36-77, lfb_helper.py:175-200) from one pass over dY -- inside the transposed-read kernel on the 16-bit
+    paths (single launch and split-K slabs), a column-sum pass behind the launch for the other families (fp32, 256 x 256
+    pipelined).  Against fp64; the weight gradient must be bit-identical to the plain WGRAD launch; deterministic."""
+    g = torch.Generator().manual_seed(5)
+    T = M // 14 // 14 if taps == 3 else 1
+    if taps == 3:
+        geom = dict(N=1, Tr=T, Hr=14, Wr=14, Ts=T, Hs=14, Ws=14, kt=3, pt=1)
+        M = T * 196
+    else:
+        geom = dict(N=1, Tr=1, Hr=1, Wr=M, Ts=1, Hs=1, Ws=M)
+    x = q(torch.randn(M, Cs, generator=g), dtype)
+    dy = q(torch.randn(M, Cn, generator=g) * 0.1 + 0.02, dtype)
+    s = torch.rand(Cn, generator=g) + 0.5
+    alpha = 0.25
+    code = hip.dtype_code(dtype)
+    kw = dict(mode=hip.WGRAD, dtype=code, out_dtype=hip.F32, Cs=Cs, Cn=Cn, alpha=alpha, **geom)
+    d_plain = hip.conv_desc(**kw)
+    d_bias = hip.conv_desc(wgrad_bias=1, **kw)
+    ws = torch.empty(max(hip.conv_workspace_bytes(d_bias), hip.conv_workspace_bytes(d_plain), 16) // 4, device=dev())
+    X, DY, S = gpu(x, dtype), gpu(dy, dtype), gpu(s)
+    dw0 = torch.empty(Cn * taps * Cs, device=dev())
+    dw1 = torch.full((Cn * taps * Cs,), 7.0, device=dev())
+    db = torch.full((Cn,), 7.0, device=dev())
+    hip.conv_run(d_plain, X, None, DY, dw0, rowscale=S, workspace=ws)
+    hip.conv_run(d_bias, X, None, DY, dw1, rowscale=S, workspace=ws, dbias=db)
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1), "the weight gradient changed with the fused bias gradient"
+    ref = dy.double().sum(0) * s.double() * alpha
+    err = rel_err(db, ref)
+    print("\n[%s M=%d Cs=%d Cn=%d taps=%d] plan %s: bias gradient rel err %.2e" % (dtype, M, Cs, Cn, taps, hip.conv_plan(d_bias), err))
+    assert err < 2e-5, err
+    db2 = torch.empty(Cn, device=dev())
+    hip.conv_run(d_bias, X, None, DY, dw1, rowscale=S, workspace=ws, dbias=db2)
+    torch.cuda.synchronize()
+    if dtype != torch.float32 and "tn_tr" in hip.conv_plan(d_bias):
+        assert torch.equal(db, db2), "the fused bias gradient is not deterministic"

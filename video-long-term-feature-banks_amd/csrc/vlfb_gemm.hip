@@ -825,6 +825,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
 #pragma unroll
     for (int b = 0; b < FP; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient (GP::dbias): the workgroups of column tile 0 also sum the P tiles over the positions.  Thread -> one
+  // 16-byte channel chunk (bc) of BK / BG consecutive-stride positions; 8 fp32 partial sums per thread, folded at the end.
+  constexpr int BG = NTHR / CP;                 // position groups
+  constexpr int BPP = BK / BG;                  // positions per thread and k-tile
+  static_assert(SP || (BK % BG == 0 && BPP >= 1), "bias-gradient thread map");
+  const bool do_bias = !SP && p.dbias != nullptr && tile_q == 0;     // workgroup-uniform
+  const int bc = tid % CP, bg = tid / CP;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
   if (ktiles > 0) load_tile(0, 0);
   for (int kt = 0; kt < ktiles; ++kt) {
     // own DMA of tile kt landed, then a bare barrier (see gemm_nt_kernel): tile kt is complete and
@@ -833,6 +842,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
     if (kt + 1 < ktiles) load_tile(kt + 1, (kt + 1) & 1);
     const char* pt = smem + (kt & 1) * BUF;
     const char* qt = pt + NPL * PLP;
+    if constexpr (!SP) {
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < BPP; ++j) {
+          const int r = bg + BG * j;            // position inside the tile (rows past the slab end were zero-filled)
+          const int slot = (((bc >> 1) ^ tr_key<RSP>(r)) << 1) | (bc & 1);
+          float v[8];
+          Vec16<T>::load(reinterpret_cast<const T*>(pt + r * RSP + slot * 16), v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[e] += v[e];
+        }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       vec_t pf[NPL][FP], qf[NPL][FQ];
@@ -864,6 +886,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_tr_kernel(const GP p) {
   // ---- epilogue: lane holds qq = qb + 0..3 for output row pp (same as gemm_tn_kernel) ----------
   const bool vec_ok = (p.ldo & 3) == 0;
   const bool to_ws = p.splits > 1;
+  if constexpr (!SP) {
+    if (do_bias) {                               // (workgroup-uniform) fold the BG position groups through LDS, in order
+      __syncthreads();                           // every wave is done with the last tile
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[bg * BP + bc * 8 + e] = bsum[e];
+      __syncthreads();
+      if (tid < BP && p0 + tid < p.Ncols) {
+        float sum = 0.f;
+        for (int j = 0; j < BG; ++j) sum += red[j * BP + tid];
+        const int pp = p0 + tid;
+        if (to_ws) p.ws[(long long)p.splits * ((long long)p.Ncols * p.ldo) + (long long)split * p.Ncols + pp] = sum;
+        else p.dbias[pp] = sum * p.alpha * (p.rowscale ? p.rowscale[pp] : 1.f);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FP; ++i) {
     const int pp = p0 + wp * WP + i * 16 + l15;
@@ -1091,6 +1129,20 @@ __global__ __launch_bounds__(CL * G) void wgrad_reduce_kernel(const float* ws, c
   }
 }
 
+// bias-gradient partial rows of a split WGRAD (GP::dbias): ws_b[split][n] -> out[n], splits folded in order
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ ws_b, float* __restrict__ out,
+                                         const float* __restrict__ rowscale, int n, int splits, float alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws_b[(long long)k * n + i];
+  out[i] = s * alpha * (rowscale ? rowscale[i] : 1.f);
+}
+__global__ void scale_rows_kernel(float* __restrict__ x, const float* __restrict__ rowscale, int n, float alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= alpha * (rowscale ? rowscale[i] : 1.f);
+}
+
 // ---- host side ------------------------------------------------------------------------------
 int ilog2_exact(int v) {
   int l = 0;
@@ -1122,6 +1174,7 @@ struct Plan {
   int skinny;     // NT: at most 64 plain rows (vlfb_gemm_skinny.hip)
   int sp_kind;    //   NT: 0 plain rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem
   int sp_pl;      //   operands arrive as bf16 term planes (WGRAD: both; FPROP / DGRAD: the activation operand)
+  int bias_fused; // WGRAD with desc.wgrad_bias: the launch itself produces the column sums of P (gemm_tn_tr_kernel)
   size_t stem_lds;
   dim3 grid;
   size_t lds;
@@ -1139,6 +1192,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
                "conv: split-bf16 math needs fp32 operands and an fp32 output");
   VLFB_REQUIRE(d->math != VLFB_MATH_BF16X6 || d->mode != VLFB_CONV_WGRAD, "conv: WGRAD has no BF16X6 form (use BF16X3)");
   VLFB_REQUIRE(!d->accumulate || d->mode == VLFB_CONV_WGRAD, "conv: accumulate (O += ...) is a WGRAD epilogue");
+  VLFB_REQUIRE(!d->wgrad_bias || d->mode == VLFB_CONV_WGRAD, "conv: wgrad_bias belongs to WGRAD descriptors");
   pl->sp = d->math == VLFB_MATH_BF16X6 ? 3 : d->math == VLFB_MATH_BF16X3 ? 2 : 0;
   pl->sp_kind = 0;
   VLFB_REQUIRE(pl->sp || (!d->a_planes && !d->p_planes && !d->o_planes), "conv: term planes belong to split-bf16 math");
@@ -1516,6 +1570,11 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     pl->lds = (size_t)2 * (pl->bm + pl->bn) * 128;
     if (pl->stem || pl->rows) { pl->lds = pl->stem_lds; pl->threads = 512; }
   }
+  // bias gradient next to the weight gradient (vlfb_conv_run_wgrad_bias): inside the transposed-read kernel where that
+  // is what runs; every other family gets a column-sum pass behind it
+  pl->bias_fused = d->mode == VLFB_CONV_WGRAD && d->wgrad_bias && is16(d->dtype) && pl->tn_tr && !pl->sp && !pl->stem &&
+                   !pl->rows && !pl->tn8 && batch == 1 && !d->accumulate;
+  if (pl->bias_fused && pl->splits > 1) pl->ws_elems += (long long)pl->splits * d->Cn;
   return VLFB_OK;
 }
 
@@ -1723,10 +1782,30 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
   return vlfb_conv_run_planes(d, A, B, P, O, bias, rowscale, R, Mask, workspace, workspace_bytes, nullptr, stream);
 }
 
+static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
+                         void* O, const float* bias, const float* rowscale, const void* R,
+                         const void* Mask, void* workspace, int64_t workspace_bytes, void* O_planes, float* dbias,
+                         vlfb_stream_t stream);
+
 extern "C" int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
                                     void* O, const float* bias, const float* rowscale, const void* R,
                                     const void* Mask, void* workspace, int64_t workspace_bytes, void* O_planes,
                                     vlfb_stream_t stream) {
+  VLFB_REQUIRE(!d->wgrad_bias, "conv: a descriptor with wgrad_bias runs through vlfb_conv_run_wgrad_bias");
+  return conv_run_impl(d, A, B, P, O, bias, rowscale, R, Mask, workspace, workspace_bytes, O_planes, nullptr, stream);
+}
+
+extern "C" int vlfb_conv_run_wgrad_bias(const vlfb_conv_desc* d, const void* A, const void* P, void* O, float* dbias,
+                                        const float* rowscale, void* workspace, int64_t workspace_bytes,
+                                        vlfb_stream_t stream) {
+  VLFB_REQUIRE(d->mode == VLFB_CONV_WGRAD && d->wgrad_bias && dbias, "conv_run_wgrad_bias: a WGRAD descriptor with wgrad_bias = 1 and dbias");
+  return conv_run_impl(d, A, nullptr, P, O, nullptr, rowscale, nullptr, nullptr, workspace, workspace_bytes, nullptr, dbias, stream);
+}
+
+static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
+                         void* O, const float* bias, const float* rowscale, const void* R,
+                         const void* Mask, void* workspace, int64_t workspace_bytes, void* O_planes, float* dbias,
+                         vlfb_stream_t stream) {
   Plan pl;
   int rc = cached_plan(d, &pl);
   if (rc != VLFB_OK) return rc;
@@ -1743,6 +1822,7 @@ extern "C" int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, cons
   g.ws = (float*)workspace;
   VLFB_REQUIRE((d->o_planes > 0) == (O_planes != nullptr), "conv: O_planes goes with desc.o_planes");
   g.OP = (char*)O_planes;
+  g.dbias = pl.bias_fused ? dbias : nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
   if (pl.sp) {
@@ -1758,6 +1838,15 @@ extern "C" int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, cons
   else if (d->dtype == VLFB_F16) rc = d->out_dtype == VLFB_F32 ? dispatch<f16_t, float>(d, pl, s) : dispatch<f16_t, f16_t>(d, pl, s);
   else rc = d->out_dtype == VLFB_F32 ? dispatch<bf16_t, float>(d, pl, s) : dispatch<bf16_t, bf16_t>(d, pl, s);
   if (rc != VLFB_OK) return rc;
+  if (dbias && !pl.bias_fused) {
+    // families without the fused column sums: one pass over P behind the launch (then alpha * rowscale, as the weights)
+    rc = vlfb_colsum(P, d->dtype, g.M, d->Cn, g.ldp, dbias, 0, stream);
+    if (rc != VLFB_OK) return rc;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((d->Cn + 255) / 256)), dim3(256), 0, s, dbias, rowscale, d->Cn, d->alpha);
+  } else if (dbias && pl.splits > 1) {
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->Cn + 63) / 64)), dim3(64), 0, s,
+                       g.ws + (long long)pl.splits * ((long long)d->Cn * g.ldo), dbias, rowscale, d->Cn, pl.splits, d->alpha);
+  }
   if (pl.splits > 1) {
     const long long n = (long long)d->Cn * g.K;
     VLFB_REQUIRE(n % 4 == 0, "conv: split WGRAD output size must be a multiple of 4");

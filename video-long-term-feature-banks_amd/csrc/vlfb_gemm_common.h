@@ -47,6 +47,10 @@ struct GP {
   long long a_ps, p_ps, o_ps;
   char* OP;
   int op_n;
+  // WGRAD (gemm_tn_tr_kernel): also the column sums of P over the positions -- the bias gradient of the conv whose weight
+  // gradient this launch computes (the column tile 0 workgroups add up the P tiles they stage anyway).  dbias: fp32 [Ncols];
+  // with splits > 1 the per-split partial rows go behind the weight slabs in ws and the reduce pass folds them in order.
+  float* dbias;
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered

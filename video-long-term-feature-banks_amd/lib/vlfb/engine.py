@@ -280,6 +280,10 @@ class ConvStep(Step):
                 self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
                                          Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
                                          math=hip.MATH_BF16X3, **geom)
+            # a conv with a trainable bias (the non-local / FBO convs): the WGRAD launch also produces the bias gradient --
+            # db = alpha * s * column sums of the output gradient it reads anyway (vlfb_conv_run_wgrad_bias)
+            if self.cbname and eng.is_trainable(self.cbname) and eng.FUSE_BIAS_GRAD:
+                self.d_w.wgrad_bias = 1
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
             if not self.bwd_f32:
                 eng.want_half(self.x)
@@ -434,8 +438,12 @@ class ConvStep(Step):
                 hip.conv_run(d, self.x_planes, None, self.g_planes, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
             elif gp is not None and xp is not None and not self.stem:
                 # both operands pre-split: DMA + transposed LDS reads, no VALU in the k-loop
-                d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2)
+                d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2, wgrad_bias=0)
                 hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
+            elif self.d_w.wgrad_bias:
+                hip.conv_run(self.d_w, self.x.storage() if self.bwd_f32 else self.x.bstorage(), None, g,
+                             eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace, dbias=eng.grad_tensor(self.cbname))
+                return
             else:
                 hip.conv_run(self.d_w, self.x.storage() if self.bwd_f32 else self.x.bstorage(), None, g,
                              eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
@@ -1539,6 +1547,8 @@ class Engine(object):
     FPROP_PLANES = True         # three-term forward products: FPROP launches read existing input planes as well
     PLANES_SCOPE = "gathered"   # "all": planes around every conv, not only the gathered ones (measured)
     STEM_PLANES = True          # conv1: clip and output gradient through a split pass, FPROP / WGRAD on planes
+    # bias gradients of the convs that carry a bias come out of their WGRAD launch (False: a column-sum pass per conv)
+    FUSE_BIAS_GRAD = True
 
     # ---- side stream for parameter gradients ---------------------------------------------------
     class _Side(object):

@@ -58,7 +58,7 @@ class ConvDesc(C.Structure):
         ("alpha", C.c_float), ("relu", C.c_int32), ("bias_mode", C.c_int32),
         ("accumulate", C.c_int32), ("splits", C.c_int32), ("algo", C.c_int32),
         ("math", C.c_int32), ("b_pstride", C.c_int64),
-        ("a_planes", C.c_int32), ("p_planes", C.c_int32), ("o_planes", C.c_int32), ("reserved0", C.c_int32),
+        ("a_planes", C.c_int32), ("p_planes", C.c_int32), ("o_planes", C.c_int32), ("wgrad_bias", C.c_int32),
         ("a_pstride", C.c_int64), ("p_pstride", C.c_int64), ("o_pstride", C.c_int64),
     ]
 
@@ -98,6 +98,7 @@ _SIGS = {
     "vlfb_conv_plan_describe": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, _I64]),
     "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_conv_run_planes": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "vlfb_conv_run_wgrad_bias": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
     "vlfb_ncthw_to_nthwc_wpad": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "vlfb_nthwc_to_ncthw": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
@@ -325,19 +326,24 @@ def conv_tag(d):
 PROFILE = None
 
 
-def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None, O_planes=None):
+def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None, O_planes=None, dbias=None):
+    """dbias (WGRAD descriptors with wgrad_bias = 1): destination of the bias gradient the launch produces as well"""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     prof = PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib().vlfb_conv_run_planes
-    args = (C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale), ptr(R), ptr(mask), ptr(workspace),
-            ws_bytes, ptr(O_planes), stream())
+    if dbias is not None:
+        fn = lib().vlfb_conv_run_wgrad_bias
+        args = (C.byref(d), ptr(A), ptr(P), ptr(O), ptr(dbias), ptr(rowscale), ptr(workspace), ws_bytes, stream())
+    else:
+        fn = lib().vlfb_conv_run_planes
+        args = (C.byref(d), ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale), ptr(R), ptr(mask), ptr(workspace),
+                ws_bytes, ptr(O_planes), stream())
     rec = tracing()
     if rec is not None:
-        rec.append((fn, freeze_args(fn, args), "vlfb_conv_run_planes"))
+        rec.append((fn, freeze_args(fn, args), "vlfb_conv_run"))
     rc = fn(*args)
     if prof is not None:
         e1.record()
