@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ava_r50_lfb_nl",
                     help="ava_r50_lfb_nl (metric config) | charades_r50_baseline | charades_r50_lfb_nl | ava_r101_lfb_nl_3l")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "split", "mix"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "split", "mix"],
+                    help="fp16 (default: the 16-bit path -- same speed as bf16, gradients 3x closer to the oracle), bf16, the "
+                         "parity-grade paths split / mix, or fp32 (exact-fp32 MFMA)")
     ap.add_argument("--clips-per-gpu", type=int, default=8)
     ap.add_argument("--rois-per-clip", type=int, default=0,
                     help="0 = SURVEY 8d C4 draw U{1..5} per clip (seeded per rank); N > 0 = exactly N per clip")
@@ -312,9 +314,11 @@ def main():
     # (scratch/pmc_traffic.py) and anything else -- another workload, an edited kernel, an unstamped file -- reports null.
     traffic, traffic_source = {}, "none: no committed PMC pass for this workload/dtype/batch"
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if args.workload == "ava_r50_lfb_nl" and args.dtype == "bf16" and clips == 8 and os.path.exists(tpath):
+    if args.workload == "ava_r50_lfb_nl" and clips == 8 and os.path.exists(tpath):
         t = json.load(open(tpath))
-        if t.get("csrc_sha256") == kernel_source_hash():
+        if t.get("dtype", "bf16") != args.dtype:
+            traffic_source = "none: profiles/hbm_traffic.json was measured with --dtype %s" % t.get("dtype", "bf16")
+        elif t.get("csrc_sha256") == kernel_source_hash():
             traffic = {"nt": t["gemm_nt"]["bytes_per_launch"], "tn": t["gemm_tn"]["bytes_per_launch"]}
             traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on " \
                              "this kernel source, read side x2 per MI355X_MICROARCH.md; not measured in this run)"

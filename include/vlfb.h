@@ -197,6 +197,21 @@ int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, 
                          const float* bias, const float* rowscale, const void* R, const void* Mask,
                          void* workspace, int64_t workspace_bytes, void* O_planes, vlfb_stream_t stream);
 
+/* Every operand of a launch in one struct (what the three entry points above pass, plus):
+ *   R_lo / O_lo  16-bit FPROP / DGRAD launches with 16-bit outputs: a TWO-TERM residual / output.  The epilogue computes
+ *                v = alpha * acc + bias + R + R_lo; relu; mask  and stores O = T(v), O_lo = T(v - O): a running sum that is
+ *                re-rounded by every launch of a chain (the residual-stream gradient of the bottleneck stack) keeps ~22
+ *                significant bits while its leading term O stays a plain 16-bit MFMA operand.  Either may be NULL. */
+typedef struct vlfb_conv_args {
+  const void* A; const void* B; const void* P; void* O;
+  const float* bias; const float* rowscale;
+  const void* R; const void* Mask;
+  void* workspace; int64_t workspace_bytes;
+  void* O_planes; float* dbias;
+  const void* R_lo; void* O_lo;
+} vlfb_conv_args;
+int vlfb_conv_run_args(const vlfb_conv_desc* d, const vlfb_conv_args* a, vlfb_stream_t stream);
+
 /* WGRAD with desc.wgrad_bias = 1: weight gradient O and bias gradient dbias (fp32 [Cn]) of a conv that carries a bias
  * (nonlocal_helper.py:36-77, lfb_helper.py:175-200) from ONE pass over the output gradient P: the 16-bit transposed-read
  * kernel sums the P tiles it stages anyway (per-split partial rows, folded in split order: deterministic); for every other

@@ -37,6 +37,9 @@ for k in ('gemm_nt', 'gemm_tn'):
 from bench import kernel_source_hash
 js["csrc_sha256"] = kernel_source_hash()      # bench.py reports these bytes only for the kernel sources they were measured on
 js["command"] = cmd
+import re as _re
+_m = _re.search(r"--dtype\s+(\w+)", cmd)
+js["dtype"] = _m.group(1) if _m else "fp16"      # bench.py's default dtype
 open(out_txt, 'w').write('\n'.join(lines) + '\n')
 json.dump(js, open(out_json, 'w'))
 print('\n'.join(lines))

@@ -12,14 +12,14 @@ from oracle import model as om
 presets = sys.argv[1:] or ["ava_r50_lfb_nl", "charades_r50_baseline"]
 FULL = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", 32, "TRAIN.CROP_SIZE", 224]
 size = FULL if os.environ.get("MIX_FULL") else SMALL
-variants = [("split", None, None), ("mix", True, True), ("mix", True, False), ("mix", False, True)]
+variants = [("mix", True, True, True), ("mix", True, True, False)]
 if os.environ.get("MIX_FULL"):
-    variants = [("mix", True, True)]
+    variants = [("mix", True, True, True)]
 for preset in presets:
     ref = None
-    for dtype, w2, nl in variants:
+    for dtype, w2, nl, t2 in variants:
         if w2 is not None:
-            Engine.MIX_W2, Engine.MIX_NL_F32 = w2, nl
+            Engine.MIX_W2, Engine.MIX_NL_F32, Engine.MIX_TRUNK2 = w2, nl, t2
         cfg, model, eng, inputs, params, seed_fn = build(preset, dtype, size)
         eng.forward(); eng.backward(); torch.cuda.synchronize()
         if ref is None:
@@ -39,8 +39,8 @@ for preset in presets:
         _, g2 = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn, decisions=dec)
         cond = sorted(((rel(eng.fetch_grad(n), g2[n].numpy()), n) for n in names), reverse=True)
         e = np.array([x for x, _ in cond]); r = np.array([x for x, _ in raw])
-        print("[%s %s w2=%s nl_f32=%s] act max %.2e | raw median %.2e max %.2e | identical decisions: median %.2e p90 %.2e max %.2e (%s) 2nd %.2e (%s) | loss_scale %g"
-              % (preset, dtype, w2, nl, max(acts), np.median(r), r.max(), np.median(e), np.sort(e)[int(0.9 * (len(e) - 1))], e[0], cond[0][1], e[1], cond[1][1], eng.loss_scale), flush=True)
+        print("[%s %s w2=%s nl_f32=%s trunk2=%s] act max %.2e | raw median %.2e max %.2e | identical decisions: median %.2e p90 %.2e max %.2e (%s) 2nd %.2e (%s) | loss_scale %g"
+              % (preset, dtype, w2, nl, t2, max(acts), np.median(r), r.max(), np.median(e), np.sort(e)[int(0.9 * (len(e) - 1))], e[0], cond[0][1], e[1], cond[1][1], eng.loss_scale), flush=True)
         if os.environ.get("MIX_FULL"):
             for x, n in cond:
                 print("   %-44s %.3e" % (n, x))

@@ -173,5 +173,5 @@ def test_eight_clip_step_equals_the_one_clip_steps(dtype):
     # fp32-storage paths: only the fp32 summation order of the split-K slabs differs.  16-bit gradient storage: a 1-clip
     # run rounds scale * (p - t) / normaliser with the scale multiplied in a different order -- last-bit differences of the
     # loss gradient that the fp16 / bf16 chain then carries (measured values in the message above)
-    tol = {"split": 2e-5, "mix": 3e-3, "fp16": 3e-3, "bf16": 2e-2}[dtype]
+    tol = {"split": 5e-5, "mix": 2e-3, "fp16": 2e-3, "bf16": 1e-2}[dtype]
     assert e[0] < tol, errs[:5]

@@ -123,13 +123,14 @@ def test_forward_backward_matches_oracle(preset, dtype):
         print("[%s %s] gradients on identical ReLU / max-pool decisions: median %.2e worst %s"
               % (preset, dtype, float(np.median([x for x, _ in cond])), ["%s=%.2e" % (n, x) for x, n in cond[:4]]))
         if dtype == "mix":
-            # "mix" = the split forward (same decisions, same saved activations) + an fp16 backward: fp16 gradient storage,
-            # 11-bit MFMA operands (two-term weights in DGRAD, fp32 / split products around the non-local softmax).  Measured
-            # at this size: median 2.4e-4 .. 3.4e-4, p90 5.8e-4 .. 6.4e-4, max 1.1e-3 .. 1.2e-3 (conv1_w: sixteen fp16 roundings of
-            # the residual-stream gradient, scratch/r4/emu_hybrid.py).  The bar for EVERY tensor is the split path's; this path
-            # is held to: nine tensors in ten inside 1e-3, none beyond 2e-3.
+            # "mix" = the split forward (same decisions, same saved activations) + an fp16 backward: fp16 gradient storage
+            # (two terms on the residual stream), 11-bit MFMA operands (two-term weights in DGRAD, fp32 gradients / split
+            # products around the non-local softmax).  Measured at this size: median 2.3e-4 .. 3.1e-4, p90 6.0e-4 .. 6.2e-4,
+            # max 9.5e-4 (AVA, conv1_w) / 1.02e-3 (Charades, one non-local theta bias): the 11-bit operands leave no margin
+            # below 1e-3, so the regression gate is 1.5e-3 here; the claim against the bar is made at the benchmarked size
+            # (test_full_size_clip_matches_oracle: 9.7e-4 / 6.7e-4).
             ce = np.sort([x for x, _ in cond])
-            assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 1e-3 and cond[0][0] < 2e-3, cond[:5]
+            assert float(np.median(ce)) < 5e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 8e-4 and cond[0][0] < 1.5e-3, cond[:5]
         else:
             assert cond[0][0] < 1e-3, cond[:5]
     else:
@@ -319,9 +320,10 @@ def test_full_size_clip_matches_oracle(preset):
         a = dict(acts)
         if dtype == "mix":
             assert max(a.values()) < 1e-3, acts
-            # split forward + fp16 backward: measured median 3.7e-4 / 4.1e-4, p90 5.3e-4 / 6.2e-4, max 7.4e-4 (Charades) /
-            # 1.19e-3 (AVA: conv1_w and one non-local theta weight); raw median 1.7e-3 (AVA), as the split path's
-            assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 1e-3 and float(ce[-1]) < 2e-3, \
+            # split forward + fp16 backward: EVERY gradient inside the north-star bar at the benchmarked size -- measured
+            # median 3.7e-4 / 4.0e-4, p90 4.9e-4 / 6.2e-4, max 6.7e-4 (Charades) / 9.7e-4 (AVA: conv1_w, the end of the
+            # chain); raw median 1.7e-3 (AVA: ties, as on the split path).  No margin to speak of: 11-bit operands.
+            assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 8e-4 and float(ce[-1]) < 1e-3, \
                 sorted(cond, key=lambda x: -x[1])[:5]
             assert med < 5e-3 and mx < 3e-2, (med, mx)
         elif dtype in ("fp32", "split"):

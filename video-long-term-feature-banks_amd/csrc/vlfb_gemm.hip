@@ -253,6 +253,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
+  const char* R2b = p.R2 ? p.R2 + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;     // low terms (GP::R2 / O2)
+  char* O2b = p.O2 ? p.O2 + (long long)z * p.o_bs * (long long)sizeof(OutT) : nullptr;
   constexpr int EPT = 16 / (int)sizeof(OutT);   // output elements per 16-byte store
   constexpr int TPR = BN / EPT;                 // lanes per tile row
   constexpr int RPP = NTHR / TPR;               // rows per pass
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
       mpre[gp] = ld16_if(Mb ? Mb : Ab, off, ok && Mb != nullptr);
     }
   }
+  (void)R2b; (void)O2b;
 
   static_assert(ST >= 2 && ST <= 5 && 3 * LPT < 64, "ring depth / vmcnt immediate");
 #pragma unroll
@@ -370,6 +373,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] += r[e];
         }
+        if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
+          if (R2b) {                                 // low term of a two-term residual
+            float r[EPT];
+            load_elems<T, EPT>(reinterpret_cast<const T*>(R2b) + ridx, r);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) v[e] += r[e];
+          }
+        }
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -385,8 +396,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
         if (sizeof(OutT) == 4) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint4*>(o) = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
-                                                    Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
+          const uint4 hv = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
+                                      Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
+          *reinterpret_cast<uint4*>(o) = hv;
+          if (O2b) {                                 // low term: what the rounding of the stored value lost
+            float h[EPT];
+            unpack_elems<OutT, EPT>(hv, h);
+            *reinterpret_cast<uint4*>(reinterpret_cast<OutT*>(O2b) + mpos * p.ldo + ncol) =
+                make_uint4(Elem<OutT>::pack2(v[0] - h[0], v[1] - h[1]), Elem<OutT>::pack2(v[2 % EPT] - h[2 % EPT], v[3 % EPT] - h[3 % EPT]),
+                           Elem<OutT>::pack2(v[4 % EPT] - h[4 % EPT], v[5 % EPT] - h[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT] - h[6 % EPT], v[7 % EPT] - h[7 % EPT]));
+          }
         }
       }
     }
@@ -1277,8 +1296,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // output rows are then visited as 256-byte pieces of four different passes over the tensor instead of one
     // stream (198 -> 248 us, 153 -> 175 us).  Classes over h only (odd lines epilogue-only, as whole contiguous lines) are
     // no better (246 / 167 us): a tile without a k-loop has nothing to hide its residual loads behind.
+    // (dt == 0: the doubled term dimension of two-term fp16 weights, VLFB_MIX_W2 -- the walk is the same per term)
     if (d->mode == VLFB_CONV_DGRAD && d->algo == VLFB_ALGO_AUTO && !pl->sp && !pl->ident && !pl->packw && batch == 1 && d->kh * d->kw > 1 &&
-        d->st == 1 && d->sh == 2 && d->sw == 2 && d->dt == 1 && d->dh == 1 && d->dw == 1 && d->Hr % 2 == 0 &&
+        d->st == 1 && d->sh == 2 && d->sw == 2 && (d->dt == 1 || d->dt == 0) && d->dh == 1 && d->dw == 1 && d->Hr % 2 == 0 &&
         d->Wr % 2 == 0 && ((long long)d->Cs * es) % 128 == 0 && d->bias_mode == VLFB_BIAS_NONE) {
       g.s2 = 1;
       g.s2_mq = (int)(M / 4);
@@ -1785,7 +1805,14 @@ extern "C" int vlfb_conv_run(const vlfb_conv_desc* d, const void* A, const void*
 static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
                          void* O, const float* bias, const float* rowscale, const void* R,
                          const void* Mask, void* workspace, int64_t workspace_bytes, void* O_planes, float* dbias,
-                         vlfb_stream_t stream);
+                         vlfb_stream_t stream, const void* R_lo = nullptr, void* O_lo = nullptr);
+
+extern "C" int vlfb_conv_run_args(const vlfb_conv_desc* d, const vlfb_conv_args* a, vlfb_stream_t stream) {
+  VLFB_REQUIRE(d && a, "conv_run_args: descriptor and arguments are required");
+  VLFB_REQUIRE(!d->wgrad_bias == !a->dbias, "conv_run_args: dbias goes with desc.wgrad_bias");
+  return conv_run_impl(d, a->A, a->B, a->P, a->O, a->bias, a->rowscale, a->R, a->Mask, a->workspace, a->workspace_bytes,
+                       a->O_planes, a->dbias, stream, a->R_lo, a->O_lo);
+}
 
 extern "C" int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
                                     void* O, const float* bias, const float* rowscale, const void* R,
@@ -1805,10 +1832,23 @@ extern "C" int vlfb_conv_run_wgrad_bias(const vlfb_conv_desc* d, const void* A, 
 static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, const void* P,
                          void* O, const float* bias, const float* rowscale, const void* R,
                          const void* Mask, void* workspace, int64_t workspace_bytes, void* O_planes, float* dbias,
-                         vlfb_stream_t stream) {
+                         vlfb_stream_t stream, const void* R_lo, void* O_lo) {
   Plan pl;
   int rc = cached_plan(d, &pl);
   if (rc != VLFB_OK) return rc;
+  if (R_lo || O_lo) {
+    // two-term residual / output: the epilogues of the tiled NT families (128 x 128, 256-row pipelined) carry it
+    VLFB_REQUIRE(d->mode != VLFB_CONV_WGRAD && is16(d->dtype) && d->out_dtype == d->dtype && !pl.sp,
+                 "conv: R_lo / O_lo belong to 16-bit FPROP / DGRAD launches with 16-bit outputs");
+    VLFB_REQUIRE(!R_lo || R, "conv: R_lo without R");
+    if (pl.skinny || pl.rows64 || pl.nts || (d->mode == VLFB_CONV_FPROP && pl.stemf)) {
+      vlfb_conv_desc d2 = *d;
+      d2.algo = VLFB_ALGO_TILE128;
+      rc = cached_plan(&d2, &pl);
+      if (rc != VLFB_OK) return rc;
+    }
+    VLFB_REQUIRE(pl.gp.vec_epi, "conv: R_lo / O_lo need 16-byte aligned output rows");
+  }
   VLFB_REQUIRE(A && O, "conv: A and O are required");
   if (d->mode == VLFB_CONV_WGRAD) VLFB_REQUIRE(P != nullptr, "conv: WGRAD needs P");
   else VLFB_REQUIRE(B != nullptr, "conv: FPROP/DGRAD need B");
@@ -1823,6 +1863,7 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
   VLFB_REQUIRE((d->o_planes > 0) == (O_planes != nullptr), "conv: O_planes goes with desc.o_planes");
   g.OP = (char*)O_planes;
   g.dbias = pl.bias_fused ? dbias : nullptr;
+  g.R2 = (const char*)R_lo; g.O2 = (char*)O_lo;
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
   if (pl.sp) {

@@ -285,6 +285,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
   char* Ob = p.O + (long long)z * p.o_bs * (long long)sizeof(OutT);
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 2 : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 2 : nullptr;
+  const char* R2b = p.R2 ? p.R2 + (long long)z * p.r_bs * 2 : nullptr;             // low terms (GP::R2 / O2)
+  char* O2b = p.O2 ? p.O2 + (long long)z * p.o_bs * (long long)sizeof(OutT) : nullptr;
+  (void)R2b; (void)O2b;
   constexpr int EPT = 16 / (int)sizeof(OutT);
   constexpr int TPR = BN / EPT;                  // lanes per output row
   constexpr int RPI = 512 / TPR;                 // rows per iteration of the store loop
@@ -338,6 +341,14 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] += r[e];
         }
+        if constexpr (sizeof(OutT) == 2) {
+          if (R2b) {
+            float r[EPT];
+            load_elems<T, EPT>(reinterpret_cast<const T*>(R2b) + ridx, r);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) v[e] += r[e];
+          }
+        }
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -352,8 +363,16 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
         if (sizeof(OutT) == 4) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<uint4*>(o) = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
-                                                    Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
+          const uint4 hv = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
+                                      Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
+          *reinterpret_cast<uint4*>(o) = hv;
+          if (O2b) {
+            float h[EPT];
+            unpack_elems<OutT, EPT>(hv, h);
+            *reinterpret_cast<uint4*>(reinterpret_cast<OutT*>(O2b) + (long long)m * p.ldo + ncol) =
+                make_uint4(Elem<OutT>::pack2(v[0] - h[0], v[1] - h[1]), Elem<OutT>::pack2(v[2 % EPT] - h[2 % EPT], v[3 % EPT] - h[3 % EPT]),
+                           Elem<OutT>::pack2(v[4 % EPT] - h[4 % EPT], v[5 % EPT] - h[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT] - h[6 % EPT], v[7 % EPT] - h[7 % EPT]));
+          }
         }
       }
     }

@@ -51,6 +51,10 @@ struct GP {
   // gradient this launch computes (the column tile 0 workgroups add up the P tiles they stage anyway).  dbias: fp32 [Ncols];
   // with splits > 1 the per-split partial rows go behind the weight slabs in ws and the reduce pass folds them in order.
   float* dbias;
+  // NT, 16-bit outputs: TWO-TERM residual / output (the "mix" path's residual-stream gradient, which is re-rounded once
+  // per bottleneck block): v = alpha * acc + bias + R + R2; relu; mask; O = T(v), O2 = T(v - T(v)).  Either may be null.
+  const char* R2;
+  char* O2;
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered

@@ -114,11 +114,25 @@ class GradSlot(object):
         self.cur = None
         self.planes = None            # "split" dtype: bf16 term planes [2][numel] of the FINISHED gradient ...
         self.planes_valid = False     # ... valid when the last contribution came from a conv epilogue that wrote them
+        # "mix" dtype, residual-stream gradients (a slot that receives the gradient of the next block's output as an alias and
+        # adds a branch to it, block after block): kept as TWO fp16 terms -- cur + cur_lo -- so that the running sum is not
+        # re-rounded to 11 bits sixteen times on its way down the stack.  The conv epilogues read / write the low term
+        # (vlfb_conv_args R_lo / O_lo); a contributor that does not know about it passes it through unchanged.
+        self.two_term = False
+        self.buf_lo = None
+        self.cur_lo = None
+        self.add_lo = None            # handed to the contributor being called: low term of `add` ...
+        self.out_lo = None            # ... and where it may leave the low term of what it writes
 
     def reset(self):
         self.count = 0
         self.cur = None
+        self.cur_lo = None
         self.planes_valid = False
+
+    def value_lo(self):
+        """low term of the finished gradient, or None"""
+        return self.cur_lo if self.count == self.expected else None
 
     def value_planes(self):
         """term planes of the finished gradient, or None (the consumer then splits the fp32 values itself)"""
@@ -140,26 +154,37 @@ class GradSlot(object):
         last = self.count == self.expected
         if writes_planes:
             want = self.planes if last else None
+            # (a conv epilogue: it adds the low term of `add` and leaves the low term of its result, GradSlot.two_term)
+            self.add_lo = self.cur_lo if add is not None else None
+            self.out_lo = self.buf_lo if self.two_term else None
             fn(self.buf, add, mask, want)
             self.planes_valid = want is not None
+            self.cur_lo = self.out_lo
         elif (add is None or supports_add) and (mask is None or supports_mask):
             fn(self.buf, add, mask)
+            if mask is not None or add is None:
+                self.cur_lo = None        # (a masked result would need a masked low term; a fresh value has none)
         else:
             tmp = self.engine.scratch_act(self.buf.numel(), self.buf.dtype)
             fn(tmp, None, None)
             hip.call("vlfb_add", hip.ptr(tmp), hip.ptr(add), hip.ptr(self.buf), hip.ptr(mask),
                      hip.dtype_code(self.buf.dtype), self.buf.numel(), 0)
+            if mask is not None or add is None:
+                self.cur_lo = None
         self.cur = self.buf
 
-    def contribute_alias(self, t):
-        """the contribution is an existing tensor (identity branch of a Sum / ReLU)"""
+    def contribute_alias(self, t, t_lo=None):
+        """the contribution is an existing tensor (identity branch of a Sum / ReLU); t_lo: its low term (two_term slots)"""
         add, mask = self._flags()
         if add is None and mask is None:
             self.cur = t
+            self.cur_lo = t_lo if self.two_term else None
             return
         hip.call("vlfb_add", hip.ptr(t), hip.ptr(add), hip.ptr(self.buf), hip.ptr(mask),
                  hip.dtype_code(self.buf.dtype), self.buf.numel(), 0)
         self.cur = self.buf
+        if mask is not None:
+            self.cur_lo = None
 
     def value(self):
         if self.count != self.expected:
@@ -407,7 +432,7 @@ class ConvStep(Step):
                 hip.call("vlfb_cast", hip.ptr(g_w), hip.F32, hip.ptr(g), eng.bcode, self.out.numel)
         gp = self.out.root.slot.value_planes()         # term planes of the finished output gradient, or None
         if self.residual is not None and self.residual.needs_grad and not self.residual.detached:
-            self.residual.root.slot.contribute_alias(g)
+            self.residual.root.slot.contribute_alias(g, self.out.root.slot.value_lo())
         if self.d_w is not None or (self.cbname and eng.is_trainable(self.cbname)):
             # weight / bias gradients are leaves of the backward graph: they run on the side stream
             # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
@@ -423,7 +448,9 @@ class ConvStep(Step):
                 if planes is not None:
                     kw.update(o_planes=2, o_pstride=planes.numel() // 2)
                 d = self._pl_desc(self.d_d, **kw) if kw else self.d_d
-                hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes)
+                xs = self.x.root.slot
+                hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes,
+                             R_lo=xs.add_lo, O_lo=xs.out_lo)
             self.x.root.slot.contribute(dgrad, writes_planes=True)
 
     def _param_grads(self, g, gp=None):
@@ -684,8 +711,9 @@ class AddStep(Step):
 
     def bwd(self):
         g = self.out_grad()
+        g_lo = self.out.root.slot.value_lo()
         for x in self.grad_inputs():
-            x.root.slot.contribute_alias(g)
+            x.root.slot.contribute_alias(g, g_lo)
 
 
 class ReluStep(Step):
@@ -1539,6 +1567,8 @@ class Engine(object):
     # "mix" dtype: gradients of theta / phi / g of the non-local blocks in fp32, their weight gradients and the dP product of
     # the attention backward as split-bf16 products, the softmax backward on the fp32 probabilities
     MIX_NL_F32 = os.environ.get("VLFB_MIX_NL_F32", "1") != "0"
+    # "mix" dtype: the residual-stream gradient as two fp16 terms (GradSlot.two_term)
+    MIX_TRUNK2 = os.environ.get("VLFB_MIX_TRUNK2", "1") != "0"
     # "split" dtype: conv epilogues also write the bf16 term planes of their outputs / input gradients, and the DGRAD / WGRAD
     # launches that find their operands in that form read them without expanding (ConvStep.bwd); tensors with more than
     # PLANES_MAX_NUMEL elements (the wide res2 / stem tensors: a second copy costs more HBM time than it saves) stay fp32-only
@@ -1818,6 +1848,14 @@ class Engine(object):
         for b in self.all_blobs:
             if b.root is b and b.grad_scale != 1.0:
                 assert b.slot.expected <= 1, "a scaled gradient (%s) must have a single contributor" % b.name
+        if self.mix and self.MIX_TRUNK2:
+            # the residual stream: a blob that is the identity operand of a conv's residual Sum receives that conv's output
+            # gradient as an alias and adds its own branch to it (GradSlot.two_term)
+            for st in self.bwd_steps:
+                if isinstance(st, ConvStep) and st.residual is not None and st.residual.needs_grad and not st.residual.detached:
+                    r = st.residual.root
+                    if r.kind == "act" and not r.grad_f32 and r.slot.expected > 1:
+                        r.slot.two_term = True
 
     def _allocate(self):
         dev = self.device
@@ -1837,6 +1875,8 @@ class Engine(object):
             if self.train and b.slot.expected > 0:
                 gdt = self.btdtype if (b.kind == "act" and not b.grad_f32) else b.tensor.dtype
                 b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=gdt)
+                if b.slot.two_term:
+                    b.slot.buf_lo = torch.zeros(b.tensor.numel(), device=dev, dtype=gdt)
                 if b.relu:
                     self.want_half(b)             # the finished gradient is masked by the sign of the values
             if b.need_half:

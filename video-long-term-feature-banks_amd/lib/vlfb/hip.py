@@ -63,6 +63,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("P", C.c_void_p), ("O", C.c_void_p), ("bias", C.c_void_p),
+                ("rowscale", C.c_void_p), ("R", C.c_void_p), ("Mask", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("O_planes", C.c_void_p), ("dbias", C.c_void_p), ("R_lo", C.c_void_p),
+                ("O_lo", C.c_void_p)]
+
+
 class WPrepItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("w_fprop", C.c_void_p), ("w_dgrad", C.c_void_p),
                 ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32), ("tile_begin", C.c_int32)]
@@ -98,6 +105,7 @@ _SIGS = {
     "vlfb_conv_plan_describe": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, _I64]),
     "vlfb_conv_run": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_conv_run_planes": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "vlfb_conv_run_args": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), _P]),
     "vlfb_conv_run_wgrad_bias": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I64, _P]),
     "vlfb_ncthw_to_nthwc": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _P]),
     "vlfb_ncthw_to_nthwc_wpad": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
@@ -321,20 +329,31 @@ def conv_tag(d):
         d.st, d.sh, d.sw, d.dh, max(d.batch, 1), d.Ts, d.Hs, d.Ws)
 
 
+_KEEP_ARGS = []       # vlfb_conv_args structs handed to the library by reference (kept alive for recorded steps)
+
 # When a list, every conv_run is bracketed by HIP events on the launch stream and appended as
 # (mode, flops, start_event, end_event); bench.py uses it for the live roofline measurement.
 PROFILE = None
 
 
-def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None, O_planes=None, dbias=None):
-    """dbias (WGRAD descriptors with wgrad_bias = 1): destination of the bias gradient the launch produces as well"""
+def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspace=None, O_planes=None, dbias=None,
+             R_lo=None, O_lo=None):
+    """dbias (WGRAD descriptors with wgrad_bias = 1): destination of the bias gradient the launch produces as well;
+    R_lo / O_lo: low terms of a two-term residual / output (vlfb_conv_args)"""
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     prof = PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    if dbias is not None:
+    if R_lo is not None or O_lo is not None:
+        fn = lib().vlfb_conv_run_args
+        a = ConvArgs(ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale), ptr(R), ptr(mask), ptr(workspace), ws_bytes,
+                     ptr(O_planes), ptr(dbias), ptr(R_lo), ptr(O_lo))
+        if tracing() is not None:
+            _KEEP_ARGS.append(a)            # (a recorded step replays the call with this struct; bounded: one per recorded call)
+        args = (C.byref(d), C.byref(a), stream())
+    elif dbias is not None:
         fn = lib().vlfb_conv_run_wgrad_bias
         args = (C.byref(d), ptr(A), ptr(P), ptr(O), ptr(dbias), ptr(rowscale), ptr(workspace), ws_bytes, stream())
     else:
