@@ -112,7 +112,7 @@ def _trace_engine(dtype="bf16", eager_solver=False, name="t"):
     return eng
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32", "split"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32", "split", "mix"])
 def test_replayed_trace_is_bit_identical_to_the_stream_step(dtype):
     a, b = _trace_engine(dtype), _engine(False, dtype)
     masks = []
