@@ -14,8 +14,10 @@ _clock = {"t": 0}  # RunNet counter: a blob that several nets of one scope produ
 
 
 def set_compute_dtype(name):
-    """'bf16' / 'fp16' (throughput paths) or 'fp32' (parity path) for engines created afterwards"""
-    assert name in ("bf16", "fp16", "fp32")
+    """'bf16' / 'fp16' (throughput paths), 'mix' / 'split' (parity-grade: fp32 storage, split-bf16 products; 'mix' with an
+    fp16 backward) or 'fp32' (exact-fp32 MFMA) for engines created afterwards"""
+    if name not in ("bf16", "fp16", "fp32", "split", "mix"):
+        raise ValueError("set_compute_dtype: %r is not one of bf16, fp16, fp32, split, mix" % (name,))
     _dtype["value"] = name
 
 
