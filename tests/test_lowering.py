@@ -6,7 +6,7 @@ import collections
 import pytest
 
 
-def plan(preset, overrides=("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2), rois=5, split="train", **kw):
+def plan(preset, overrides=("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2), rois=5, split="train", dtype="bf16", **kw):
     from vlfb.presets import load_preset
     from core.config import config as cfg
     from models.model_builder_video import ModelBuilder
@@ -28,7 +28,7 @@ def plan(preset, overrides=("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2), rois=5, split
         sh["labels" + sfx] = (n, cfg.MODEL.NUM_CLASSES)
         if "lfb" + sfx in m.input_blob_names:
             sh["lfb" + sfx] = (n, cfg.LFB.WINDOW_SIZE, 2048)
-    eng = Engine(m, "bf16", dry_run=True)
+    eng = Engine(m, dtype, dry_run=True)
     eng.plan(sh)
     return cfg, m, eng
 
@@ -135,3 +135,61 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), os.path.join(dirpath, f)
+
+
+def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
+    """Engine dtype "mix" (DESIGN.md 3.1g): every forward value the backward reads has an fp16 copy with exactly one writer
+    (the producing conv's epilogue, a copy pass behind a non-conv step, or the start of forward() for fed blobs); the
+    backward descriptors are fp16 with two-term weights; theta / phi / g of the non-local blocks keep fp32 gradients; the
+    residual-stream slots are two-term"""
+    import torch
+    from vlfb import hip
+    from vlfb.engine import ConvStep, AttentionStep, Engine
+    cfg, m, eng = plan("ava_r50_lfb_nl", dtype="mix")
+    assert eng.mix and eng.split and eng.tdtype == torch.float32 and eng.btdtype == torch.float16
+    assert eng.math_fwd == hip.MATH_BF16X3 and eng.math_bwd == hip.MATH_NATIVE and eng.wcode == hip.MIX_W2
+    halves = [b for b in eng.all_blobs if b.root is b and b.half is not None]
+    by_conv = {id(o.root) for st in eng.steps if isinstance(st, ConvStep) for o in st.outputs}
+    posted = [id(b) for st in eng.steps for b in st._half_post]
+    fed = [id(b) for b in eng._half_inputs]
+    assert len(posted) == len(set(posted)) and not (set(posted) & by_conv) and not (set(fed) & by_conv)
+    for b in halves:
+        assert (id(b) in by_conv) + (id(b) in posted) + (id(b) in fed) == 1, b.name
+        assert b.half.dtype == torch.float16 and b.half.numel() == b.tensor.numel()
+    assert sorted(b.name for b in eng._half_inputs) == ["data_train", "lfb_train"]
+    convs = {s.out.name: s for s in eng.steps if isinstance(s, ConvStep)}
+    c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
+    assert (c.d_f.dtype, c.d_f.math, c.d_f.kt) == (hip.F32, hip.MATH_BF16X3, 1)
+    assert (c.d_d.dtype, c.d_d.math, c.d_d.kt, c.d_d.dt, c.d_d.kh, c.d_d.kw) == (hip.F16, hip.MATH_NATIVE, 2, 0, 3, 3)
+    assert abs(c.d_d.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.w_d.numel() == 2 * c.w_f.numel() // 3
+    assert hip.conv_flops(c.d_d) == hip.conv_flops(c.d_f)          # the doubled taps are not algorithmic work
+    assert (c.d_w.dtype, c.d_w.out_dtype, c.d_w.math) == (hip.F16, hip.F32, hip.MATH_NATIVE)
+    a = convs["res4_2_branch2a_bn"]                       # 3x1x1: T plays H, H x W one pointwise axis, T' = 1 carries the terms
+    N, _, T, H, W = a.x.shape
+    assert (a.d_d.kt, a.d_d.dt, a.d_d.kh, a.d_d.kw, a.d_d.ph) == (2, 0, 3, 1, 1)
+    assert (a.d_d.Tr, a.d_d.Hr, a.d_d.Wr, a.d_d.Ts, a.d_d.Hs, a.d_d.Ws) == (1, T, H * W, 1, T, H * W)
+    # fp32 gradients and split products around the non-local softmax
+    f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32)
+    assert len(f32) == 15 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g") for n in f32), f32
+    th = convs["nonlocal_conv4_1_theta"]
+    assert th.bwd_f32 and (th.d_w.dtype, th.d_w.math, th.d_w.wgrad_bias) == (hip.F32, hip.MATH_BF16X3, 1)
+    assert th.out.root.slot.buf.dtype == torch.float32
+    att = [s for s in eng.steps if isinstance(s, AttentionStep) and not s.single][0]
+    assert att.precise and not att.fused_bwd and (att.d_dp.dtype, att.d_dp.math) == (hip.F32, hip.MATH_BF16X3)
+    # the residual stream: the identity operands of the residual Sums
+    two = [b.name for b in eng.all_blobs if b.root is b and b.slot.two_term]
+    assert len(two) == 17 and "res2_0_branch2c_bn" in two and "nonlocal_conv4_3_sum" in two and "res5_2_branch2c_bn" not in two
+    assert all(eng.env[n].root.slot.buf_lo is not None and eng.env[n].root.slot.buf.dtype == torch.float16 for n in two)
+    # every launch has a plan; the table is a pure function of the descriptors (what bench.py and the plan test compare)
+    table = eng.plan_table()
+    assert len(table) > 250 and all(r[3] for r in table)
+    assert Engine(m, "mix", dry_run=True).plan(collections.OrderedDict((b.name, b.shape) for b in eng.all_blobs
+                                                if getattr(b, "is_input", False) and b.root is b)).plan_table() == table
+
+
+def test_other_dtypes_plan_without_half_copies():
+    for dtype in ("bf16", "fp16", "split", "fp32"):
+        cfg, m, eng = plan("charades_r50_baseline", dtype=dtype)
+        assert not eng.mix and all(b.half is None for b in eng.all_blobs)
+        assert not eng._half_inputs and not any(st._half_post for st in eng.steps)
+        assert eng.bcode == eng.code and not any(b.slot.two_term for b in eng.all_blobs if b.root is b)
