@@ -60,3 +60,24 @@ def test_host_side_argument_checks_need_no_gpu():
         hip.query_workspace(17, (1,))
     assert hip.lib().vlfb_dtype_size(hip.BF16) == 2 and hip.lib().vlfb_dtype_size(hip.F32) == 4
     assert hip.conv_flops(d) == 2.0 * 4 * 8 * 8 * 64 * 9 * 64
+
+
+def test_the_step_recorder_only_sees_the_recording_thread():
+    """hip.TRACE is what Engine.train_step replays with frozen pointers: a call of ANOTHER thread (a loader thread
+    preprocessing the next clip, a bank sampler) must never land in it"""
+    import threading
+    from vlfb import hip
+    rec = hip.trace_begin()
+    try:
+        assert hip.tracing() is rec
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(hip.tracing()))
+        t.start()
+        t.join()
+        assert seen == [None]
+        import pytest
+        with pytest.raises(hip.VlfbError):
+            hip.trace_begin()               # one recording at a time
+    finally:
+        hip.trace_end()
+    assert hip.tracing() is None and hip.TRACE is None
