@@ -347,7 +347,8 @@ int vlfb_relu_fwd(const void* x, void* y, int dtype, int64_t n, vlfb_stream_t st
 int vlfb_relu_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n,
                   vlfb_stream_t stream);
 /* colsum[c] (+)= sum_r g[r][c] -- bias gradients of the convs that carry a bias
- * (nonlocal_helper.py:36-77, lfb_helper.py:175-200, resnet_video.py:327) */
+ * (nonlocal_helper.py:36-77, lfb_helper.py:175-200, resnet_video.py:327).  Row slabs are folded with fp32 atomics (no scratch
+ * argument): not bit-reproducible.  The engine takes its bias gradients from vlfb_conv_run_wgrad_bias, which is. */
 int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out,
                 int accumulate, vlfb_stream_t stream);
 /* ------------------------------------------------------------------------------------------
@@ -431,7 +432,9 @@ int vlfb_roi_align_max_fwd(const void* feat, int dtype, const float* rois, void*
  * inside}; samples beyond the RoI's adaptive grid carry {.., -2, -2, -2, -2, -1}. */
 int vlfb_roi_align_decisions(const float* rois, int32_t* dbg, int64_t h, int64_t w, int64_t r, int pooled,
                              float spatial_scale, int max_grid, vlfb_stream_t stream);
-/* dfeat (fp32 [N,H,W,C], must be zeroed by the caller) += scatter of dout through argbin */
+/* dfeat (fp32 [N,H,W,C], must be zeroed by the caller) += scatter of dout through argbin.  Deterministic: one thread owns a
+ * (clip, channel) column and adds its RoIs' contributions in RoI / sample / corner order (the reference operator scatters
+ * with atomics, whose order -- overlapping RoIs of a clip -- varies from run to run). */
 int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois, const uint8_t* argbin,
                            float* dfeat, int64_t n, int64_t h, int64_t w, int64_t c, int64_t r,
                            int pooled, float spatial_scale, vlfb_stream_t stream);

@@ -573,3 +573,22 @@ def test_test_crop_256_shapes_nonlocal_4096x1024():
     for key in ("prob", "pool5"):
         got = eng.fetch(key)
         assert rel(got, blobs[key].numpy().reshape(got.shape)) < 1e-3, key
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "mix"])
+def test_a_training_step_is_reproducible_bit_for_bit(dtype):
+    """SURVEY.md 8b 'determinism': no reduction of the step depends on the order in which workgroups finish -- split-K slabs,
+    bias column sums and the RoIAlign backward (the reference scatters with atomics; overlapping RoIs of a clip hit the same
+    pixels) are all folded in a fixed order.  Two engines built from the same seed take three steps each: every parameter
+    and every momentum buffer must be identical, bit for bit."""
+    states = []
+    for run in range(2):
+        cfg, model, eng, inputs, params, seed_fn = build("ava_r50_lfb_nl", dtype)
+        for it in range(3):
+            eng.train_step(0.02)
+        torch.cuda.synchronize()
+        states.append((eng.flat_param.clone(), eng.flat_mom.clone(), eng.flat_grad.clone()))
+        del eng
+    for a, b, what in zip(states[0], states[1], ("parameters", "momentum", "gradients")):
+        assert torch.equal(a, b), "%s differ between two identical runs (%d of %d words)" % (
+            what, int((a != b).sum()), a.numel())

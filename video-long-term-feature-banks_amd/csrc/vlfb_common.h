@@ -114,6 +114,10 @@ template <typename T> struct Vec16x16bit {
 template <> struct Vec16<bf16_t> : Vec16x16bit<bf16_t> {};
 template <> struct Vec16<f16_t> : Vec16x16bit<f16_t> {};
 
+// vlfb_ops.hip: column sums without atomics -- per-slab partial rows that the caller folds in a fixed order
+int colsum_slabs(int dtype, long long rows, long long cols);
+int colsum_partials(const void* g, int dtype, long long rows, long long cols, long long ld, float* partials, hipStream_t s);
+
 inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;

@@ -1157,10 +1157,6 @@ __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ ws_b, float* 
   for (int k = 0; k < splits; ++k) s += ws_b[(long long)k * n + i];
   out[i] = s * alpha * (rowscale ? rowscale[i] : 1.f);
 }
-__global__ void scale_rows_kernel(float* __restrict__ x, const float* __restrict__ rowscale, int n, float alpha) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= alpha * (rowscale ? rowscale[i] : 1.f);
-}
 
 // ---- host side ------------------------------------------------------------------------------
 int ilog2_exact(int v) {
@@ -1595,6 +1591,9 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->bias_fused = d->mode == VLFB_CONV_WGRAD && d->wgrad_bias && is16(d->dtype) && pl->tn_tr && !pl->sp && !pl->stem &&
                    !pl->rows && !pl->tn8 && batch == 1 && !d->accumulate;
   if (pl->bias_fused && pl->splits > 1) pl->ws_elems += (long long)pl->splits * d->Cn;
+  // (other families: per-slab column sums behind the weight slabs, folded in order -- no atomics)
+  if (d->mode == VLFB_CONV_WGRAD && d->wgrad_bias && !pl->bias_fused)
+    pl->ws_elems += (long long)colsum_slabs(pl->sp_pl ? VLFB_BF16 : d->dtype, M, d->Cn) * d->Cn;
   return VLFB_OK;
 }
 
@@ -1880,10 +1879,15 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
   else rc = d->out_dtype == VLFB_F32 ? dispatch<bf16_t, float>(d, pl, s) : dispatch<bf16_t, bf16_t>(d, pl, s);
   if (rc != VLFB_OK) return rc;
   if (dbias && !pl.bias_fused) {
-    // families without the fused column sums: one pass over P behind the launch (then alpha * rowscale, as the weights)
-    rc = vlfb_colsum(P, d->dtype, g.M, d->Cn, g.ldp, dbias, 0, stream);
+    // families without the fused column sums: one pass over P behind the launch -- per-slab partial rows behind the
+    // weight slabs, folded in slab order (then alpha * rowscale, as the weights): deterministic
+    VLFB_REQUIRE(!pl.sp_pl, "conv: wgrad_bias with pre-split operands is not supported (pass the fp32 operands)");
+    const int slabs = colsum_slabs(d->dtype, g.M, d->Cn);
+    float* part = g.ws + (pl.splits > 1 ? (long long)pl.splits * ((long long)d->Cn * g.ldo) : 0);
+    rc = colsum_partials(P, d->dtype, g.M, d->Cn, g.ldp, part, s);
     if (rc != VLFB_OK) return rc;
-    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((d->Cn + 255) / 256)), dim3(256), 0, s, dbias, rowscale, d->Cn, d->alpha);
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->Cn + 63) / 64)), dim3(64), 0, s, part, dbias, rowscale,
+                       d->Cn, slabs, d->alpha);
   } else if (dbias && pl.splits > 1) {
     hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->Cn + 63) / 64)), dim3(64), 0, s,
                        g.ws + (long long)pl.splits * ((long long)d->Cn * g.ldo), dbias, rowscale, d->Cn, pl.splits, d->alpha);

@@ -939,7 +939,8 @@ __global__ void add_kernel(const T* a, const T* b, T* y, const T* __restrict__ m
 
 // column sums: block = 16-byte channel-chunk lanes x row lanes over one row slab; 16-byte loads,
 // LDS reduction over the row lanes, then one fp32 atomic per channel and slab.
-template <typename T>
+// PARTIAL: every row slab leaves its sums in out[slab][cols] instead (a later pass folds the slabs in order: deterministic)
+template <typename T, bool PARTIAL = false>
 __global__ void colsum_kernel(const T* __restrict__ g, long long rows, int cols, long long ld,
                               float* __restrict__ out) {
   constexpr int V = Vec16<T>::N;
@@ -967,7 +968,8 @@ __global__ void colsum_kernel(const T* __restrict__ g, long long rows, int cols,
   if (rl < V && c0 < cols) {            // row lane k sums channel k of this chunk
     float sum = 0.f;
     for (int j = 0; j < RL; ++j) sum += red[j][cl * 8 + rl];
-    atomicAdd(out + c0 + rl, sum);
+    if (PARTIAL) out[(long long)blockIdx.y * cols + c0 + rl] = sum;
+    else atomicAdd(out + c0 + rl, sum);
   }
 }
 
@@ -1341,6 +1343,29 @@ extern "C" int vlfb_relu_bwd(const void* dy, const void* yv, void* dx, int dtype
   VLFB_REQUIRE(yv != nullptr, "relu_bwd: y is required");
   return vlfb_add(dy, nullptr, dx, yv, dtype, n, 0, stream);
 }
+namespace vlfb {
+// row slabs of a column-sum launch over (rows x cols) elements of `dtype` (the grid's y extent)
+int colsum_slabs(int dtype, long long rows, long long cols) {
+  const int v = dtype == VLFB_F32 ? 4 : 8;
+  const int cblocks = (int)((cols / v + 7) / 8);
+  int slabs = (int)((rows + 1023) / 1024);
+  const int want = (2048 + cblocks - 1) / cblocks;
+  if (slabs > want) slabs = want;
+  return slabs < 1 ? 1 : slabs;
+}
+// per-slab column sums into partials[colsum_slabs][cols] (no atomics: the caller folds the slabs in a fixed order)
+int colsum_partials(const void* g, int dtype, long long rows, long long cols, long long ld, float* partials, hipStream_t s) {
+  const int v = dtype == VLFB_F32 ? 4 : 8;
+  VLFB_REQUIRE(g && partials && rows > 0 && cols > 0 && ld >= cols && cols % v == 0 && ld % v == 0 && dtype_ok(dtype), "colsum_partials: bad args");
+  dim3 grid((unsigned)((cols / v + 7) / 8), (unsigned)colsum_slabs(dtype, rows, cols));
+  if (dtype == VLFB_F32)
+    hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), 0, s, (const float*)g, rows, (int)cols, ld, partials);
+  else
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL((colsum_kernel<T16, true>), grid, dim3(256), 0, s, (const T16*)g, rows, (int)cols, ld, partials));
+  return check_launch("colsum (partials)");
+}
+}  // namespace vlfb
+
 extern "C" int vlfb_colsum(const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld,
                            float* out, int accumulate, vlfb_stream_t stream) {
   VLFB_REQUIRE(g && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");

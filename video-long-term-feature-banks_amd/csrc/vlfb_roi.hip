@@ -153,33 +153,44 @@ __global__ void roi_align_max_fwd_kernel(const T* __restrict__ feat, const float
   }
 }
 
-// one thread per (roi, channel); scatters through the selected bin with fp32 atomics
+// Backward of RoIAlign + max: the gradient of (roi, channel) goes through the selected bin's bilinear samples to at most
+// 4 x grid_h x grid_w pixels of the RoI's clip.  DETERMINISTIC: one thread owns a (clip, channel) column of dfeat and adds
+// the contributions of that clip's RoIs in RoI order, sample order, corner order with plain read-modify-writes -- no two
+// threads ever touch the same address (the reference operator scatters with atomics, whose order varies from run to run:
+// overlapping RoIs of a clip hit the same pixels).  R is a few tens, so a thread scanning all RoIs costs nothing.
 template <typename T>
 __global__ void roi_align_max_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
                                          const uint8_t* __restrict__ argbin, float* __restrict__ dfeat,
-                                         long long R, int H, int W, int C, int pooled,
+                                         long long N, long long R, int H, int W, int C, int pooled,
                                          float spatial_scale) {
-  const long long total = R * C;
+  const long long total = N * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / C;
-    const int c = (int)(i - r * C);
-    const RoiGeom g = roi_geom(rois + r * 5, spatial_scale, pooled);
-    const float count = (float)(g.grid_h * g.grid_w);
-    const int bin = argbin[i];
-    const int ph = bin / pooled, pw = bin - ph * pooled;
-    const float gv = Elem<T>::ld(dout + i) / count;
-    float* fb = dfeat + (long long)g.batch * H * W * C + c;
-    for (int iy = 0; iy < g.grid_h; ++iy) {
-      const float y = g.start_h + (float)ph * g.bin_h + (((float)iy + 0.5f) * g.bin_h) / (float)g.grid_h;
-      for (int ix = 0; ix < g.grid_w; ++ix) {
-        const float x = g.start_w + (float)pw * g.bin_w + (((float)ix + 0.5f) * g.bin_w) / (float)g.grid_w;
-        const Bilin b = bilinear(y, x, H, W);
-        if (!b.inside) continue;
-        atomicAdd(fb + ((long long)b.y_low * W + b.x_low) * C, gv * b.w1);
-        atomicAdd(fb + ((long long)b.y_low * W + b.x_high) * C, gv * b.w2);
-        atomicAdd(fb + ((long long)b.y_high * W + b.x_low) * C, gv * b.w3);
-        atomicAdd(fb + ((long long)b.y_high * W + b.x_high) * C, gv * b.w4);
+    const long long n = i / C;
+    const int c = (int)(i - n * C);
+    float* fb = dfeat + n * H * W * C + c;
+    for (long long r = 0; r < R; ++r) {
+      const RoiGeom g = roi_geom(rois + r * 5, spatial_scale, pooled);
+      if ((long long)g.batch != n) continue;
+      const float count = (float)(g.grid_h * g.grid_w);
+      const int bin = argbin[r * C + c];
+      const int ph = bin / pooled, pw = bin - ph * pooled;
+      const float gv = Elem<T>::ld(dout + r * C + c) / count;
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float y = g.start_h + (float)ph * g.bin_h + (((float)iy + 0.5f) * g.bin_h) / (float)g.grid_h;
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          const float x = g.start_w + (float)pw * g.bin_w + (((float)ix + 0.5f) * g.bin_w) / (float)g.grid_w;
+          const Bilin b = bilinear(y, x, H, W);
+          if (!b.inside) continue;
+          float* p1 = fb + ((long long)b.y_low * W + b.x_low) * C;
+          float* p2 = fb + ((long long)b.y_low * W + b.x_high) * C;
+          float* p3 = fb + ((long long)b.y_high * W + b.x_low) * C;
+          float* p4 = fb + ((long long)b.y_high * W + b.x_high) * C;
+          *p1 += gv * b.w1;          // (the four corners may coincide at the border: sequential adds, in this order)
+          *p2 += gv * b.w2;
+          *p3 += gv * b.w3;
+          *p4 += gv * b.w4;
+        }
       }
     }
   }
@@ -254,12 +265,12 @@ extern "C" int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* 
                                       int64_t w, int64_t c, int64_t r, int pooled, float spatial_scale,
                                       vlfb_stream_t stream) {
   VLFB_REQUIRE(dout && rois && argbin && dfeat && n > 0 && h > 0 && w > 0 && c > 0 && r > 0, "roi_align_bwd: bad args");
-  int grid = grid_for(r * c, 256);
+  int grid = grid_for(n * c, 64);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VLFB_F32)
-    hipLaunchKernelGGL(roi_align_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale);
+    hipLaunchKernelGGL(roi_align_max_bwd_kernel<float>, dim3(grid), dim3(64), 0, s, (const float*)dout, rois, argbin, dfeat, (long long)n, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale);
   else if (is16(dtype))
-    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(roi_align_max_bwd_kernel<T16>, dim3(grid), dim3(256), 0, s, (const T16*)dout, rois, argbin, dfeat, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale));
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(roi_align_max_bwd_kernel<T16>, dim3(grid), dim3(64), 0, s, (const T16*)dout, rois, argbin, dfeat, (long long)n, (long long)r, (int)h, (int)w, (int)c, pooled, spatial_scale));
   else return set_error(VLFB_ERR_ARG, "roi_align_bwd: bad dtype");
   return check_launch("roi_align_max_bwd");
 }

@@ -2116,8 +2116,8 @@ class Engine(object):
         if self._operand_version != self._pstate[0]:
             # parameters were changed through another engine that shares them (the train net's solver)
             self.refresh_operands(all_params=True)
-        for b in self._half_inputs:                 # "mix": fp16 copies of the fed blobs the backward reads (clip, bank)
-            hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
+        if self._half_inputs:                       # "mix": fp16 copies of the fed blobs the backward reads (clip, bank)
+            self._half_copies(self._half_inputs)
         if self.side is None or not self.FORWARD_BRANCHES or not self._fwd_side:
             for st in self.steps:
                 self._fwd_step(st)
@@ -2143,8 +2143,24 @@ class Engine(object):
 
     def _fwd_step(self, st):
         st.fwd()
-        for b in st._half_post:                     # "mix": outputs whose fp16 copy no conv epilogue wrote
-            hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
+        if st._half_post:                           # "mix": outputs whose fp16 copy no conv epilogue wrote
+            self._half_copies(st._half_post)
+
+    # "mix": the copy passes only feed the BACKWARD pass, so they do not have to sit in the forward chain: they run on the
+    # parameter-gradient stream (idle during forward) behind an event of the producer; backward() joins that stream first
+    HALF_COPIES_ON_SIDE = True
+
+    def _half_copies(self, blobs):
+        cur = torch.cuda.current_stream() if not self.dry_run else None
+        if self.side is None or not self.HALF_COPIES_ON_SIDE or cur == self.side:
+            for b in blobs:
+                hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
+            return
+        self.wait_event(self.side, self.record_event())
+        with torch.cuda.stream(self.side):
+            for b in blobs:
+                hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
+        self._half_pending = True
 
     def _plan_half_copies(self):
         """which fp16 copies (Blob.half, "mix" dtype) are made by a copy pass: behind the step that produced the values
@@ -2217,6 +2233,9 @@ class Engine(object):
                 b.slot.reset()
         del self._wq[:]               # (parameter-gradient launches a failed backward() left queued: WGRAD_LAG)
         self._bwd_index = 0
+        if getattr(self, "_half_pending", False):    # "mix": the fp16 copies made on the parameter-gradient stream
+            self.wait_stream(self.side)
+            self._half_pending = False
         if self.comm is not None:
             self.comm.begin()
         eager = self._eager_lr is not None
