@@ -325,14 +325,15 @@ def test_full_size_clip_matches_oracle(preset):
             # chain); raw median 1.7e-3 (AVA: ties, as on the split path).  No margin to speak of: 11-bit operands.
             assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 8e-4 and float(ce[-1]) < 1e-3, \
                 sorted(cond, key=lambda x: -x[1])[:5]
-            assert med < 5e-3 and mx < 3e-2, (med, mx)
+            assert med < 3e-3 and mx < 2e-2, (med, mx)
         elif dtype in ("fp32", "split"):
             assert max(a.values()) < 1e-3, acts
             # arithmetic parity (identical branches): EVERY gradient inside the north-star bar
             assert float(ce[-1]) < 1e-3, sorted(cond, key=lambda x: -x[1])[:5]
-            # raw comparison: tie-limited (measured 3e-5 .. 2e-3 median, up to 9e-3 on conv1_w, from run to run of
-            # mathematically equivalent kernels) -- a regression gate, not the parity claim
-            assert med < 5e-3 and mx < 3e-2, (med, mx)
+            # raw comparison: tie-limited (measured median 2.6e-5 / 3.2e-5 on the fp32 path, 1.6e-3 / 1.4e-4 on the split path
+            # whose forward decides 307 instead of 20 units differently; max 1.0e-2, conv1_w) -- a regression gate at twice the
+            # measured values, not the parity claim
+            assert med < 3e-3 and mx < 2e-2, (med, mx)
         else:
             assert max(v for k, v in a.items() if k not in ("prob", "loss")) < 2e-2, acts
             assert a["prob"] < 1e-3 and a["loss"] < 1e-3, acts
