@@ -353,11 +353,16 @@ def _spacetime_nonlocal(cx, x, prefix, dim_inner):
     shp5 = theta.shape
     theta, phi, g = (t.reshape(Bn, dim_inner, -1) for t in (theta, phi, g))
     aff = torch.bmm(theta.transpose(1, 2), phi)                    # BatchMatMul(trans_a=1)
-    assert cfg.NONLOCAL.USE_SOFTMAX
-    if cfg.NONLOCAL.USE_SCALE:
-        aff = aff * dim_inner ** -0.5
-    p = torch.softmax(aff, dim=2)
-    cx.B[prefix + "_affinity_prob"] = p
+    if cfg.NONLOCAL.USE_SOFTMAX:
+        if cfg.NONLOCAL.USE_SCALE:
+            aff = aff * dim_inner ** -0.5
+        p = torch.softmax(aff, dim=2)
+        cx.B[prefix + "_affinity_prob"] = p
+    else:
+        # dot-product variant (nonlocal_helper.py:107-119): ConstantFill(1) -> ReduceBackSum = number of keys, broadcast,
+        # StopGradient, Div -- no scale, no softmax
+        p = aff / float(aff.shape[2])
+        cx.B[prefix + "_affinity_sc"] = p
     t = torch.bmm(g, p.transpose(1, 2)).reshape(shp5)               # BatchMatMul(trans_b=1)
     out = _conv(t, P, prefix + "_out")
     return _norm(cx, out, prefix + "_bn", nonlocal_block=True)

@@ -103,9 +103,9 @@ def test_test_split_and_lfb_inference_plans():
 def test_unsupported_graphs_fail_loudly():
     from vlfb.presets import load_preset
     from models.model_builder_video import ModelBuilder
-    load_preset("charades_r50_baseline", ["NONLOCAL.USE_SOFTMAX", "False"])
+    load_preset("charades_r50_baseline", ["RESNETS.NUM_GROUPS", 2, "RESNETS.WIDTH_PER_GROUP", 32])
     m = ModelBuilder(train=True, split="train", name="t")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):       # grouped convolution: the one graph option of the builders left out
         m.build_model(suffix="_train")
 
 
@@ -193,3 +193,18 @@ def test_other_dtypes_plan_without_half_copies():
         assert not eng.mix and all(b.half is None for b in eng.all_blobs)
         assert not eng._half_inputs and not any(st._half_post for st in eng.steps)
         assert eng.bcode == eng.code and not any(b.slot.two_term for b in eng.all_blobs if b.root is b)
+
+
+def test_dot_product_nonlocal_variant_lowers_to_the_same_attention_step():
+    """NONLOCAL.USE_SOFTMAX False (reference nonlocal_helper.py:107-119): BatchMatMul -> ConstantFill(1) -> ReduceBackSum ->
+    ConstantFill(0) -> Add(broadcast) -> StopGradient -> Div -> BatchMatMul is recorded operator by operator and lowers
+    to ONE attention step whose scores product carries 1 / L2 (no Scale, no Softmax)"""
+    from vlfb.engine import AttentionStep
+    cfg, m, eng = plan("charades_r50_baseline", overrides=("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "NONLOCAL.USE_SOFTMAX", False))
+    types = [o.type for o in m.net.ops]
+    assert types.count("ReduceBackSum") == 5 and types.count("Div") == 5 and "Softmax" not in types and "Scale" not in types
+    att = [s for s in eng.steps if isinstance(s, AttentionStep)]
+    assert len(att) == 5 and len(eng.steps) == 89 and all(a.dot and not a.fused_fwd and not a.fused_bwd for a in att)
+    a = att[-1]
+    assert a.prob.name == "nonlocal_conv4_5_affinity_sc" and abs(a.d_s.alpha * a.L2 - 1.0) < 1e-6
+    assert abs(a.d_dp.alpha * a.L2 / a.ds_scale - 1.0) < 1e-6

@@ -593,3 +593,35 @@ def test_a_training_step_is_reproducible_bit_for_bit(dtype):
     for a, b, what in zip(states[0], states[1], ("parameters", "momentum", "gradients")):
         assert torch.equal(a, b), "%s differ between two identical runs (%d of %d words)" % (
             what, int((a != b).sum()), a.numel())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "split", "mix", "fp16"])
+def test_dot_product_nonlocal_variant(dtype):
+    """NONLOCAL.USE_SOFTMAX False (reference nonlocal_helper.py:107-119; no shipped yaml sets it): the affinity divided by the
+    number of keys instead of the softmax.  Forward blobs, loss and every parameter gradient against the oracle.  The bench's
+    weight recipe (trained-BatchNorm-like gains) is used: without the softmax's normalisation the blocks square the
+    activation scale, and the oracle recipe's unit gains overflow fp64 after five blocks."""
+    from oracle import model as om
+    from vlfb import synth
+    cfg, model, eng, inputs, params, seed_fn = build("charades_r50_baseline", dtype, SMALL + ["NONLOCAL.USE_SOFTMAX", False])
+    params = synth.params(model, seed=cfg.RNG_SEED)
+    eng.feed_params(params)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    tol = {"fp32": 1e-5, "split": 1e-4, "mix": 1e-4, "fp16": 5e-3}[dtype]
+    for name in ("nonlocal_conv3_1_sum", "nonlocal_conv4_1_affinity_sc", "res4_5_branch2c_bn", "res5_2_branch2c_bn", "prob"):
+        got = eng.fetch(name)
+        e = rel(got, blobs[name].detach().numpy().reshape(got.shape))
+        assert e < tol, (name, e)
+    ref_loss = float(blobs["loss"].detach())
+    assert abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) < 1e-3 * abs(ref_loss)
+    gmax = max(float(g.norm()) for g in grads.values())
+    errs = sorted(((rel(eng.fetch_grad(n), grads[n].numpy()), n) for n in eng.trainable
+                   if float(grads[n].norm()) > 1e-9 * gmax), reverse=True)
+    e = np.array([x for x, _ in errs])
+    print("\n[dot-product NL %s] gradients median %.2e p90 %.2e max %.2e (%s)" % (
+        dtype, np.median(e), np.sort(e)[int(0.9 * (len(e) - 1))], e[0], errs[0][1]))
+    gtol = {"fp32": (1e-3, 5e-3), "split": (1e-3, 5e-3), "mix": (2e-3, 1e-2), "fp16": (3e-2, 0.3)}[dtype]
+    assert np.median(e) < gtol[0] and e[0] < gtol[1], errs[:5]

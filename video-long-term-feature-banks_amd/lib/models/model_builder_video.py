@@ -86,7 +86,9 @@ class ModelBuilder(object):
     # ---- operator emitters (names and argument meaning follow CNNModelHelper) ---------------------
     def ConvNd(self, blob_in, blob_out, dim_in, dim_out, kernel, weight_init=None, bias_init=None,
                strides=None, pads=None, dilations=None, group=1, no_bias=False, **kwargs):
-        assert group == 1, "grouped convolutions are not used by any shipped config"
+        if group != 1:
+            raise NotImplementedError("grouped convolution (RESNETS.NUM_GROUPS = %d): no shipped config uses it and the "
+                                      "implicit-GEMM kernels are not built for it" % group)
         kernel = list(kernel)
         nd = len(kernel)
         w = self._new_param(blob_out + "_w", [dim_out, dim_in] + kernel,

@@ -42,7 +42,14 @@ def spacetime_nonlocal(model, blob_in, dim_in, dim_out, batch_size, prefix, dim_
             scaled = model.Scale(affinity, affinity, scale=dim_inner ** -.5)
         p = model.Softmax(scaled, affinity + "_prob", engine="CUDNN", axis=2)
     else:
-        raise NotImplementedError("NONLOCAL.USE_SOFTMAX False (dot-product variant) is not shipped")
+        # dot-product variant (nonlocal_helper.py:107-119): the affinity divided by the number of keys -- a blob of ones
+        # summed over the last axis, broadcast back, detached
+        ones = model.net.ConstantFill([affinity], [affinity + "_ones"], value=1.)
+        ones = model.net.ReduceBackSum([ones], [affinity + "_const"])
+        zeros = model.net.ConstantFill([affinity], [affinity + "_zeros"], value=0.)
+        denom = model.net.Add([zeros, ones], [affinity + "_denom"], broadcast=1, axis=0)
+        model.StopGradient(denom, denom)
+        p = model.net.Div([affinity, denom], [affinity + "_sc"])
 
     t = model.net.BatchMatMul([g, p], prefix + "_y", trans_b=1)
     t_re, _ = model.Reshape(

@@ -543,9 +543,11 @@ class AttentionStep(Step):
     """BatchMatMul(trans_a) -> Scale -> Softmax(axis=2) -> BatchMatMul(trans_b)
     (nonlocal_helper.py:94-121, lfb_helper.py:223-234) with theta/phi/g stored [B][L][Ci]."""
 
-    def __init__(self, eng, theta, phi, g, prob, out, scale):
+    def __init__(self, eng, theta, phi, g, prob, out, scale, dot=False):
+        """dot: the dot-product variant (NONLOCAL.USE_SOFTMAX False): prob = theta^T phi / L2, no softmax"""
         Step.__init__(self, eng)
         self.theta, self.phi, self.g, self.prob, self.out, self.scale = theta, phi, g, prob, out, scale
+        self.dot = bool(dot)
         self.inputs, self.outputs = [theta, phi, g], [out]
         self.aux_outputs = [prob]
 
@@ -606,8 +608,19 @@ class AttentionStep(Step):
         # 16-bit paths: scores + row softmax (and their backward) in one kernel each, the fp32 score matrix never
         # exists (csrc/vlfb_attn.hip) -- per direction, and only where the library reports the fused kernel as
         # measured faster; otherwise GEMM -> fp32 scratch -> softmax kernels
-        self.fused_fwd = bool(hip.lib().vlfb_attn_scores_supported(code, L1, L2, Ci) & hip.ATTN_FWD_FASTER)
-        self.fused_bwd = bool(hip.lib().vlfb_attn_scores_supported(bcode, L1, L2, Ci) & hip.ATTN_BWD_FASTER) and not self.precise
+        self.fused_fwd = bool(hip.lib().vlfb_attn_scores_supported(code, L1, L2, Ci) & hip.ATTN_FWD_FASTER) and not self.dot
+        self.fused_bwd = bool(hip.lib().vlfb_attn_scores_supported(bcode, L1, L2, Ci) & hip.ATTN_BWD_FASTER) and \
+            not self.precise and not self.dot
+        if self.dot:
+            # p = theta^T phi / L2 comes straight out of the scores product (alpha), and so does dS = dP / L2 backward
+            self.d_s = gemm(out_dtype=code, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mf,
+                            alpha=1.0 / L2, **pl)
+            if self.precise:
+                self.d_dp = gemm(dtype=hip.F32, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci,
+                                 o_bstride=L1 * L2, math=hip.MATH_BF16X3, alpha=self.ds_scale / L2, **pl)
+            else:
+                self.d_dp = gemm(dtype=bcode, out_dtype=bcode, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci,
+                                 o_bstride=L1 * L2, math=mb, alpha=self.ds_scale / L2, **bpl)
         if not (self.fused_fwd and self.fused_bwd):
             eng.need_scratch_f32(B * L1 * L2 + (B * L1 * Ci if self.precise else 0))
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
@@ -627,13 +640,18 @@ class AttentionStep(Step):
                      self.out.ptr(), eng.code, B, L2, Ci, Ci, self.scale)
             return
         if eng.split:
-            S = eng.scratch_f32(B * L1 * L2)
             nf = 3 if eng.math_fwd == hip.MATH_BF16X6 else 2
-            hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, S)
-            hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
+            if self.dot:
+                hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, self.prob.storage())
+            else:
+                S = eng.scratch_f32(B * L1 * L2)
+                hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, S)
+                hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
             hip.conv_run(self.d_y, self.prob.storage(), self._planes(self.g.storage(), nf, True), None, self.out.storage())
             return
-        if self.fused_fwd:
+        if self.dot:
+            hip.conv_run(self.d_s, self.theta.storage(), self.phi.storage(), None, self.prob.storage())
+        elif self.fused_fwd:
             hip.call("vlfb_attn_scores_fwd", self.theta.ptr(), self.phi.ptr(), self.prob.ptr(), eng.code, B, L1, L2, Ci,
                      self.scale)
         else:
@@ -659,6 +677,29 @@ class AttentionStep(Step):
                      eng.bcode, B, L2, Ci, Ci, self.scale)
             return
         P = self.prob.bstorage()
+        if self.dot:
+            # dot-product variant: dS = dP / L2 is the scores-gradient product itself (alpha), no softmax Jacobian
+            gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
+                          supports_add=False, supports_mask=False)
+            act = eng.scratch_act(B * L1 * L2 + B * Ci * L2)
+            dS, phT = act[:B * L1 * L2], act[B * L1 * L2:]
+            if self.precise:
+                f32 = eng.scratch_f32(B * L1 * L2 + B * L1 * Ci)
+                dP, dY32 = f32[:B * L1 * L2], f32[B * L1 * L2:]
+                hip.call("vlfb_cast", hip.ptr(dY), eng.bcode, hip.ptr(dY32), hip.F32, B * L1 * Ci)
+                hip.conv_run(self.d_dp, dY32, self._planes(self.g.storage(), 2, False), None, dP)
+                hip.call("vlfb_cast", hip.ptr(dP), hip.F32, hip.ptr(dS), eng.bcode, B * L1 * L2)
+            else:
+                hip.conv_run(self.d_dp, dY, self._planes(self.g.storage(), 2, False) if self.bsplit else self.g.bstorage(), None, dS)
+            if self.bsplit:
+                phT = self._planes(self.phi.storage(), 2, True)
+            else:
+                hip.call("vlfb_transpose2d", self.phi.bptr(), hip.ptr(phT), eng.bcode, B, L2, Ci)
+            th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
+                          supports_add=False, supports_mask=False)
+            ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.bstorage(), None, dS, out),
+                          supports_add=False, supports_mask=False)
+            return
         if self.precise:
             f32 = eng.scratch_f32(B * L1 * L2 + B * L1 * Ci)
             dP, dY32 = f32[:B * L1 * L2], f32[B * L1 * L2:]
@@ -1304,13 +1345,27 @@ class Lowering(object):
         theta, phi = self.get(op.inputs[0]), self.get(op.inputs[1])
         j = i + 1
         scale = 1.0
-        if self.ssa[j][0].type == "Scale":
-            scale = float(self.ssa[j][0].args["scale"])
+        dot = False
+        if self.ssa[j][0].type == "ConstantFill":
+            # dot-product variant (NONLOCAL.USE_SOFTMAX False, nonlocal_helper.py:107-119): ones -> ReduceBackSum (the
+            # number of keys) -> zeros + broadcast Add -> StopGradient -> Div, i.e. p = affinity / L2
+            seq = [self.ssa[j + k][0] for k in range(6)]
+            aff = op.outputs[0]
+            assert [o.type for o in seq] == ["ConstantFill", "ReduceBackSum", "ConstantFill", "Add", "StopGradient", "Div"] and \
+                float(seq[0].args.get("value")) == 1.0 and float(seq[2].args.get("value")) == 0.0 and \
+                seq[1].inputs == seq[0].outputs and seq[3].inputs == [seq[2].outputs[0], seq[1].outputs[0]] and \
+                seq[5].inputs == [aff, seq[3].outputs[0]], "unexpected operators behind the affinity: %r" % (seq,)
+            dot = True
+            prob_name = seq[5].outputs[0]
+            j += 6
+        else:
+            if self.ssa[j][0].type == "Scale":
+                scale = float(self.ssa[j][0].args["scale"])
+                j += 1
+            sm = self.ssa[j][0]
+            assert sm.type == "Softmax" and sm.args.get("axis") == 2, "expected Softmax(axis=2) after the affinity"
+            prob_name = sm.outputs[0]
             j += 1
-        sm = self.ssa[j][0]
-        assert sm.type == "Softmax" and sm.args.get("axis") == 2, "expected Softmax(axis=2) after the affinity"
-        prob_name = sm.outputs[0]
-        j += 1
         mm = self.ssa[j][0]
         assert mm.type == "BatchMatMul" and mm.args.get("trans_b"), "expected BatchMatMul(trans_b=1)"
         g = self.get(mm.inputs[0])
@@ -1335,7 +1390,8 @@ class Lowering(object):
         prob = self.new_blob(prob_name, (B, L1, L2), 2, "f32" if single else "act")
         out = self.new_blob(mm.outputs[0], (B, Ci, L1), 1)
         out.needs_grad = True
-        self.add_step(AttentionStep(self.eng, theta, phi, g, prob, out, scale))
+        assert not (dot and single), "the dot-product variant belongs to the space-time non-local block"
+        self.add_step(AttentionStep(self.eng, theta, phi, g, prob, out, scale, dot=dot))
         self.env[prob_name] = prob
         self.env[mm.outputs[0]] = out
         return j + 1
