@@ -2208,7 +2208,8 @@ class Engine(object):
 
     def _half_copies(self, blobs):
         cur = torch.cuda.current_stream() if not self.dry_run else None
-        if self.side is None or not self.HALF_COPIES_ON_SIDE or cur == self.side:
+        # (a captured forward pass has to end with every forked stream joined: the copies stay in the chain there)
+        if self.side is None or not self.HALF_COPIES_ON_SIDE or cur == self.side or self.STEP_GRAPH:
             for b in blobs:
                 hip.call("vlfb_half_copy", b.ptr(), hip.ptr(b.half), b.half.numel())
             return
