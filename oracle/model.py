@@ -46,8 +46,8 @@ def param_spec(cfg, lfb_infer_only=False):
     """OrderedDict name -> dict(shape, kind, fan_out, std, trainable)."""
     spec = OrderedDict()
 
-    def conv(name, cout, cin, k, bias, kind, std=None):
-        spec[name + "_w"] = dict(shape=(cout, cin) + tuple(k), kind=kind, std=std, trainable=True)
+    def conv(name, cout, cin, k, bias, kind, std=None, groups=1):
+        spec[name + "_w"] = dict(shape=(cout, cin // groups) + tuple(k), kind=kind, std=std, trainable=True)
         if bias:
             spec[name + "_b"] = dict(shape=(cout,), kind="zero_bias", trainable=True)
 
@@ -62,9 +62,9 @@ def param_spec(cfg, lfb_infer_only=False):
         spec[name + "_rm"] = dict(shape=(c,), kind="bn_rm", trainable=False)
         spec[name + "_riv"] = dict(shape=(c,), kind="bn_riv", trainable=False)
 
-    def conv_affine(prefix, cout, cin, k):
+    def conv_affine(prefix, cout, cin, k, groups=1):
         """Conv3dAffine, or Conv3dBN when MODEL.USE_AFFINE is off (resnet_helper.py:28-32)"""
-        conv(prefix, cout, cin, k, False, "msra")
+        conv(prefix, cout, cin, k, False, "msra", groups=groups)
         (affine if cfg.MODEL.USE_AFFINE else bn)(prefix + "_bn", cout)
 
     def nonlocal_block(prefix, c, ci):
@@ -99,7 +99,7 @@ def param_spec(cfg, lfb_infer_only=False):
             p = "%s_%d" % (prefix, i)
             utc = arc[si + 1][i]
             conv_affine(p + "_branch2a", dinner, din, (1 + 2 * utc, 1, 1))
-            conv_affine(p + "_branch2b", dinner, dinner, (1, 3, 3))
+            conv_affine(p + "_branch2b", dinner, dinner, (1, 3, 3), groups=cfg.RESNETS.NUM_GROUPS)   # resnet_helper.py:56-63
             conv_affine(p + "_branch2c", dout, dinner, (1, 1, 1))
             if i == 0:
                 conv_affine(p + "_branch1", dout, din, (1, 1, 1))
@@ -316,14 +316,14 @@ def _norm(cx, x, prefix, nonlocal_block=False):
     return _bn(cx, x, prefix, cfg.MODEL.BN_EPSILON, cfg.MODEL.BN_MOMENTUM)
 
 
-def _conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
-    """ConvNd, NCTHW cross-correlation; bias iff `<name>_b` exists"""
-    return F.conv3d(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil)
+def _conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1), groups=1):
+    """ConvNd, NCTHW cross-correlation; bias iff `<name>_b` exists; `groups` as Caffe2's `group` argument"""
+    return F.conv3d(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil, groups)
 
 
-def _conv_affine(cx, x, prefix, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
+def _conv_affine(cx, x, prefix, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1), groups=1):
     """ModelBuilder.Conv3dAffine / Conv3dBN (lib/models/model_builder_video.py:176-221)"""
-    return _norm(cx, _conv(x, cx.P, prefix, stride, pad, dil), prefix + "_bn")
+    return _norm(cx, _conv(x, cx.P, prefix, stride, pad, dil, groups), prefix + "_bn")
 
 
 def _bottleneck(cx, x, prefix, dim_in, dim_out, stride, utc, dilation):
@@ -331,7 +331,8 @@ def _bottleneck(cx, x, prefix, dim_in, dim_out, stride, utc, dilation):
     (lib/models/resnet_helper.py:35-119)"""
     h = _relu(cx, _conv_affine(cx, x, prefix + "_branch2a", pad=(utc, 0, 0)), prefix + "_branch2a_bn")
     h = _relu(cx, _conv_affine(cx, h, prefix + "_branch2b", stride=(1, stride, stride),
-                               pad=(0, dilation, dilation), dil=(1, dilation, dilation)), prefix + "_branch2b_bn")
+                               pad=(0, dilation, dilation), dil=(1, dilation, dilation), groups=cx.cfg.RESNETS.NUM_GROUPS),
+              prefix + "_branch2b_bn")
     h = _conv_affine(cx, h, prefix + "_branch2c")
     if dim_in == dim_out and stride == 1:
         sc = x

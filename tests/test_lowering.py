@@ -100,12 +100,30 @@ def test_test_split_and_lfb_inference_plans():
     assert "box_pooled" in eng.env and "pred" not in eng.env and "lfb_test" not in m.input_blob_names
 
 
+def test_grouped_convolution_is_a_batch_of_channel_slice_launches():
+    """RESNETS.NUM_GROUPS > 1 (resnet_helper.py:56-63 forwards `group` to the 1x3x3 conv of every bottleneck; 1 in every
+    shipped config): the weight is (Cout, Cin / G, 1, 3, 3) as in Caffe2, the step launches the ordinary kernels once per
+    group on channel slices (leading dimensions = the tensors' row strides), one weight-operand block per group"""
+    from vlfb.engine import ConvStep
+    ov = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "RESNETS.NUM_GROUPS", 2, "RESNETS.WIDTH_PER_GROUP", 32)
+    cfg, m, eng = plan("charades_r50_baseline", overrides=ov, dtype="mix")
+    assert m.param_init_net.fills["res3_1_branch2b_w"].shape == (128, 64, 1, 3, 3)
+    grouped = [s for s in eng.steps if isinstance(s, ConvStep) and s.group > 1]
+    assert len(grouped) == 16 and all(s.out.name.endswith("_branch2b_bn") for s in grouped)
+    c = [s for s in grouped if s.out.name == "res3_1_branch2b_bn"][0]
+    assert (c.d_f.Cs, c.d_f.Cn, c.d_f.lda, c.d_f.ldo) == (64, 64, 128, 128)
+    assert (c.d_d.Cs, c.d_d.Cn, c.d_d.lda, c.d_d.ldo, c.d_d.ldr) == (64, 64, 128, 128, 128)
+    assert (c.d_w.Cs, c.d_w.Cn, c.d_w.lda, c.d_w.ldp) == (64, 64, 128, 128)
+    assert c.wblk == 64 * 9 * 64 and c.w_f.numel() == 3 * 2 * c.wblk and c.w_d.numel() == 2 * 2 * c.wblk
+    assert len(eng.trainable) == 95          # same parameter catalogue, half the 3x3 weights
+
+
 def test_unsupported_graphs_fail_loudly():
     from vlfb.presets import load_preset
     from models.model_builder_video import ModelBuilder
-    load_preset("charades_r50_baseline", ["RESNETS.NUM_GROUPS", 2, "RESNETS.WIDTH_PER_GROUP", 32])
+    load_preset("charades_r50_baseline", ["RESNETS.NUM_GROUPS", 3])
     m = ModelBuilder(train=True, split="train", name="t")
-    with pytest.raises(NotImplementedError):       # grouped convolution: the one graph option of the builders left out
+    with pytest.raises(ValueError):       # a group count that does not divide the channels
         m.build_model(suffix="_train")
 
 

@@ -627,3 +627,39 @@ def test_dot_product_nonlocal_variant(dtype):
     # mix 4.1e-4 / 5.1e-3, fp16 5.2e-3 / 6.1e-2 (conv1_w every time)
     gtol = {"fp32": (1e-3, 5e-3), "split": (1e-3, 1e-2), "mix": (2e-3, 1e-2), "fp16": (3e-2, 0.3)}[dtype]
     assert np.median(e) < gtol[0] and e[0] < gtol[1], errs[:5]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "split", "mix", "fp16", "bf16"])
+def test_grouped_convolution_model(dtype):
+    """RESNETS.NUM_GROUPS 2 x WIDTH_PER_GROUP 32 (grouped 1x3x3 convs in every bottleneck, resnet_helper.py:56-63; no shipped
+    yaml): forward blobs, loss and every parameter gradient against the oracle (torch's grouped conv3d in fp64)"""
+    from oracle import model as om
+    ov = SMALL + ["RESNETS.NUM_GROUPS", 2, "RESNETS.WIDTH_PER_GROUP", 32]
+    cfg, model, eng, inputs, params, seed_fn = build("charades_r50_baseline", dtype, ov)
+    assert params["res2_0_branch2b_w"].shape == (64, 32, 1, 3, 3)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn)
+    exact = dtype in ("fp32", "split", "mix")
+    for name in ("res2_2_branch2c_bn", "res3_3_branch2c_bn", "res4_5_branch2c_bn", "res5_2_branch2c_bn", "prob"):
+        got = eng.fetch(name)
+        e = rel(got, blobs[name].detach().numpy().reshape(got.shape))
+        assert e < (1e-4 if exact else 2e-2), (name, e)
+    gmax = max(float(g.norm()) for g in grads.values())
+    errs = sorted(((rel(eng.fetch_grad(n), grads[n].numpy()), n) for n in eng.trainable
+                   if float(grads[n].norm()) > 1e-9 * gmax), reverse=True)
+    e = np.array([x for x, _ in errs])
+    print("\n[grouped conv %s] gradients median %.2e p90 %.2e max %.2e (%s)" % (
+        dtype, np.median(e), np.sort(e)[int(0.9 * (len(e) - 1))], e[0], errs[0][1]))
+    if exact:
+        dec = eng.discrete_decisions()
+        _, g2 = om.run(cfg, params, inputs, "train", torch.float64, True, seed_fn, decisions=dec)
+        cond = sorted(((rel(eng.fetch_grad(n), g2[n].numpy()), n) for _, n in errs), reverse=True)
+        print("[grouped conv %s] on identical decisions: max %.2e (%s)" % (dtype, cond[0][0], cond[0][1]))
+        assert cond[0][0] < (1.5e-3 if dtype == "mix" else 1e-3), cond[:5]
+        assert np.median(e) < 2e-3 and e[0] < 2e-2, errs[:5]
+    else:
+        assert np.sort(e)[int(0.9 * (len(e) - 1))] < 0.12 and e[0] < 0.35, errs[:5]
+    eng.sgd_step(0.01)
+    torch.cuda.synchronize()

@@ -86,12 +86,12 @@ class ModelBuilder(object):
     # ---- operator emitters (names and argument meaning follow CNNModelHelper) ---------------------
     def ConvNd(self, blob_in, blob_out, dim_in, dim_out, kernel, weight_init=None, bias_init=None,
                strides=None, pads=None, dilations=None, group=1, no_bias=False, **kwargs):
-        if group != 1:
-            raise NotImplementedError("grouped convolution (RESNETS.NUM_GROUPS = %d): no shipped config uses it and the "
-                                      "implicit-GEMM kernels are not built for it" % group)
+        if group < 1 or dim_in % group or dim_out % group:
+            raise ValueError("ConvNd %s: group = %d does not divide %d -> %d channels" % (blob_out, group, dim_in, dim_out))
         kernel = list(kernel)
         nd = len(kernel)
-        w = self._new_param(blob_out + "_w", [dim_out, dim_in] + kernel,
+        # Caffe2's grouped Conv: weight (dim_out, dim_in / group, k...), output channel block g reads input channel block g
+        w = self._new_param(blob_out + "_w", [dim_out, dim_in // group] + kernel,
                             weight_init or ("XavierFill", {}), True)
         inputs = [blob_in, w]
         if not no_bias:

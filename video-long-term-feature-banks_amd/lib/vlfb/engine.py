@@ -43,6 +43,15 @@ def _prod(xs):
     return out
 
 
+def _at(t, elems):
+    """device address of element `elems` of a flat tensor (None stays None): the channel slice / weight block of a group"""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        raise TypeError("_at needs the tensor (element size)")
+    return t.data_ptr() + int(elems) * t.element_size()
+
+
 # ================================================================================================
 # values
 # ================================================================================================
@@ -220,8 +229,12 @@ class Step(object):
 class ConvStep(Step):
     """ConvNd [+ AffineNd] [+ residual Sum] [+ ReLU] as one implicit-GEMM launch."""
 
-    def __init__(self, eng, x, out, wname, cbname, kernels, strides, pads, dils):
+    def __init__(self, eng, x, out, wname, cbname, kernels, strides, pads, dils, group=1):
+        """group > 1 (RESNETS.NUM_GROUPS, resnet_helper.py:56-63; no shipped config): output channel block g reads input
+        channel block g -- G launches of the ordinary kernels on channel SLICES of the tensors (pointer offset + the
+        descriptor's leading dimensions), one weight-operand block per group.  Correct, not tuned."""
         Step.__init__(self, eng)
+        self.group = int(group)
         self.x, self.out = x, out
         self.inputs, self.outputs = [x], [out]
         self.wname, self.cbname = wname, cbname
@@ -245,7 +258,14 @@ class ConvStep(Step):
         eng = self.eng
         N, Cin, T, H, W = self.x.shape
         _, Cout, To, Ho, Wo = self.out.shape
-        self.Cin_k = 4 if self.stem else Cin          # channels as the kernel sees them
+        G = self.group
+        assert not (self.stem and G > 1)
+        self.Cin_k = 4 if self.stem else Cin // G     # channels as the kernel sees them (one group's)
+        self.Cog = Cout // G                          # output channels of one group
+        # grouped: a launch works on a channel slice -- the tensors keep their row strides
+        ld_f = dict(lda=Cin, ldo=Cout, ldr=Cout) if G > 1 else {}
+        ld_d = dict(lda=Cout, ldo=Cin, ldr=Cin) if G > 1 else {}
+        ld_w = dict(lda=Cin, ldp=Cout) if G > 1 else {}
         self.pack = 8 if self.stem else 0
         code, bcode = eng.code, eng.bcode
         geom = self._geom()
@@ -261,12 +281,13 @@ class ConvStep(Step):
         # split-bf16 math on fp32 storage (Engine dtype "split"): the weight operand copies are bf16 term planes
         wshape = eng.kernel_shape(self.wname)
         mf, mb = eng.math_fwd, eng.math_bwd
-        planes = dict(b_pstride=_prod(wshape)) if eng.split else {}
+        self.wblk = _prod(wshape) // G                # elements of one group's weight block
+        planes = dict(b_pstride=self.wblk) if eng.split else {}
         bplanes = planes if mb != hip.MATH_NATIVE else {}          # ("mix": split forward, native fp16 backward)
         self.d_f = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
-                                 Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, relu=int(self.relu),
+                                 Ws=W, Cs=self.Cin_k, Cn=self.Cog, pack_w=self.pack, relu=int(self.relu),
                                  bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, math=mf,
-                                 **planes, **geom)
+                                 **planes, **geom, **ld_f)
         self.d_d = None
         self.w2 = False
         self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
@@ -292,19 +313,19 @@ class ConvStep(Step):
                     rows = dict(N=N, Tr=1, Hr=T, Wr=H * W, Ts=1, Hs=To, Ws=Ho * Wo)
                 alpha /= hip.MIX_W2_SCALE
                 self.w2 = True
-            self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=bcode, Cs=Cout, Cn=Cin, alpha=alpha, math=mb,
-                                     **rows, **bplanes, **dg)
+            self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=bcode, Cs=self.Cog, Cn=Cin // G, alpha=alpha, math=mb,
+                                     **rows, **bplanes, **dg, **ld_d)
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
-                                     Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
-                                     math=mb, **geom)
+                                     Hs=H, Ws=W, Cs=self.Cin_k, Cn=self.Cog, pack_w=self.pack, alpha=1.0 / self.gscale,
+                                     math=mb, **geom, **ld_w)
             # "mix": the gradient arriving at `out` is fp32 (Blob.grad_f32): WGRAD as split-bf16 products on the fp32 operands
             self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
             if self.bwd_f32:
                 self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=hip.F32, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
-                                         Hs=H, Ws=W, Cs=self.Cin_k, Cn=Cout, pack_w=self.pack, alpha=1.0 / self.gscale,
-                                         math=hip.MATH_BF16X3, **geom)
+                                         Hs=H, Ws=W, Cs=self.Cin_k, Cn=self.Cog, pack_w=self.pack, alpha=1.0 / self.gscale,
+                                         math=hip.MATH_BF16X3, **geom, **ld_w)
             # a conv with a trainable bias (the non-local / FBO convs): the WGRAD launch also produces the bias gradient --
             # db = alpha * s * column sums of the output gradient it reads anyway (vlfb_conv_run_wgrad_bias)
             if self.cbname and eng.is_trainable(self.cbname) and eng.FUSE_BIAS_GRAD:
@@ -328,10 +349,10 @@ class ConvStep(Step):
                 self.g_planes = torch.empty(2 * self.out.numel, device=eng.device, dtype=torch.bfloat16)
         unit = tuple(self.s) == (1, 1, 1)
         plain = unit and tuple(self.k) == (1, 1, 1) and tuple(self.p) == (0, 0, 0)
-        self.dgrad_takes_planes = bool(eng.split and eng.PLANES and (plain or (unit and Cout % 32 == 0)))
+        self.dgrad_takes_planes = bool(eng.split and eng.PLANES and G == 1 and (plain or (unit and Cout % 32 == 0)))
         # FPROP reads its input as planes too when the forward products are the three-term ones (two planes per operand:
         # the LDS image of the plane DGRAD; six-term products would need three planes of both operands, 96 KiB per stage)
-        self.fprop_takes_planes = bool(eng.split and eng.PLANES and eng.FPROP_PLANES and mf == hip.MATH_BF16X3 and
+        self.fprop_takes_planes = bool(eng.split and eng.PLANES and eng.FPROP_PLANES and mf == hip.MATH_BF16X3 and G == 1 and
                                        not self.stem and (plain or self.Cin_k % 32 == 0))
         # operand copies (split math: 3 bf16 term planes for FPROP, 2 for DGRAD -- include/vlfb.h VLFB_SPLIT)
         if eng.split:
@@ -345,6 +366,10 @@ class ConvStep(Step):
             else:
                 self.w_d = (torch.empty(2 * _prod(wshape), device=eng.device, dtype=torch.bfloat16) if eng.split else
                             torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype))
+        # one group's weight-operand block: [planes][wblk] elements, group g at g * planes * wblk (vlfb_weight_prep* is run
+        # per group, so the term planes of a group lie next to each other)
+        self.wf_npl = 3 if eng.split else 1
+        self.wd_npl = (2 if self.w2 else 1) if eng.mix else (2 if eng.split else 1)
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
@@ -360,12 +385,19 @@ class ConvStep(Step):
     def refresh(self):
         """rebuild the MFMA operand copies from the fp32 masters (after a solver step / feed)"""
         eng = self.eng
-        Cout = self.out.shape[1]
         w = eng.param_tensor(self.wname)
         s = eng.param_tensor(self.sname) if self.sname else None
-        hip.call("vlfb_weight_prep", hip.ptr(w), hip.ptr(s), hip.ptr(self.w_f), hip.ptr(self.w_d),
-                 eng.wcode, Cout, self.taps(), self.Cin_k)
+        for g in range(self.group):
+            hip.call("vlfb_weight_prep", _at(w, g * self.wblk), _at(s, g * self.Cog), self.wf_ptr(g), self.wd_ptr(g),
+                     eng.wcode, self.Cog, self.taps(), self.Cin_k)
         self.refresh_bias()
+
+    def wf_ptr(self, g):
+        """FPROP weight operand of group g"""
+        return _at(self.w_f, g * self.wf_npl * self.wblk)
+
+    def wd_ptr(self, g):
+        return _at(self.w_d, g * self.wd_npl * self.wblk)
 
     def refresh_bias(self):
         eng = self.eng
@@ -418,8 +450,15 @@ class ConvStep(Step):
         elif self.out.root.half is not None:       # "mix": the fp16 copy the backward reads, written by this epilogue
             op = self.out.root.half
             kw.update(o_planes=1)
-        hip.conv_run(self._pl_desc(self.d_f, **kw) if kw else self.d_f, self.x.storage() if xp is None else xp, self.w_f, None,
-                     self.out.storage(), bias=self.bias_tensor(), R=R, O_planes=op)
+        d = self._pl_desc(self.d_f, **kw) if kw else self.d_f
+        if self.group == 1:
+            hip.conv_run(d, self.x.storage() if xp is None else xp, self.w_f, None,
+                         self.out.storage(), bias=self.bias_tensor(), R=R, O_planes=op)
+            return
+        xs, os_, bt = self.x.storage(), self.out.storage(), self.bias_tensor()
+        for g in range(self.group):                # channel slices: block g of the outputs reads block g of the inputs
+            hip.conv_run(d, _at(xs, g * self.Cin_k), self.wf_ptr(g), None, _at(os_, g * self.Cog), bias=_at(bt, g * self.Cog),
+                         R=_at(R, g * self.Cog), O_planes=_at(op, g * self.Cog))
 
     def bwd(self):
         eng = self.eng
@@ -449,8 +488,14 @@ class ConvStep(Step):
                     kw.update(o_planes=2, o_pstride=planes.numel() // 2)
                 d = self._pl_desc(self.d_d, **kw) if kw else self.d_d
                 xs = self.x.root.slot
-                hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes,
-                             R_lo=xs.add_lo, O_lo=xs.out_lo)
+                if self.group == 1:
+                    hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes,
+                                 R_lo=xs.add_lo, O_lo=xs.out_lo)
+                    return
+                for gi in range(self.group):
+                    c = gi * self.Cin_k
+                    hip.conv_run(d, _at(g, gi * self.Cog), self.wd_ptr(gi), None, _at(out, c), R=_at(add, c), mask=_at(mask, c),
+                                 O_planes=_at(planes, c), R_lo=_at(xs.add_lo, c), O_lo=_at(xs.out_lo, c))
             self.x.root.slot.contribute(dgrad, writes_planes=True)
 
     def _param_grads(self, g, gp=None):
@@ -463,10 +508,18 @@ class ConvStep(Step):
                 hip.call("vlfb_split_planes", hip.ptr(g), hip.ptr(self.g_planes), 2, 1, self.out.numel // 8, 8, 0)
                 d = self._pl_desc(self.d_w, a_planes=self.x_npl, a_pstride=n, p_planes=2, p_pstride=self.out.numel)
                 hip.conv_run(d, self.x_planes, None, self.g_planes, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
-            elif gp is not None and xp is not None and not self.stem:
+            elif gp is not None and xp is not None and not self.stem and self.group == 1:
                 # both operands pre-split: DMA + transposed LDS reads, no VALU in the k-loop
                 d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2, wgrad_bias=0)
                 hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
+            elif self.group > 1:
+                xsrc, gw = (self.x.storage() if self.bwd_f32 else self.x.bstorage()), eng.grad_tensor(self.wname)
+                gb = eng.grad_tensor(self.cbname) if self.d_w.wgrad_bias else None
+                for gi in range(self.group):
+                    hip.conv_run(self.d_w, _at(xsrc, gi * self.Cin_k), None, _at(g, gi * self.Cog), _at(gw, gi * self.wblk),
+                                 rowscale=_at(s, gi * self.Cog), workspace=eng.workspace, dbias=_at(gb, gi * self.Cog))
+                if gb is not None:
+                    return
             elif self.d_w.wgrad_bias:
                 hip.conv_run(self.d_w, self.x.storage() if self.bwd_f32 else self.x.bstorage(), None, g,
                              eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace, dbias=eng.grad_tensor(self.cbname))
@@ -1179,10 +1232,11 @@ class Lowering(object):
         N, Cin, T, H, W = x.shape
         wshape = self.model.param_init_net.fills[wname].shape
         Cout = wshape[0]
-        assert wshape[1] == Cin, "conv %s: weight expects %d channels, input has %d" % (wname, wshape[1], Cin)
+        group = int(a.get("group", 1))
+        assert wshape[1] * group == Cin, "conv %s: weight expects %d x %d channels, input has %d" % (wname, group, wshape[1], Cin)
         dims = [(n_ + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for n_, kk, ss, pp, dd in zip((T, H, W), k, s, p, d)]
         out_name = op.outputs[0]
-        step = ConvStep(eng, x, None, wname, cbname, k, s, p, d)
+        step = ConvStep(eng, x, None, wname, cbname, k, s, p, d, group=group)
         j = i
         cur = outs[0]
         if self.sole_reader_is_next(j, cur, ("AffineNd",)):
@@ -2033,15 +2087,16 @@ class Engine(object):
         """device table for vlfb_weight_prep_batched over these conv steps: (tensor, items, tiles) or None"""
         items, tile = [], 0
         for st in convs:
-            cout, taps, cin = st.out.shape[1], st.taps(), st.Cin_k
-            it = hip.WPrepItem()
-            it.w = hip.ptr(self.param_tensor(st.wname))
-            it.scale = hip.ptr(self.param_tensor(st.sname)) if st.sname else None
-            it.w_fprop = hip.ptr(st.w_f)
-            it.w_dgrad = hip.ptr(st.w_d) if st.w_d is not None else None
-            it.cout, it.taps, it.cin, it.tile_begin = cout, taps, cin, tile
-            tile += taps * ((cout + 31) // 32) * ((cin + 31) // 32)
-            items.append(it)
+            cout, taps, cin = st.Cog, st.taps(), st.Cin_k
+            for g in range(st.group):              # (a grouped conv: one item per group, each with its own operand block)
+                it = hip.WPrepItem()
+                it.w = _at(self.param_tensor(st.wname), g * st.wblk)
+                it.scale = _at(self.param_tensor(st.sname), g * cout) if st.sname else None
+                it.w_fprop = st.wf_ptr(g)
+                it.w_dgrad = st.wd_ptr(g) if st.w_d is not None else None
+                it.cout, it.taps, it.cin, it.tile_begin = cout, taps, cin, tile
+                tile += taps * ((cout + 31) // 32) * ((cin + 31) // 32)
+                items.append(it)
         if not items:
             return None
         arr = (hip.WPrepItem * len(items))(*items)
