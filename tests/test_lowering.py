@@ -119,12 +119,15 @@ def test_grouped_convolution_is_a_batch_of_channel_slice_launches():
 
 
 def test_unsupported_graphs_fail_loudly():
-    from vlfb.presets import load_preset
-    from models.model_builder_video import ModelBuilder
-    load_preset("charades_r50_baseline", ["RESNETS.NUM_GROUPS", 3])
-    m = ModelBuilder(train=True, split="train", name="t")
-    with pytest.raises(ValueError):       # a group count that does not divide the channels
-        m.build_model(suffix="_train")
+    """what the kernels cannot run is refused when the engine plans, with the library's own message -- never a fallback:
+    ResNeXt-32x4d has 4 channels per group in res2, and a 16-byte operand chunk is 8 (16-bit) channels"""
+    from vlfb import hip
+    with pytest.raises(hip.VlfbError, match="Cs=4"):
+        plan("charades_r50_baseline", overrides=("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "RESNETS.NUM_GROUPS", 32,
+                                                 "RESNETS.WIDTH_PER_GROUP", 4))
+    with pytest.raises(ValueError):       # a group count that does not divide the channels (not reachable from the yaml keys)
+        from models.model_builder_video import ModelBuilder
+        ModelBuilder(train=True, split="train", name="t").ConvNd("x", "y", 64, 64, [1, 3, 3], group=3, no_bias=True)
 
 
 def test_spatial_bn_graph_lowers_to_bn_steps():
