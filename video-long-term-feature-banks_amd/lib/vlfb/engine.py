@@ -1714,6 +1714,39 @@ class Engine(object):
     def on_side_stream(self):
         return Engine._Side(self)
 
+    # Fraction of the CUs the parameter-gradient stream may use (hipExtStreamCreateWithCUMask; 1.0 = an ordinary stream).
+    # The idea: the main stream (forward, dgrad chain) is the critical path of a step and the parameter gradients finish
+    # with ~6 ms of slack, so confining them to a part of the chip would leave the rest to the chain alone.  MEASURED
+    # (round 4, one box, 8 clips): 1.0 -> 455.1 / 452.9 clips/s fp16; 0.875 -> 277.0, 0.75 -> 281.0, 0.625 -> 273.9,
+    # 0.5 -> 273.2, 0.375 -> 245.8; mix 240.3 -> 173.1 (0.75) / 167.7 (0.5).  A masked queue costs far more than it frees
+    # (the whole-row / streaming kernels are sized for one workgroup per CU of the full chip, and the two queues stop
+    # overlapping the way unmasked ones do).  Off; kept as a switch so the measurement can be repeated.
+    SIDE_CU_FRACTION = float(os.environ.get("VLFB_SIDE_CU_FRACTION", "1.0"))
+
+    def _make_side_stream(self):
+        frac = float(self.SIDE_CU_FRACTION)
+        if frac >= 1.0:
+            return torch.cuda.Stream(device=self.device)
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        # groups of 8 consecutive mask bits are taken or left whole, spread evenly: whatever the bit -> (XCD, CU) map is
+        # (round-robin over the 8 XCDs or XCD-major), every XCD keeps the same share
+        ngroups = (ncu + 7) // 8
+        take = max(1, int(round(frac * ngroups)))
+        words = [0] * ((ncu + 31) // 32)
+        for k in range(take):
+            gidx = (k * ngroups) // take
+            for b in range(8 * gidx, min(8 * gidx + 8, ncu)):
+                words[b // 32] |= 1 << (b % 32)
+        rt = C.CDLL("libamdhip64.so")
+        stream = C.c_void_p()
+        mask = (C.c_uint32 * len(words))(*words)
+        torch.cuda.set_device(self.device)
+        rc = rt.hipExtStreamCreateWithCUMask(C.byref(stream), C.c_uint32(len(words)), mask)
+        if rc != 0:
+            raise hip.VlfbError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+        self._side_cu_mask = words
+        return torch.cuda.ExternalStream(stream.value, device=self.device)
+
     # Parameter gradients are leaves of the backward graph: when they run does not matter as long as it is after their
     # output gradient exists (event) and before the all-reduce / solver.  WGRAD_LAG = k issues the parameter gradients of
     # backward step i only after the dgrad chain has advanced to step i + k, so that the (MFMA-bound) res5 / res4 wgrads run
@@ -1834,7 +1867,7 @@ class Engine(object):
         if not self.dry_run:
             self.refresh_operands(all_params=True)
             if self.train and self.use_side_stream:
-                self.side = torch.cuda.Stream(device=self.device)
+                self.side = self._make_side_stream()
                 self.solver_stream = torch.cuda.Stream(device=self.device)
         if self.train:
             self._plan_solver_buckets()
