@@ -1,0 +1,563 @@
+"""Run the REFERENCE's own host-side functions around the hot path and commit their outputs.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference; the GPU box has none):
+
+    python oracle/make_ref_aux_golden.py              # writes tests/golden/ref_aux.npz
+
+Sections (each is the reference's code, imported from where it lies and called with seeded synthetic inputs):
+  lr      lib/utils/lr_policy.py:41-157 get_lr_at_iter on every shipped config and on the other policies / warm-up
+          settings; model_builder_video.py:392 _get_lr_change_ratio
+  misc    lib/utils/misc.py:68-80,97 get_batch_size / get_crop_size / unscope_name
+  lfb     tools/lfb_loader.py:49-112 construct_frame_level_lfb / construct_ava_lfb; lib/datasets/ava.py:300-323,
+          charades.py:238-276, epic.py:310-374 sample_lfb / get_lfb_frames / sample_verb_lfb / sample_noun_lfb
+  prep    lib/datasets/data_input_helper.py:70-139 images_and_boxes_preprocessing with everything it calls in
+          lib/datasets/image_processor.py (jitter, crops, flips, box transforms, normalisation, channel order)
+  mc      lib/utils/metrics.py:619-711 merge_ava_3shift_score_files / merge_ava_score_files (the AVA multi-crop merge)
+  ckpt    lib/utils/checkpoints.py:88-146 (BN fold, field / momentum removal), :271-383 initialize_master_gpu_model_params
+          (classifier rule, 2-D -> 3-D inflation, momentum policy, lr blob) and :421-459 save_model_params
+
+What is substituted, and why it is not the thing under test:
+  * Caffe2: `workspace` is a dict (FeedBlob / FetchBlob / Blobs), `core.NameScope` sets the prefix `scope.CurrentNameScope()`
+    returns, `DeviceScope` / `DeviceOption` do nothing -- blob storage, no arithmetic.
+  * OpenCV (not installed; the reference pins no version): `cv2.resize` is oracle.preprocess.resize_u8 -- the restated
+    INTER_LINEAR, still PARITY-UNPINNED -- and `cv2.flip(img, 1)` is `img[:, ::-1]`.  Everything else in the
+    preprocessing (order of random draws, sizes, offsets, box arithmetic, normalisation) is the reference's.
+  * Python 2 -> 3: `cPickle` = pickle; files are opened in binary mode ('r' -> 'rb', 'w' -> 'wb'); dictionaries read from
+    pickles answer `.keys()` with a list (remove_momentum, checkpoints.py:126-129, deletes while it iterates);
+    byte-string config defaults are decoded (see make_ref_graph_golden.py).
+"""
+import builtins
+import contextlib
+import io
+import json
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+OUT = os.path.join(HERE, "..", "tests", "golden", "ref_aux.npz")
+sys.path.insert(0, os.path.join(HERE, ".."))
+
+
+class Py2Dict(dict):
+    def keys(self):
+        return list(dict.keys(self))
+
+
+def _py2(obj):
+    if isinstance(obj, dict):
+        return Py2Dict((k, _py2(v)) for k, v in obj.items())
+    return obj
+
+
+class DictWorkspace(object):
+    """caffe2.python.workspace as a dict"""
+
+    def __init__(self):
+        self.blobs = {}
+
+    def install(self, module):
+        module.FeedBlob = self.FeedBlob
+        module.FetchBlob = self.FetchBlob
+        module.Blobs = self.Blobs
+        module.HasBlob = lambda n: str(n) in self.blobs
+
+    def FeedBlob(self, name, arr):
+        self.blobs[str(name)] = np.array(arr)
+        return True
+
+    def FetchBlob(self, name):
+        return self.blobs[str(name)]
+
+    def Blobs(self):
+        return list(self.blobs.keys())
+
+
+def install_stubs():
+    from oracle import make_ref_graph_golden as G
+    config, resnet_video = G._import_reference()
+    mb = G._import_reference_builder()
+    python = sys.modules["caffe2.python"]
+    scope, core, pb2 = python.scope, python.core, sys.modules["caffe2.proto.caffe2_pb2"]
+    state = {"scope": ""}
+    scope._NAMESCOPE_SEPARATOR = "/"
+    scope.CurrentNameScope = lambda: state["scope"]
+
+    @contextlib.contextmanager
+    def NameScope(prefix):
+        old = state["scope"]
+        state["scope"] = old + prefix + "/"
+        try:
+            yield
+        finally:
+            state["scope"] = old
+
+    @contextlib.contextmanager
+    def DeviceScope(opt):
+        yield
+    core.NameScope, core.DeviceScope, core.DeviceOption = NameScope, DeviceScope, lambda *a, **k: None
+    pb2.CUDA = 1
+    sys.modules["cPickle"] = pickle
+    from oracle import preprocess as op
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+
+    def resize(image, size, interpolation=None):
+        assert interpolation == cv2.INTER_LINEAR and image.dtype == np.uint8
+        return op.resize_u8(image, size[0], size[1])
+    cv2.resize = resize
+    cv2.flip = lambda image, code: np.ascontiguousarray(image[:, ::-1]) if code == 1 else None
+    cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda flag: None)      # dataset_helper.py:30, at import
+    sys.modules["cv2"] = cv2
+    return config, mb
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def section_lr(config, mb, reset, meta, arrays):
+    import glob
+    import utils.lr_policy as lr_policy
+    cases = [(os.path.basename(p)[:-5], []) for p in sorted(glob.glob(os.path.join(REF, "configs", "*.yaml")))]
+    cases += [
+        ("ava_r50_lfb_nl", ["SOLVER.WARMUP.WARMUP_ON", False]),
+        ("ava_r50_lfb_nl", ["SOLVER.WARMUP.WARMUP_END_ITER", 7, "SOLVER.WARMUP.WARMUP_START_LR", 0.0]),
+        ("charades_r50_baseline", ["SOLVER.LR_POLICY", "steps_with_lrs", "SOLVER.LRS", "[0.3, 0.07, 0.0011]"]),
+        ("charades_r50_baseline", ["SOLVER.LR_POLICY", "steps_with_decay", "SOLVER.GAMMA", 0.3]),
+        ("charades_r50_baseline", ["SOLVER.LR_POLICY", "steps_with_decay", "SOLVER.WARMUP.WARMUP_ON", True,
+                                   "SOLVER.WARMUP.WARMUP_END_ITER", 123, "SOLVER.WARMUP.WARMUP_START_LR", 0.001]),
+        ("epic_verb_r50_lfb_nl", ["SOLVER.BASE_LR", 0.0007]),
+    ]
+    out = []
+    for k, (name, overrides) in enumerate(cases):
+        reset()
+        config.cfg_from_file(os.path.join(REF, "configs", name + ".yaml"))
+        if overrides:
+            config.cfg_from_list([o if isinstance(o, str) else str(o) for o in overrides])
+        config.assert_and_infer_cfg()
+        sol = config.config.SOLVER
+        its = {0, 1, 2, 3, 10, 1000, sol.MAX_ITER - 1, sol.MAX_ITER, sol.MAX_ITER + 5, 10 * sol.MAX_ITER}
+        for s in sol.STEPS:
+            its |= {max(s - 1, 0), s, s + 1}
+        w = sol.WARMUP.WARMUP_END_ITER
+        its |= {max(w - 2, 0), max(w - 1, 0), w, w + 1, w // 2}
+        its = sorted(its)
+        lrs, raises = [], []
+        for i in its:
+            try:
+                v = lr_policy.get_lr_at_iter(i)
+                assert isinstance(v, np.float32)
+                lrs.append(v)
+                raises.append(False)
+            except IndexError:             # an iteration past the last LRS entry (the schedules end at MAX_ITER)
+                lrs.append(np.float32("nan"))
+                raises.append(True)
+        arrays["lr_%d_iters" % k] = np.array(its, dtype=np.int64)
+        arrays["lr_%d_values" % k] = np.array(lrs, dtype=np.float32)
+        arrays["lr_%d_raises" % k] = np.array(raises)
+        out.append({"config": name, "overrides": overrides})
+    pairs = [(0.1, 0.01), (0.01, 0.1), (0.04, 0.04), (1e-12, 0.1), (0.1, 0.0), (0.00125, 0.04), (0.04, 0.004)]
+    arrays["lr_change_pairs"] = np.array(pairs, dtype=np.float64)
+    arrays["lr_change_ratio"] = np.array([mb._get_lr_change_ratio(a, b) for a, b in pairs], dtype=np.float64)
+    meta["lr"] = out
+
+
+def section_misc(config, reset, meta):
+    import utils.misc as misc
+    out = []
+    for name, overrides in [("ava_r50_lfb_nl", []), ("charades_r50_baseline", ["NUM_GPUS", 4]),
+                            ("epic_verb_r50_lfb_nl", ["TRAIN.BATCH_SIZE", 24, "TEST.BATCH_SIZE", 8, "TEST.CROP_SIZE", 224])]:
+        reset()
+        config.cfg_from_file(os.path.join(REF, "configs", name + ".yaml"))
+        if overrides:
+            config.cfg_from_list([str(o) for o in overrides])
+        config.assert_and_infer_cfg()
+        out.append({"config": name, "overrides": overrides,
+                    "batch": {s: misc.get_batch_size(s) for s in ("train", "val", "test")},
+                    "crop": {s: misc.get_crop_size(s) for s in ("train", "val", "test")}})
+    names = ["gpu_0/conv1_w", "conv1_w", "gpu_3/a/b_momentum", "gpu_0/"]
+    meta["misc"] = {"sizes": out, "unscope": [[n, misc.unscope_name(n)] for n in names]}
+
+
+def section_lfb(config, reset, meta, arrays):
+    sys.path.insert(0, os.path.join(REF, "tools"))
+    import lfb_loader
+    import datasets.ava as ava
+    import datasets.charades as charades
+    import datasets.epic as epic
+    rng = np.random.RandomState(7)
+    D = 6
+    cases = []
+
+    def load(name, overrides):
+        reset()
+        config.cfg_from_file(os.path.join(REF, "configs", name + ".yaml"))
+        config.cfg_from_list([str(o) for o in overrides])
+        config.assert_and_infer_cfg()
+
+    # -- AVA: construction from per-iteration, per-GPU feature / metadata batches, then the windowed draw ------------
+    load("ava_r50_lfb_nl", ["LFB.LFB_DIM", D, "LFB.WINDOW_SIZE", 9, "AVA.LFB_MAX_NUM_FEAT_PER_STEP", 3])
+    feats, metas = [], []
+    for it in range(3):
+        fi, mi = [], []
+        for gpu in range(2):
+            r = int(rng.randint(1, 7))
+            f = rng.standard_normal((r, D, 1, 1, 1)).astype(np.float32)
+            m = np.stack([rng.randint(0, 3, r) + rng.uniform(-0.2, 0.2, r),          # video id, as the float it travels as
+                          rng.randint(900, 912, r) + rng.uniform(-0.3, 0.3, r),      # second
+                          rng.uniform(size=r), rng.uniform(size=r)], 1).astype(np.float32)
+            fi.append(f)
+            mi.append(m)
+        feats.append(fi)
+        metas.append(mi)
+    lfb = lfb_loader.construct_ava_lfb(feats, metas)
+    arrays["lfb_ava_feats"] = np.concatenate([f.reshape(len(f), D) for fi in feats for f in fi])
+    arrays["lfb_ava_meta"] = np.concatenate([m for mi in metas for m in mi])
+    arrays["lfb_ava_batch_rows"] = np.array([[len(f) for f in fi] for fi in feats], dtype=np.int64)
+    bank_rows, bank_keys = [], []
+    for v in sorted(lfb):
+        for s in sorted(lfb[v]):
+            for f in lfb[v][s]:
+                bank_keys.append((v, s))
+                bank_rows.append(f)
+    arrays["lfb_ava_bank_keys"] = np.array(bank_keys, dtype=np.int64)      # append order inside a (video, sec) kept
+    arrays["lfb_ava_bank_rows"] = np.array(bank_rows, dtype=np.float32)
+    draws = []
+    for k, (video, sec, seed) in enumerate([(0, 905, 1), (1, 900, 2), (2, 911, 3), (0, 950, 4), (1, 906, 5)]):
+        np.random.seed(seed)
+        out = ava.sample_lfb(lfb[video], sec)
+        arrays["lfb_ava_sample_%d" % k] = np.asarray(out)
+        draws.append({"video": video, "sec": sec, "np_seed": seed})
+    cases.append({"kind": "ava", "dim": D, "window": 9, "max_per_step": 3, "draws": draws})
+
+    # -- Charades: frame-level bank --------------------------------------------------------------------------------
+    load("charades_r50_lfb_nl", ["LFB.LFB_DIM", D, "LFB.WINDOW_SIZE", 8, "CHARADES.LFB_CLIPS_PER_SECOND", 2])
+    nframes = [100, 37, 260]
+    frames = charades.get_lfb_frames([[None] * n for n in nframes])
+    arrays["lfb_ch_frames"] = np.array(frames, dtype=np.int64)
+    per_gpu = 5
+    total = len(frames)
+    nb = -(-total // (2 * per_gpu))
+    feats = [[rng.standard_normal((per_gpu, D, 1, 1, 1)).astype(np.float32) for _ in range(2)] for _ in range(nb)]
+    config.config.DATASET = "charades"
+    bank = lfb_loader.construct_frame_level_lfb(feats, frames)
+    arrays["lfb_ch_feats"] = np.concatenate([f.reshape(per_gpu, D) for fi in feats for f in fi])
+    keys = [(v, f) for v in sorted(bank) for f in sorted(bank[v])]
+    arrays["lfb_ch_bank_keys"] = np.array(keys, dtype=np.int64)
+    arrays["lfb_ch_bank_rows"] = np.array([bank[v][f] for v, f in keys], dtype=np.float32)
+    q = [(0, 0), (0, 50), (0, 99), (1, 5), (1, 36), (2, 130), (2, 259), (2, 20)]
+    arrays["lfb_ch_queries"] = np.array(q, dtype=np.int64)
+    arrays["lfb_ch_samples"] = np.stack([charades.sample_lfb(v, c, bank) for v, c in q])
+    cases.append({"kind": "charades", "dim": D, "window": 8, "clips_per_second": 2, "num_frames": nframes,
+                  "per_gpu": per_gpu})
+
+    # -- EPIC verb (frame-level features) and noun (a variable number of detections per frame) ---------------------
+    load("epic_verb_r50_lfb_nl", ["LFB.LFB_DIM", D, "LFB.WINDOW_SIZE", 7])
+    vbank = {f: rng.standard_normal(D).astype(np.float32) for f in range(15, 600, 30)}
+    q = [15, 100, 300, 590, 5000, 44]
+    arrays["lfb_ev_bank_keys"] = np.array(sorted(vbank), dtype=np.int64)
+    arrays["lfb_ev_bank_rows"] = np.array([vbank[f] for f in sorted(vbank)], dtype=np.float32)
+    arrays["lfb_ev_queries"] = np.array(q, dtype=np.int64)
+    arrays["lfb_ev_samples"] = np.stack([np.asarray(epic.sample_verb_lfb(c, vbank), dtype=np.float64) for c in q])
+    cases.append({"kind": "epic_verb", "dim": D, "window": 7})
+    load("epic_noun_r50_lfb_nl", ["LFB.LFB_DIM", D, "LFB.WINDOW_SIZE", 12, "EPIC.MAX_NUM_FEATS_PER_NOUN_LFB_FRAME", 4,
+                                  "EPIC.NOUN_LFB_FRAMES_PER_SECOND", 1])
+    nbank, counts = {}, []
+    for f in range(0, 400, 30):
+        n = int(rng.randint(0, 7))
+        nbank[f] = rng.standard_normal((n, D)).astype(np.float32) if n else []
+        counts.append((f, n))
+    arrays["lfb_en_counts"] = np.array(counts, dtype=np.int64)
+    arrays["lfb_en_rows"] = np.concatenate([nbank[f] for f, n in counts if n])
+    q = [0, 45, 200, 390, 1000]
+    arrays["lfb_en_queries"] = np.array(q, dtype=np.int64)
+    arrays["lfb_en_samples"] = np.stack([np.asarray(epic.sample_noun_lfb(c, nbank), dtype=np.float64) for c in q])
+    cases.append({"kind": "epic_noun", "dim": D, "window": 12, "max_per_frame": 4, "frames_per_second": 1})
+    meta["lfb"] = cases
+
+
+def section_prep(config, reset, meta, arrays):
+    import datasets.data_input_helper as dih
+    rng = np.random.RandomState(11)
+    cases = []
+    k = 0
+    for (h, w) in [(40, 56), (56, 40), (48, 48)]:
+        frames = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(3)]
+        arrays["prep_frames_%dx%d" % (h, w)] = np.stack(frames)
+        for split, shift, boxes_on, dataset, force_flip, bgr, seed in [
+                (1, 1, True, "ava", False, False, 1), (1, 1, True, "ava", False, False, 2), (1, 1, False, "charades", False, False, 3),
+                (1, 1, True, "ava", False, True, 4),
+                (0, 0, True, "ava", False, False, 5), (0, 1, True, "ava", True, False, 6), (0, 2, True, "ava", False, False, 7),
+                (0, 1, False, "charades", False, False, 8), (0, 2, True, "charades", True, False, 9)]:
+            reset()
+            config.cfg_from_file(os.path.join(REF, "configs", "ava_r50_lfb_nl.yaml"))
+            crop = 28 if split == 1 else 32
+            config.cfg_from_list(["TRAIN.JITTER_SCALES", "[32, 40]", "TEST.SCALE", "32", "DATASET", dataset,
+                                  "AVA.FORCE_TEST_FLIP", str(force_flip), "MODEL.USE_BGR", str(bgr)])
+            config.assert_and_infer_cfg()
+            boxes = None
+            if boxes_on:
+                b = rng.uniform(0, 1, (4, 4))
+                boxes = np.stack([np.minimum(b[:, 0], b[:, 2]), np.minimum(b[:, 1], b[:, 3]),
+                                  np.maximum(b[:, 0], b[:, 2]) + 0.05, np.maximum(b[:, 1], b[:, 3]) + 0.05], 1)
+                arrays["prep_%d_boxes_in" % k] = boxes.copy()
+            np.random.seed(seed)
+            imgs, out_boxes = dih.images_and_boxes_preprocessing([f.copy() for f in frames], split, crop, shift,
+                                                                 boxes=None if boxes is None else boxes.copy())
+            arrays["prep_%d_clip" % k] = np.ascontiguousarray(imgs)
+            if out_boxes is not None:
+                arrays["prep_%d_boxes_out" % k] = np.asarray(out_boxes)
+            cases.append({"frames": [h, w], "split": split, "crop": crop, "shift": shift, "boxes": boxes_on,
+                          "dataset": dataset, "force_flip": force_flip, "use_bgr": bgr, "np_seed": seed,
+                          "jitter": [32, 40], "test_scale": 32, "clip_dtype": str(np.asarray(imgs).dtype)})
+            k += 1
+    meta["prep"] = cases
+    meta["prep_mean_std"] = [list(map(float, dih.DATA_MEAN)), list(map(float, dih.DATA_STD))]
+
+
+def section_ckpt(config, reset, meta, arrays):
+    import utils.checkpoints as ck
+    pyws = sys.modules["caffe2.python"].workspace
+
+    class PickleShim(object):
+        HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+
+        @staticmethod
+        def load(f):
+            return _py2(pickle.load(f))
+
+        dump = staticmethod(pickle.dump)
+    ck.pickle = PickleShim
+    ck.open = lambda name, mode="r": builtins.open(name, {"r": "rb", "w": "wb"}.get(mode, mode))
+    rng = np.random.RandomState(5)
+    tmp = tempfile.mkdtemp()
+
+    # -- a Caffe2 classification checkpoint: BN blobs to fold, momentum and bookkeeping fields to drop ------------------
+    src = {}
+    for layer, c in [("conv1", 8), ("res2_0_branch2a", 4), ("nonlocal_conv3_1", 6)]:
+        src[layer + "_w"] = rng.standard_normal((c, 3, 3, 3)).astype(np.float32)
+        src[layer + "_w_momentum"] = rng.standard_normal((c, 3, 3, 3)).astype(np.float32)
+        src[layer + "_bn_s"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        src[layer + "_bn_b"] = rng.standard_normal(c).astype(np.float32)
+        src[layer + "_bn_rm"] = rng.standard_normal(c).astype(np.float32)
+        src[layer + "_bn_riv"] = rng.uniform(0.1, 2.0, c).astype(np.float32)
+    src["pred_w"] = rng.standard_normal((5, 8)).astype(np.float32)
+    src["pred_b"] = rng.standard_normal(5).astype(np.float32)
+    src.update({"epoch": 3, "model_iter": 1234, "lr": np.float32(0.01)})
+    path = os.path.join(tmp, "cls.pkl")
+    with open(path, "wb") as f:
+        pickle.dump({"blobs": src}, f, protocol=2)
+    for n, v in src.items():
+        arrays["ckpt_cls_in/" + n] = np.asarray(v)
+    conv = ck.load_and_convert_caffe2_cls_model(path)
+    for n, v in conv["blobs"].items():
+        arrays["ckpt_cls_out/" + n] = np.asarray(v)
+
+    # -- initialisation of a graph from a weights file --------------------------------------------------------------------
+    class FakeNet(object):
+        def __init__(self, name):
+            self._name = name
+
+        def Name(self):
+            return self._name
+
+    class FakeModel(object):
+        def __init__(self, name, params, computed, frozen):
+            self.net = FakeNet(name)
+            self.params = ["gpu_0/" + p for p in params]
+            self.computed = ["gpu_0/" + p for p in computed]
+            self.frozen = set("gpu_0/" + p for p in frozen)
+
+        def TrainableParams(self, scope=""):
+            return [p for p in self.params if p not in self.frozen]
+
+        def GetParams(self, namescope=None):
+            return list(self.params)
+
+        def GetAllParams(self, namescope=None):
+            return self.params + self.computed
+
+        def GetComputedParams(self, namescope=None):
+            return list(self.computed)
+
+    shapes = {                                    # what the graph holds (workspace shapes)
+        "conv1_w": (8, 3, 5, 7, 7),               # file: 2-D kernel (8, 3, 7, 7) -> inflated over 5 frames
+        "res2_0_branch2a_w": (4, 8, 3, 1, 1),     # file: (4, 8, 1, 1) -> inflated over 3
+        "res2_0_branch2b_w": (4, 4, 1, 3, 3),     # file: already 5-D
+        "res2_0_branch2a_bn_s": (4,), "res2_0_branch2a_bn_b": (4,),
+        "res2_0_branch2b_bn_s": (4,), "res2_0_branch2b_bn_b": (4,),      # not in the file: keeps its initial value
+        "pred_w": (6, 10), "pred_b": (6,),        # file pred_w (6, 10, 1, 1): same size -> reshaped; pred_b (7,): skipped
+        "lfb_nl0_theta_w": (4, 4, 1, 1, 1),
+        "bn_rm": (4,),
+    }
+    params = [n for n in shapes if n != "bn_rm"]
+    frozen = ["res2_0_branch2a_bn_s", "res2_0_branch2a_bn_b", "res2_0_branch2b_bn_s", "res2_0_branch2b_bn_b"]
+    file_blobs = {
+        "conv1_w": rng.standard_normal((8, 3, 7, 7)).astype(np.float64),          # (float64 in the file -> fed as float32)
+        "res2_0_branch2a_w": rng.standard_normal((4, 8, 1, 1)).astype(np.float32),
+        "res2_0_branch2b_w": rng.standard_normal((4, 4, 1, 3, 3)).astype(np.float32),
+        "res2_0_branch2a_bn_s": rng.standard_normal(4).astype(np.float32),
+        "res2_0_branch2a_bn_b": rng.standard_normal(4).astype(np.float32),
+        "pred_w": rng.standard_normal((6, 10, 1, 1)).astype(np.float32),
+        "pred_b": rng.standard_normal(7).astype(np.float32),
+        "lfb_nl0_theta_w": rng.standard_normal((4, 4, 1, 1, 1)).astype(np.float32),
+        "bn_rm": rng.standard_normal(4).astype(np.float32),
+        "conv1_w_momentum": rng.standard_normal((8, 3, 7, 7)).astype(np.float32),
+        "res2_0_branch2b_w_momentum": rng.standard_normal((4, 4, 1, 3, 3)).astype(np.float32),
+        "pred_w_momentum": rng.standard_normal((6, 10)).astype(np.float32),
+        "unrelated_blob": rng.standard_normal(3).astype(np.float32),
+        "model_iter": 4321, "lr": np.float32(0.004),
+    }
+    for n, v in file_blobs.items():
+        arrays["ckpt_file/" + n] = np.asarray(v)
+    init = {n: rng.standard_normal(s).astype(np.float32) for n, s in shapes.items()}
+    init_mom = {n: rng.standard_normal(shapes[n]).astype(np.float32) for n in params if n not in frozen}
+    for n, v in init.items():
+        arrays["ckpt_init/" + n] = v
+    for n, v in init_mom.items():
+        arrays["ckpt_init/" + n + "_momentum"] = v
+    runs = []
+    for r, (net_name, wrap, momentum, with_lr, reset_iter) in enumerate([
+            ("train", True, True, True, True), ("train", False, False, True, True), ("test", True, True, True, True),
+            ("train", True, True, False, True)]):
+        reset()
+        config.cfg_from_file(os.path.join(REF, "configs", "ava_r50_lfb_nl.yaml"))
+        config.cfg_from_list(["NUM_GPUS", "2", "TRAIN.RESET_START_ITER", str(reset_iter)])
+        config.assert_and_infer_cfg()
+        ws = DictWorkspace()
+        ws.install(pyws)
+        for n, v in init.items():
+            ws.FeedBlob("gpu_0/" + n, v)
+        for n, v in init_mom.items():
+            ws.FeedBlob("gpu_0/" + n + "_momentum", v)
+        blobs = dict(file_blobs)
+        if not with_lr:
+            del blobs["lr"]
+        path = os.path.join(tmp, "w%d.pkl" % r)
+        with open(path, "wb") as f:
+            pickle.dump({"blobs": blobs} if wrap else blobs, f, protocol=2)
+        model = FakeModel(net_name, params, ["bn_rm"], frozen)
+        model_iter, prev_lr = ck.initialize_master_gpu_model_params(model, path, load_momentum=momentum)
+        for n, v in ws.blobs.items():
+            arrays["ckpt_run%d/%s" % (r, n)] = np.asarray(v)
+        runs.append({"net": net_name, "wrapped": wrap, "load_momentum": momentum, "file_has_lr": with_lr,
+                     "reset_start_iter": reset_iter, "model_iter": int(model_iter), "prev_lr": float(prev_lr),
+                     "dtypes": {n: str(np.asarray(v).dtype) for n, v in ws.blobs.items()}})
+        if r == 0:
+            out = os.path.join(tmp, "saved.pkl")
+            ck.save_model_params(model, out, 99)
+            with open(out, "rb") as f:
+                saved = pickle.load(f)
+            assert list(saved.keys()) == ["blobs"]
+            for n, v in saved["blobs"].items():
+                arrays["ckpt_saved/" + n] = np.asarray(v)
+            runs[-1]["saved_keys"] = sorted(saved["blobs"].keys())
+    meta["ckpt"] = {"shapes": {n: list(s) for n, s in shapes.items()}, "params": params, "computed": ["bn_rm"],
+                    "frozen": frozen, "runs": runs}
+
+
+def section_multicrop(config, reset, meta, arrays):
+    """lib/utils/metrics.py:623-711 on synthetic score files.  Python-2 leftovers in that module: `map` must return a
+    list (`box = map(float, ...)` is indexed, :642,:662; `np.mean(map(sigmoid, ...))`, :676); the evaluation call at
+    the end of both functions (:684,:710 -- eval protocol, out of scope) is a no-op; `cv2.imread` (only `.shape` is
+    used, :649-651) returns an array of the frame size the case names; sklearn is not needed by these functions."""
+    if "sklearn" not in sys.modules:
+        try:
+            import sklearn.metrics  # noqa: F401
+        except Exception:
+            sk = types.ModuleType("sklearn")
+            sk.metrics = types.ModuleType("sklearn.metrics")
+            sys.modules["sklearn"], sys.modules["sklearn.metrics"] = sk, sk.metrics
+    import utils.metrics as metrics
+    metrics.map = lambda f, *a: list(builtins.map(f, *a))
+    metrics.eval_ava_score_file = lambda name: None
+    cv2 = sys.modules["cv2"]
+    rng = np.random.RandomState(21)
+    tmp = tempfile.mkdtemp()
+    old = os.getcwd()
+    os.chdir(tmp)
+    try:
+        cases = []
+        for k, (H, W, scales) in enumerate([(360, 640, [224, 256, 320]), (480, 360, [256]), (240, 320, [256, 320])]):
+            reset()
+            config.cfg_from_file(os.path.join(REF, "configs", "ava_r50_lfb_nl.yaml"))
+            config.assert_and_infer_cfg()
+            cv2.imread = lambda path, H=H, W=W: np.zeros((H, W, 3), np.uint8)
+            nb, ncls = 9, 3
+            x1 = rng.uniform(0, 0.9, nb)
+            y1 = rng.uniform(0, 0.9, nb)
+            boxes = np.stack([x1, y1, np.minimum(x1 + rng.uniform(0.02, 0.6, nb), 1.0),
+                              np.minimum(y1 + rng.uniform(0.02, 0.6, nb), 1.0)], 1)
+            boxes[0] = [0.0, 0.1, 0.08, 0.5]           # left edge only
+            boxes[1] = [0.93, 0.2, 1.0, 0.6]           # right edge only
+            boxes = np.array([[float("%.3f" % v) for v in b] for b in boxes])      # (as written to the csv)
+            logits = rng.standard_normal((len(scales), 2, 3, nb, ncls)) * 3
+            files = []
+            for si, scale in enumerate(scales):
+                for fi, flip in enumerate([False, True]):
+                    names = []
+                    for shift in range(3):
+                        name = "detections_final_%d%s_shift%d_%.03f.csv" % (scale, "_flip" if flip else "", shift, 0.9)
+                        with open(name, "w") as f:
+                            for b in range(nb):
+                                for c in range(ncls):
+                                    f.write("vid%d,%04d,%.3f,%.3f,%.3f,%.3f,%d,%r\n" % (
+                                        k, 900 + b, boxes[b, 0], boxes[b, 1], boxes[b, 2], boxes[b, 3], c + 1,
+                                        float(logits[si, fi, shift, b, c])))
+                        names.append(name)
+                    files.append(metrics.merge_ava_3shift_score_files(names, flip, scale))
+            per_file = np.array([[float(line.split(",")[-1]) for line in open(f)] for f in files])
+            metrics.merge_ava_score_files(files)
+            final = np.array([float(line.split(",")[-1]) for line in open("final_multi_crop_testing_results.csv")])
+            arrays["mc_%d_boxes" % k] = boxes
+            arrays["mc_%d_logits" % k] = logits
+            arrays["mc_%d_combined" % k] = per_file.reshape(len(scales), 2, nb, ncls)
+            arrays["mc_%d_final" % k] = final.reshape(nb, ncls)
+            cases.append({"height": H, "width": W, "scales": scales})
+            for f in os.listdir("."):
+                os.remove(f)
+        meta["multicrop"] = cases
+    finally:
+        os.chdir(old)
+
+
+def main():
+    config, mb = install_stubs()
+    import copy
+
+    def snap(d):
+        return {k: snap(v) if isinstance(v, dict) else copy.deepcopy(v) for k, v in d.items()}
+    defaults = snap(config.config)
+
+    def reset():
+        def rec(dst, src):
+            for k in list(dst.keys()):
+                if k not in src:
+                    del dst[k]
+            for k, v in src.items():
+                if isinstance(v, dict):
+                    rec(dst[k], v)
+                else:
+                    dst[k] = copy.deepcopy(v)
+        rec(config.config, defaults)
+
+    meta, arrays = {"generator": "oracle/make_ref_aux_golden.py"}, {}
+    section_lr(config, mb, reset, meta, arrays)
+    section_misc(config, reset, meta)
+    section_lfb(config, reset, meta, arrays)
+    section_prep(config, reset, meta, arrays)
+    section_ckpt(config, reset, meta, arrays)
+    section_multicrop(config, reset, meta, arrays)
+    arrays["meta"] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8)
+    buf = io.BytesIO()
+    np.savez_compressed(buf, **arrays)
+    with open(OUT, "wb") as f:
+        f.write(buf.getvalue())
+    print("wrote %s: %d arrays, %d bytes" % (os.path.normpath(OUT), len(arrays), os.path.getsize(OUT)))
+
+
+if __name__ == "__main__":
+    main()

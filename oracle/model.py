@@ -322,7 +322,12 @@ def _conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1), groups=1):
 
 
 def _conv_affine(cx, x, prefix, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1), groups=1):
-    """ModelBuilder.Conv3dAffine / Conv3dBN (lib/models/model_builder_video.py:176-221)"""
+    """ModelBuilder.Conv3dAffine / Conv3dBN (lib/models/model_builder_video.py:176-221).  Conv3dBN does not forward
+    `dilations=` to ConvNd (:176-183, it lands in **kwargs) while the caller still pads for the dilated kernel
+    (resnet_helper.py:57): a batch-norm graph runs the undilated kernel on the dilated pads, and with cfg.DILATIONS = 2
+    the residual Sum of res5_0 then fails on its shapes (torch raises here, Caffe2 there)."""
+    if not cx.cfg.MODEL.USE_AFFINE:
+        dil = (1, 1, 1)
     return _norm(cx, _conv(x, cx.P, prefix, stride, pad, dil, groups), prefix + "_bn")
 
 

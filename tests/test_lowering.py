@@ -136,6 +136,12 @@ def test_spatial_bn_graph_lowers_to_bn_steps():
     bucket; res3 non-local blocks are not grouped in this graph (resnet_video.py:248-272)"""
     ov = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64,
           "MODEL.USE_AFFINE", False, "NONLOCAL.USE_BN", True, "NONLOCAL.USE_AFFINE", False]
+    # the reference's Conv3dBN swallows `dilations=` (model_builder_video.py:176-183) while resnet_helper.py:57 still pads
+    # for the dilated kernel: with cfg.DILATIONS = 2 res5_0_branch2b comes out 2 pixels larger per side and the residual
+    # Sum cannot be formed -- Caffe2 fails when the net runs, the engine when it plans
+    with pytest.raises(ValueError, match="Sum.res5_0_branch2c_bn, res5_0_branch1_bn.: operand shapes differ"):
+        plan("ava_r50_lfb_nl", ov)
+    ov += ["MODEL.DILATIONS_AFTER_CONV5", False]
     cfg, m, eng = plan("ava_r50_lfb_nl", ov)
     k = kinds(eng)
     assert k["BNStep"] == 1 + 16 * 3 + 4 + 5

@@ -206,7 +206,8 @@ def test_spatial_bn_graph_matches_torch_batch_norm_and_moves_the_running_statist
     from core.config import config as cfg
     from oracle import model as om
     load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 32,
-                                          "MODEL.USE_AFFINE", False, "NONLOCAL.USE_BN", True, "NONLOCAL.USE_AFFINE", False])
+                                          "MODEL.USE_AFFINE", False, "NONLOCAL.USE_BN", True, "NONLOCAL.USE_AFFINE", False,
+                                          "MODEL.DILATIONS_AFTER_CONV5", False])
     spec = om.param_spec(cfg)
     assert spec["res_conv1_bn_s"]["trainable"] and spec["res_conv1_bn_b"]["trainable"]
     assert not spec["res_conv1_bn_rm"]["trainable"] and not spec["nonlocal_conv4_1_bn_riv"]["trainable"]

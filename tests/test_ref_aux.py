@@ -1,0 +1,353 @@
+"""Host logic and oracle restatements against outputs of the REFERENCE's own functions.
+
+tests/golden/ref_aux.npz was produced by oracle/make_ref_aux_golden.py, which imports the reference's modules from
+/root/reference in the build container and calls them on seeded synthetic inputs (what it had to substitute -- a dict for
+the Caffe2 workspace, the restated INTER_LINEAR for cv2.resize, Python-2 leftovers -- is listed in its docstring).  Nothing
+here needs the reference tree: the fixture travels.
+
+  * learning-rate schedule            utils.lr_policy (product)            == lib/utils/lr_policy.py, bit for bit (float32)
+  * per-GPU batch / crop, unscoping   utils.misc (product)                 == lib/utils/misc.py
+  * bank construction and sampling    oracle.lfb (checker of csrc/vlfb_lfb.hip) == tools/lfb_loader.py, datasets/{ava,charades,epic}.py
+  * clip + box preprocessing          oracle.preprocess (checker of csrc/vlfb_data.hip) == data_input_helper.py / image_processor.py
+  * checkpoint import / export        utils.checkpoints (product)          == lib/utils/checkpoints.py
+"""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_aux.npz")
+Z = np.load(GOLDEN)
+META = json.loads(bytes(Z["meta"]).decode())
+
+
+def _load(name, overrides):
+    """the same configuration the generator loaded (YAML of that name + overrides), from this repo's presets / config"""
+    from core import config as C
+    from vlfb.presets import PRESETS, load_preset
+    if name in PRESETS:
+        return load_preset(name, overrides)
+    # no preset of that name: the reference's effective configuration from the graph fixture (tests/test_ref_graph.py)
+    tree = json.loads(json.dumps(_ref_cfgs()[name]))
+    tree["LFB"].pop("NUM_LFB_FEAT")
+    tree["SOLVER"]["STEPS"] = None
+    C.reset_cfg()
+    C.merge_dicts(tree, C.config)
+    if overrides:
+        C.cfg_from_list([str(x) for x in overrides])
+    C.assert_and_infer_cfg()
+    return C.config
+
+
+_REF_CFGS = {}
+
+
+def _ref_cfgs():
+    if not _REF_CFGS:
+        import gzip
+        with gzip.open(os.path.join(os.path.dirname(GOLDEN), "ref_graphs.json.gz"), "rb") as fh:
+            for g in json.loads(fh.read().decode())["graphs"]:
+                if not g["overrides"]:
+                    _REF_CFGS[g["config"]] = g["cfg"]
+    return _REF_CFGS
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---- learning rate ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", range(len(META["lr"])), ids=lambda k: "%s%s" % (META["lr"][k]["config"], "+" * bool(META["lr"][k]["overrides"])))
+def test_lr_schedule_bit_for_bit(k):
+    import utils.lr_policy as lr_policy
+    case = META["lr"][k]
+    _load(case["config"], case["overrides"])
+    for it, want, raises in zip(Z["lr_%d_iters" % k], Z["lr_%d_values" % k], Z["lr_%d_raises" % k]):
+        if raises:
+            with pytest.raises(IndexError):
+                lr_policy.get_lr_at_iter(int(it))
+            continue
+        got = lr_policy.get_lr_at_iter(int(it))
+        assert isinstance(got, np.float32)
+        assert bits(got) == bits(want), (int(it), float(got), float(want))
+
+
+def test_lr_change_ratio():
+    from models.model_builder_video import _get_lr_change_ratio
+    for (a, b), want in zip(Z["lr_change_pairs"], Z["lr_change_ratio"]):
+        assert _get_lr_change_ratio(a, b) == want
+
+
+# ---- misc ----------------------------------------------------------------------------------------------------------------
+def test_batch_crop_and_unscope():
+    import utils.misc as misc
+    for case in META["misc"]["sizes"]:
+        _load(case["config"], case["overrides"])
+        for s in ("train", "val", "test"):
+            assert misc.get_batch_size(s) == case["batch"][s] and misc.get_crop_size(s) == case["crop"][s]
+    for name, want in META["misc"]["unscope"]:
+        assert misc.unscope_name(name) == want
+
+
+# ---- long-term feature bank ----------------------------------------------------------------------------------------------------
+def _lfb_case(kind):
+    return [c for c in META["lfb"] if c["kind"] == kind][0]
+
+
+def test_ava_bank_construction_and_windowed_draw(monkeypatch):
+    from oracle import lfb as ol
+    case = _lfb_case("ava")
+    D = case["dim"]
+    rows = Z["lfb_ava_batch_rows"]
+    feats, metas, at = [], [], 0
+    for it in range(rows.shape[0]):
+        fi, mi = [], []
+        for g in range(rows.shape[1]):
+            n = int(rows[it, g])
+            fi.append(Z["lfb_ava_feats"][at:at + n].reshape(n, D, 1, 1, 1))
+            mi.append(Z["lfb_ava_meta"][at:at + n])
+            at += n
+        feats.append(fi)
+        metas.append(mi)
+    bank = ol.construct_ava_lfb(feats, metas)
+    keys, got = [], []
+    for v in sorted(bank):
+        for s in sorted(bank[v]):
+            for f in bank[v][s]:
+                keys.append((v, s))
+                got.append(f)
+    assert np.array_equal(np.array(keys), Z["lfb_ava_bank_keys"])
+    assert np.array_equal(np.array(got, dtype=np.float32), Z["lfb_ava_bank_rows"])
+    # the draw: the reference consumes np.random.choice(range(n), k, replace=False) once per occupied second, in window
+    # order (ava.py:315-319).  With the oracle's counter-based choice swapped for exactly that call, under the same seed,
+    # every other line of sample_lfb must agree: window bounds, row layout j * K + k, zero rows, dtype
+    monkeypatch.setattr(ol, "choice_without_replacement",
+                        lambda n, k, seed, sample_id, video, step: list(np.random.choice(range(n), k, replace=False)))
+    for i, d in enumerate(case["draws"]):
+        np.random.seed(d["np_seed"])
+        out = ol.sample_lfb_ava(bank[d["video"]], d["sec"], case["window"], case["max_per_step"], D, 0, 0, d["video"])
+        want = Z["lfb_ava_sample_%d" % i]
+        assert out.dtype == want.dtype and np.array_equal(out, want), i
+    monkeypatch.undo()
+    # ... and the oracle's own draw has the reference's structure: same rows occupied, each from the right second, distinct
+    for i, d in enumerate(case["draws"]):
+        out = ol.sample_lfb_ava(bank[d["video"]], d["sec"], case["window"], case["max_per_step"], D, 77, i, d["video"])
+        want = Z["lfb_ava_sample_%d" % i]
+        assert np.array_equal(np.any(out != 0, 1), np.any(want != 0, 1))
+        K, lower = case["max_per_step"], d["sec"] - case["window"] // 2
+        for j in range(case["window"]):
+            have = [tuple(r) for r in out[j * K:(j + 1) * K] if np.any(r != 0)]
+            pool = [tuple(np.float64(f)) for f in bank[d["video"]].get(lower + j, [])]
+            assert len(set(have)) == len(have) and all(h in pool for h in have)
+
+
+def test_charades_bank_and_window():
+    from oracle import lfb as ol
+    case = _lfb_case("charades")
+    D, per = case["dim"], case["per_gpu"]
+    frames = ol.charades_lfb_frames(case["num_frames"], case["clips_per_second"])
+    assert np.array_equal(np.array(frames), Z["lfb_ch_frames"])
+    flat = Z["lfb_ch_feats"]
+    feats = [[flat[(2 * b + g) * per:(2 * b + g + 1) * per].reshape(per, D, 1, 1, 1) for g in range(2)]
+             for b in range(len(flat) // (2 * per))]
+    bank = ol.construct_frame_level_lfb(feats, frames)
+    keys = [(v, f) for v in sorted(bank) for f in sorted(bank[v])]
+    assert np.array_equal(np.array(keys), Z["lfb_ch_bank_keys"])
+    assert np.array_equal(np.array([bank[v][f] for v, f in keys], dtype=np.float32), Z["lfb_ch_bank_rows"])
+    for (v, c), want in zip(Z["lfb_ch_queries"], Z["lfb_ch_samples"]):
+        out = ol.sample_lfb_charades(bank[int(v)], int(c), case["window"], case["clips_per_second"], D)
+        assert out.dtype == want.dtype and np.array_equal(out, want), (v, c)
+
+
+def test_epic_verb_and_noun_windows():
+    from oracle import lfb as ol
+    case = _lfb_case("epic_verb")
+    bank = {int(f): r for f, r in zip(Z["lfb_ev_bank_keys"], Z["lfb_ev_bank_rows"])}
+    for c, want in zip(Z["lfb_ev_queries"], Z["lfb_ev_samples"]):
+        out = ol.sample_verb_lfb_epic(int(c), bank, case["window"], case["dim"])
+        assert np.array_equal(out.astype(np.float32), want.astype(np.float32)), c      # (the reference returns float32 here)
+    case = _lfb_case("epic_noun")
+    bank, at = {}, 0
+    for f, n in Z["lfb_en_counts"]:
+        bank[int(f)] = Z["lfb_en_rows"][at:at + n] if n else []
+        at += int(n)
+    for c, want in zip(Z["lfb_en_queries"], Z["lfb_en_samples"]):
+        out = ol.sample_noun_lfb_epic(int(c), bank, case["window"], case["dim"], case["max_per_frame"],
+                                      case["frames_per_second"])
+        assert np.array_equal(out, want), c
+
+
+# ---- preprocessing -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", range(len(META["prep"])))
+def test_clip_and_box_preprocessing(k):
+    """random jitter size, crop offsets, flip decision (in the reference's draw order), test-time scale / forced flip /
+    three-way shift crop, box clipping-scaling-cropping-flipping, /255, mean / std, BGR -> RGB: the reference's code with
+    its cv2.resize replaced by the oracle's restatement, against the oracle end to end"""
+    from oracle import preprocess as op
+    case = META["prep"][k]
+    cfg = _load("ava_r50_lfb_nl", ["TRAIN.JITTER_SCALES", str(case["jitter"]), "TEST.SCALE", case["test_scale"],
+                                   "DATASET", case["dataset"], "AVA.FORCE_TEST_FLIP", case["force_flip"],
+                                   "MODEL.USE_BGR", case["use_bgr"]])
+    frames = list(Z["prep_frames_%dx%d" % tuple(case["frames"])])
+    boxes = Z["prep_%d_boxes_in" % k].copy() if case["boxes"] else None
+    np.random.seed(case["np_seed"])
+    clip, out_boxes = op.images_and_boxes_preprocessing(frames, case["split"], case["crop"], case["shift"], cfg, boxes=boxes,
+                                                        rng=np.random)
+    want = Z["prep_%d_clip" % k]
+    assert clip.shape == want.shape and str(clip.dtype) == case["clip_dtype"]
+    assert np.array_equal(clip, want), float(np.abs(clip.astype(np.float64) - want).max())
+    if case["boxes"]:
+        assert np.array_equal(np.asarray(out_boxes, dtype=np.float64), Z["prep_%d_boxes_out" % k])
+    else:
+        assert out_boxes is None
+
+
+def test_normalisation_constants():
+    """data_input_helper.py:40-41: float32 copies of cfg.DATA_MEAN / cfg.DATA_STD (BGR order)"""
+    cfg = _load("ava_r50_lfb_nl", [])
+    mean, std = META["prep_mean_std"]
+    assert [float(np.float32(v)) for v in cfg.DATA_MEAN] == mean and [float(np.float32(v)) for v in cfg.DATA_STD] == std
+
+
+# ---- checkpoints ---------------------------------------------------------------------------------------------------------------
+def _group(prefix):
+    return {n[len(prefix):]: Z[n] for n in Z.files if n.startswith(prefix)}
+
+
+def _scalar_or_array(v):
+    return v.item() if v.shape == () and v.dtype.kind in "iu" else v
+
+
+def test_classification_checkpoint_conversion(tmp_path):
+    """BN statistics folded into the affine pair, `epoch / model_iter / lr` and every `*_momentum` dropped
+    (checkpoints.py:88-146), in the reference's float32 arithmetic"""
+    from utils import checkpoints as ck
+    src = {n: _scalar_or_array(v) for n, v in _group("ckpt_cls_in/").items()}
+    path = str(tmp_path / "cls.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump({"blobs": src}, fh, protocol=2)
+    got = ck.load_and_convert_caffe2_cls_model(path)["blobs"]
+    want = _group("ckpt_cls_out/")
+    assert sorted(got) == sorted(want)
+    for n in want:
+        g = np.asarray(got[n])
+        assert g.dtype == want[n].dtype and np.array_equal(g, want[n]), n
+
+
+class _Fill(object):
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class _Engine(object):
+    allocated = True
+
+    def __init__(self, init, train):
+        self.train = train
+        self.p = {n: v.copy() for n, v in init.items() if not n.endswith("_momentum")}
+        self.m = {n[:-len("_momentum")]: v.copy() for n, v in init.items() if n.endswith("_momentum")}
+        self.lr = None
+
+    def feed_params(self, d):
+        for n, v in d.items():
+            assert v.dtype == np.float32 and v.shape == self.p[n].shape, n
+            self.p[n] = v.copy()
+
+    def feed_momentum(self, d):
+        for n, v in d.items():
+            assert v.dtype == np.float32 and v.shape == self.m[n].shape, n
+            self.m[n] = v.copy()
+
+    def fetch_param(self, n):
+        return self.p[n]
+
+    def fetch_momentum(self, n):
+        return self.m[n]
+
+    def set_lr(self, lr):
+        self.lr = np.float32(lr)
+
+
+class _Model(object):
+    def __init__(self, ck, train):
+        self.train = train
+        self.params = list(ck["params"])
+        self.computed = list(ck["computed"])
+        self.frozen = set(ck["frozen"])
+        self.param_init_net = type("P", (), {})()
+        self.param_init_net.fills = {n: _Fill(s) for n, s in ck["shapes"].items()}
+
+    def TrainableParams(self, scope=""):
+        return [p for p in self.params if p not in self.frozen]
+
+    def GetParams(self, namescope=None):
+        return list(self.params)
+
+    def GetComputedParams(self, namescope=None):
+        return list(self.computed)
+
+    def GetAllParams(self, namescope=None):
+        return self.params + self.computed
+
+
+@pytest.mark.parametrize("r", range(len(META["ckpt"]["runs"])))
+def test_initialisation_from_a_weights_file(r, tmp_path):
+    """classifier rule (same element count -> reshaped, else left alone), 2-D -> 3-D inflation (repeat over kT, / kT) of
+    weights AND of their momentum, blobs missing from the file keep their values, float64 -> float32, momentum only
+    for the trainable parameters of a training net and only when asked, lr from the file or 1.0 with
+    TRAIN.RESET_START_ITER, wrapped and bare pickles (checkpoints.py:271-383); then the file a training net writes (:421-459)"""
+    from utils import checkpoints as ck
+    from vlfb import dist
+    info = META["ckpt"]
+    run = info["runs"][r]
+    _load("ava_r50_lfb_nl", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 8, "TEST.BATCH_SIZE", 8, "TRAIN.RESET_START_ITER",
+                             run["reset_start_iter"]])
+    blobs = {n: _scalar_or_array(v) for n, v in _group("ckpt_file/").items()}
+    if not run["file_has_lr"]:
+        del blobs["lr"]
+    path = str(tmp_path / "w.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump({"blobs": blobs} if run["wrapped"] else blobs, fh, protocol=2)
+    train = run["net"] == "train"
+    model = _Model(info, train)
+    model.engine = _Engine(_group("ckpt_init/"), train)
+    model_iter, prev_lr = ck.initialize_master_gpu_model_params(model, path, load_momentum=run["load_momentum"])
+    assert (model_iter, prev_lr) == (run["model_iter"], run["prev_lr"])
+    want = _group("ckpt_run%d/gpu_0/" % r)
+    assert bits(model.engine.lr) == bits(want.pop("lr"))
+    for n, w in want.items():
+        got = model.engine.m[n[:-len("_momentum")]] if n.endswith("_momentum") else model.engine.p[n]
+        assert got.dtype == w.dtype and np.array_equal(got, w), n
+    assert set(want) == set(model.engine.p) | {n + "_momentum" for n in model.engine.m}
+    if "saved_keys" in run:
+        out = str(tmp_path / "saved.pkl")
+        ck.save_model_params(model, out, 99)
+        with open(out, "rb") as fh:
+            saved = pickle.load(fh)
+        assert list(saved) == ["blobs"] and sorted(saved["blobs"]) == run["saved_keys"]
+        ref = _group("ckpt_saved/")
+        for n in run["saved_keys"]:
+            assert np.array_equal(np.asarray(saved["blobs"][n]), ref[n]), n
+            assert np.asarray(saved["blobs"][n]).dtype == ref[n].dtype, n
+
+
+# ---- AVA multi-crop merge -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", range(len(META["multicrop"])))
+def test_multi_crop_merge(k):
+    """lib/utils/metrics.py:623-711 run on synthetic score files: which of the three shifted crops see a box (after the
+    flip of its x range), the mean of their sigmoids, then the sum over scales and flips (written with '%f')"""
+    from oracle import multicrop as omc
+    case = META["multicrop"][k]
+    boxes, logits = Z["mc_%d_boxes" % k], Z["mc_%d_logits" % k]
+    total = 0.0
+    for si, scale in enumerate(case["scales"]):
+        for fi, flip in enumerate([False, True]):
+            got = omc.merge_three_shifts(list(logits[si, fi]), boxes, flip, scale, case["height"], case["width"])
+            want = Z["mc_%d_combined" % k][si, fi]
+            # the reference parses the logit back from the csv (written here with repr(): exact) and writes str(float)
+            assert np.array_equal(got, want), (scale, flip, float(np.abs(got - want).max()))
+            total = total + want
+    final = Z["mc_%d_final" % k]
+    assert np.array_equal(np.array([[float("%f" % v) for v in row] for row in total]), final)

@@ -124,14 +124,17 @@ class ModelBuilder(object):
                            dilations=dilations if dilations is not None else [1, 1, 1])
         return self.AffineNd(conv, prefix + suffix, dim_out, inplace=inplace_affine)
 
-    def Conv3dBN(self, blob_in, prefix, dim_in, dim_out, kernels, strides, pads, group=1, bn_init=None,
-                 dilations=None, **kwargs):
+    def Conv3dBN(self, blob_in, prefix, dim_in, dim_out, kernels, strides, pads, group=1, bn_init=None, **kwargs):
         """bias-free MSRA conv followed by SpatialBN (model_builder_video.py:176-197); bn_init != 1 re-fills the scale
-        (the zero-initialised last BN of a bottleneck, resnet_helper.py:70)"""
+        (the zero-initialised last BN of a bottleneck, resnet_helper.py:70).
+        As in the reference, a `dilations=` argument is NOT forwarded to the convolution (it lands in **kwargs, :179):
+        a batch-norm graph with cfg.DILATIONS = 2 gets the pads of the dilated 3x3 (resnet_helper.py:57) on an
+        undilated kernel, res5_0_branch2b grows by 2 pixels per side and the residual Sum no longer fits -- in Caffe2
+        at run time, here when the engine plans the graph.  Batch-norm graphs therefore need
+        MODEL.DILATIONS_AFTER_CONV5 False, here as there (tests/test_ref_graph.py holds this to the reference's class)."""
         conv = self.ConvNd(blob_in, prefix, dim_in, dim_out, kernels, strides=strides, pads=pads,
                            group=group, weight_init=("MSRAFill", {}),
-                           bias_init=("ConstantFill", {"value": 0.0}), no_bias=1,
-                           dilations=dilations if dilations is not None else [1, 1, 1])
+                           bias_init=("ConstantFill", {"value": 0.0}), no_bias=1)
         out = self.SpatialBN(conv, prefix + "_bn", dim_out, epsilon=cfg.MODEL.BN_EPSILON,
                              momentum=cfg.MODEL.BN_MOMENTUM, is_test=self.split in ["test", "val"])
         if bn_init is not None and bn_init != 1.0:

@@ -111,12 +111,13 @@ def remove_spatial_bn_layers(c2cls_weights):
         rm, riv = layer + "_bn_rm", layer + "_bn_riv"
         if rm not in blobs or riv not in blobs:
             continue                       # already an affine pair
-        gamma = np.asarray(blobs[layer + "_bn_s"], dtype=np.float64)
-        beta = np.asarray(blobs[layer + "_bn_b"], dtype=np.float64)
-        inv_std = 1.0 / np.sqrt(np.asarray(blobs.pop(riv), dtype=np.float64) + BN_EPS)
-        mean = np.asarray(blobs.pop(rm), dtype=np.float64)
-        blobs[layer + "_bn_s"] = (gamma * inv_std).astype(np.float32)
-        blobs[layer + "_bn_b"] = (beta - mean * gamma * inv_std).astype(np.float32)
+        # the reference's arithmetic, in the dtype of the file (float32) and in its order of operations, so that a
+        # converted file is the same file bit for bit (tests/test_ref_aux.py)
+        gamma, beta = np.asarray(blobs[layer + "_bn_s"]), np.asarray(blobs[layer + "_bn_b"])
+        std = np.sqrt(np.asarray(blobs.pop(riv)) + BN_EPS)
+        mean = np.asarray(blobs.pop(rm))
+        blobs[layer + "_bn_s"] = gamma / std
+        blobs[layer + "_bn_b"] = beta - mean * gamma / std
     return layers
 
 

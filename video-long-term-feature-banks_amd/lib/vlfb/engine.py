@@ -1260,6 +1260,11 @@ class Lowering(object):
         op, ins, outs = self.ssa[i]
         assert len(op.inputs) == 2, "Sum of two blobs expected"
         a, b = self.get(op.inputs[0]), self.get(op.inputs[1])
+        if tuple(a.shape) != tuple(b.shape):
+            # Caffe2's Sum enforces equal shapes at run time; here the plan refuses (e.g. a batch-norm graph with
+            # cfg.DILATIONS = 2: Conv3dBN drops the dilation but keeps its pads, as in the reference)
+            raise ValueError("Sum(%s, %s): operand shapes differ, %s vs %s" % (op.inputs[0], op.inputs[1],
+                                                                             tuple(a.shape), tuple(b.shape)))
         out_name = op.outputs[0]
         j = i
         relu = False
