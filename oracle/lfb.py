@@ -7,9 +7,12 @@ CPU restatement of the reference's long-term-feature-bank construction and sampl
   * sample_lfb (Charades)        lib/datasets/charades.py:251-276
   * sample_verb_lfb / sample_noun_lfb (EPIC-Kitchens)   lib/datasets/epic.py:310-374
 
-Parity unpinned: the reference holds no fixtures for these functions, and its AVA sampler draws
-with `np.random.choice(..., replace=False)` from the global MT19937 stream, which no device kernel
-can (or should) replay.  What is restated exactly is the *structure* -- which rows of the output
+Pinned to the reference's own functions, executed on synthetic banks (oracle/make_ref_aux_golden.py ->
+tests/golden/ref_aux.npz, tests/test_ref_aux.py): construction, the Charades / EPIC windows and -- with
+the draw below swapped for the reference's `np.random.choice` under the same seed -- the AVA sampler, all
+bit for bit.  Not replayed: the draw itself.  The reference takes `np.random.choice(..., replace=False)`
+from the global MT19937 stream, which no device kernel can (or should) follow.  What is restated exactly
+is the *structure* -- which rows of the output
 belong to which time step, how many features a step contributes, distinctness, zero padding, the
 Charades window arithmetic -- and the draw itself is replaced by the counter-based key
 `choice_key` shared bit for bit with csrc/vlfb_lfb.hip: the chosen features of a step are the

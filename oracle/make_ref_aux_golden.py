@@ -12,6 +12,7 @@ Sections (each is the reference's code, imported from where it lies and called w
           charades.py:238-276, epic.py:310-374 sample_lfb / get_lfb_frames / sample_verb_lfb / sample_noun_lfb
   prep    lib/datasets/data_input_helper.py:70-139 images_and_boxes_preprocessing with everything it calls in
           lib/datasets/image_processor.py (jitter, crops, flips, box transforms, normalisation, channel order)
+  solver  lib/models/model_builder_video.py:348-389 add_parameter_update_ops (weight-decay class, momentum, nesterov)
   mc      lib/utils/metrics.py:619-711 merge_ava_3shift_score_files / merge_ava_score_files (the AVA multi-crop merge)
   ckpt    lib/utils/checkpoints.py:88-146 (BN fold, field / momentum removal), :271-383 initialize_master_gpu_model_params
           (classifier rule, 2-D -> 3-D inflation, momentum policy, lr blob) and :421-459 save_model_params
@@ -524,6 +525,58 @@ def section_multicrop(config, reset, meta, arrays):
         os.chdir(old)
 
 
+SOLVER_CASES = [("ava_r50_lfb_nl", []),
+                ("charades_r50_baseline", ["MODEL.USE_AFFINE", False, "NONLOCAL.USE_BN", True, "NONLOCAL.USE_AFFINE", False,
+                                           "MODEL.DILATIONS_AFTER_CONV5", False, "SOLVER.WEIGHT_DECAY_BN", 0.00003,
+                                           "SOLVER.NESTEROV", False, "SOLVER.MOMENTUM", 0.8]),
+                ("charades_r50_lfb_nl", [])]
+
+
+def section_solver(config, mb, reset, meta):
+    """model_builder_video.py:348-389 add_parameter_update_ops: the operators the reference appends per trainable
+    parameter (which weight-decay blob its WeightedSum reads, MomentumSGDUpdate's momentum / nesterov, the zero-filled
+    momentum blob, the lr / weight_decay / weight_decay_bn / ONE fills).  The parameter names are THIS repo's
+    catalogue for the configuration (dumped by a subprocess that imports this repo's builder: the two trees cannot
+    share one interpreter, both are `models`, `core`, `utils`)."""
+    import subprocess
+    from oracle.graph_recorder import RecordingModel
+    lib = os.path.join(HERE, "..", "video-long-term-feature-banks_amd", "lib")
+    code = (
+        "import json, sys\n"
+        "from vlfb.presets import load_preset\n"
+        "from models.model_builder_video import ModelBuilder\n"
+        "out = []\n"
+        "for name, ov in json.loads(sys.argv[1]):\n"
+        "    load_preset(name, ['NUM_GPUS', 1, 'TRAIN.BATCH_SIZE', 2] + ov)\n"
+        "    m = ModelBuilder(train=True, split='train', name='t'); m.build_model(suffix='_train')\n"
+        "    out.append({'params': m.GetParams(), 'trainable': m.TrainableParams()})\n"
+        "print(json.dumps(out))\n")
+    env = dict(os.environ, PYTHONPATH=lib)
+    dumped = json.loads(subprocess.check_output([sys.executable, "-c", code, json.dumps(SOLVER_CASES)], env=env).decode()
+                        .strip().splitlines()[-1])
+    out = []
+    for (name, overrides), d in zip(SOLVER_CASES, dumped):
+        reset()
+        config.cfg_from_file(os.path.join(REF, "configs", name + ".yaml"))
+        if overrides:
+            config.cfg_from_list([str(o) for o in overrides])
+        config.assert_and_infer_cfg()
+        model = RecordingModel(split="train", train=True, inplace_relu=True)
+        model.current_lr = 0.0375
+        model.param_to_grad = {p: p + "_grad" for p in d["trainable"]}
+        model.GetParams = lambda d=d: list(d["params"])
+        model.TrainableParams = lambda scope="", d=d: list(d["trainable"])
+        mb.add_parameter_update_ops(model)(model)
+        sol = config.config.SOLVER
+        out.append({"config": name, "overrides": overrides, "params": d["params"], "trainable": d["trainable"],
+                    "current_lr": model.current_lr, "calls": model.transcript(),
+                    "solver": {"WEIGHT_DECAY": sol.WEIGHT_DECAY, "WEIGHT_DECAY_BN": sol.WEIGHT_DECAY_BN,
+                               "MOMENTUM": sol.MOMENTUM, "NESTEROV": sol.NESTEROV}})
+        print("solver %-24s %3d parameters, %3d trainable, %d calls" % (name, len(d["params"]), len(d["trainable"]),
+                                                                        len(model.calls)))
+    meta["solver"] = out
+
+
 def main():
     config, mb = install_stubs()
     import copy
@@ -551,6 +604,7 @@ def main():
     section_prep(config, reset, meta, arrays)
     section_ckpt(config, reset, meta, arrays)
     section_multicrop(config, reset, meta, arrays)
+    section_solver(config, mb, reset, meta)
     arrays["meta"] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8)
     buf = io.BytesIO()
     np.savez_compressed(buf, **arrays)

@@ -1,8 +1,9 @@
 """ORACLE (test infrastructure only): the AVA multi-crop merge of the reference, restated on arrays.
   merge_ava_3shift_score_files   lib/utils/metrics.py:623-686   (per box: which crops overlap it; mean of sigmoids)
   merge_ava_score_files          lib/utils/metrics.py:689-711   (sum over scales and flips)
-and the per-pass loop of tools/test_net.py:48-93 over oracle.preprocess + oracle.model.  Parity unpinned (the
-reference has no fixtures for it); loops are written per box exactly like the csv code, not vectorised."""
+and the per-pass loop of tools/test_net.py:48-93 over oracle.preprocess + oracle.model.  Pinned: the two merge functions of the
+reference are run on synthetic score files by oracle/make_ref_aux_golden.py and merge_three_shifts must reproduce their
+output exactly (tests/test_ref_aux.py); loops are written per box exactly like the csv code, not vectorised."""
 import numpy as np
 
 

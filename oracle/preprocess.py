@@ -11,8 +11,10 @@ version (INSTALL.md: "pip install opencv-python", early 2019 => 3.4.x / 4.0.x). 
 published algorithm of modules/imgproc/src/resize.cpp for 8-bit INTER_LINEAR: per-axis source index
 sx = floor((dx + 0.5) * scale - 0.5) with border clamps, weights quantised to 11 bits
 (INTER_RESIZE_COEF_BITS) with cvRound + saturate_cast<short>, horizontal pass in int, vertical pass
-((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  Parity unpinned: no cv2 to run, no
-fixtures in the reference.  TRAIN.USE_COLOR_AUGMENTATION (off in every shipped config) is not restated.
+((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  The resize is parity-unpinned (no cv2 to run, no
+fixtures in the reference); everything around it is pinned: oracle/make_ref_aux_golden.py runs the reference's own
+images_and_boxes_preprocessing with `cv2.resize` replaced by resize_u8 below, and tests/test_ref_aux.py requires this
+module to reproduce its clips and boxes bit for bit under the same np.random seed (27 cases).  TRAIN.USE_COLOR_AUGMENTATION (off in every shipped config) is not restated.
 """
 import math
 

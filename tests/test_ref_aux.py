@@ -351,3 +351,51 @@ def test_multi_crop_merge(k):
             total = total + want
     final = Z["mc_%d_final" % k]
     assert np.array_equal(np.array([[float("%f" % v) for v in row] for row in total]), final)
+
+
+# ---- solver structure -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", range(len(META["solver"])), ids=lambda k: META["solver"][k]["config"])
+def test_parameter_update_rules(k):
+    """model_builder_video.py:348-389 run on this repo's parameter catalogue: one WeightedSum (gradient += decay * param,
+    decay class by '_bn' in the name) and one MomentumSGDUpdate (SOLVER.MOMENTUM / NESTEROV, zero-filled `<param>_momentum`)
+    per TRAINABLE parameter and nothing for the others -- against the engine's decay ranges, trainable set and the
+    constants its fused solver launch reads"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_lowering import plan
+    case = META["solver"][k]
+    small = ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64]
+    cfg, m, eng = plan(case["config"], small + case["overrides"])
+    assert m.GetParams() == case["params"] and m.TrainableParams() == case["trainable"]
+    sol = case["solver"]
+    assert (cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.WEIGHT_DECAY_BN, cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV) == \
+        (sol["WEIGHT_DECAY"], sol["WEIGHT_DECAY_BN"], sol["MOMENTUM"], sol["NESTEROV"])
+    fills = {c[1][1]: c for c in case["calls"] if c[0] == "param_init_net.ConstantFill"}
+    assert fills["lr"][2] == {"shape": [1], "value": case["current_lr"]}
+    decay = {"weight_decay": fills["weight_decay"][2]["value"], "weight_decay_bn": fills["weight_decay_bn"][2]["value"]}
+    assert decay == {"weight_decay": sol["WEIGHT_DECAY"], "weight_decay_bn": sol["WEIGHT_DECAY_BN"]}
+    assert fills["ONE"][2]["value"] == 1.0
+    want_wd, updated = {}, []
+    for name, args, kw in case["calls"]:
+        if name == "WeightedSum":
+            (grad, one, param, wd), out = args
+            assert one == "ONE" and grad == param + "_grad" and out == grad
+            want_wd[param] = decay[wd]
+        elif name == "net.MomentumSGDUpdate":
+            ins, outs = args
+            grad, mom, lr, param = ins
+            assert outs == [grad, mom, param] and lr == "lr" and mom == param + "_momentum"
+            assert kw == {"momentum": sol["MOMENTUM"], "nesterov": sol["NESTEROV"]}
+            assert fills[mom][1][0] == [param] and fills[mom][2] == {"value": 0.0}
+            updated.append(param)
+    assert updated == case["trainable"] and sorted(want_wd) == sorted(updated)
+    # the engine: the same parameters are the solver's, each under the same decay
+    assert sorted(eng.train_layout) == sorted(updated)
+    got_wd = {}
+    for n, (off, cnt, shape) in eng.train_layout.items():
+        r = [w for lo, hi, w in eng.wd_ranges if lo <= off and off + cnt <= hi]
+        assert len(r) == 1, n
+        got_wd[n] = r[0]
+    assert got_wd == want_wd
+    if "NONLOCAL.USE_BN" in case["overrides"]:
+        assert len(set(want_wd.values())) == 2          # (the batch-norm case exercises both classes)
