@@ -228,7 +228,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the job has %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus %d` "
                          "(self-launching) or through torch.distributed.run with --nproc-per-node %d"
                          % (args.gpus, world, args.gpus, args.gpus))
-    device = "cuda:%d" % dist.local_rank()
+    # (VLFB_BENCH_ONE_DEVICE=1, with VLFB_DIST_BACKEND=gloo: every rank on cuda:0 -- how a one-GPU box drives the N > 1
+    #  code of this file, tests/test_bench_launch_gpu.py; never a measurement)
+    one_device = os.environ.get("VLFB_BENCH_ONE_DEVICE", "0") == "1"
+    device = "cuda:0" if one_device else "cuda:%d" % dist.local_rank()
     torch.cuda.set_device(device)
 
     from vlfb import hip, synth

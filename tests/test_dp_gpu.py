@@ -165,7 +165,16 @@ def _ava_rank_inputs(cfg, rank):
     return om.synth_inputs(cfg, 1, "train", seed=20 + rank, rois_per_clip=ROIS[rank], crop=64, frames=16)
 
 
-def _ava_worker(rank, world, port, q):
+def _ava_worker(rank, world, port, q, dtype="fp32"):
+    try:
+        _ava_worker_body(rank, world, port, q, dtype)
+    except BaseException:                 # the parent must hear about it at once, not after its queue time-out
+        import traceback
+        q.put((rank, {"_error": traceback.format_exc()}))
+        raise
+
+
+def _ava_worker_body(rank, world, port, q, dtype):
     import collections
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -182,7 +191,7 @@ def _ava_worker(rank, world, port, q):
     params = om.synth_params(cfg, seed=2)
     model = ModelBuilder(train=True, split="train", name="dp")
     model.build_model(suffix="_train")
-    eng = Engine(model, "fp32", device="cuda:0", base_seed=2)
+    eng = Engine(model, dtype, device="cuda:0", base_seed=2)
     assert eng.replica == rank
     eng.plan(collections.OrderedDict((k + "_train", v.shape) for k, v in inputs.items()))
     eng.feed_params(params)
@@ -197,28 +206,42 @@ def _ava_worker(rank, world, port, q):
     out = {n: eng.fetch_grad(n) for n in CHECK}
     out["_mask_row0"] = drop.mask.view(-1)[:drop.ch * drop.inner].cpu().numpy().copy()
     out["_loss"] = float(eng.fetch("loss").reshape(-1)[0])
+    out["_loss_scale"] = float(eng.loss_scale)
     q.put((rank, out))
     dist.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_ranks_with_different_roi_counts_sum_their_per_gpu_normalised_losses():
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "mix"])
+def test_ranks_with_different_roi_counts_sum_their_per_gpu_normalised_losses(dtype):
     """Each GPU normalises its loss by ITS OWN number of valid targets and scales by 1/NUM_GPUS
     (resnet_video.py:333-338), so with 1 RoI on rank 0 and 4 on rank 1 the all-reduced gradient is the SUM
     of the two per-rank oracle gradients -- not the gradient of one 5-RoI batch.  Also: the replicas draw
-    different dropout masks (one RNG per GPU in the reference)."""
+    different dropout masks (one RNG per GPU in the reference).
+    fp16 / mix: the summed gradients carry the fp16 loss scale, so every rank has to choose the SAME scale although it
+    holds a different number of RoI rows (it used to be sized from the rows: 2^13 on the 1-RoI rank, 2^15 on the 4-RoI one,
+    and the ranks' weights drifted apart)."""
     import torch.multiprocessing as mp
     _setup_paths()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ava_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ava_worker, args=(r, 2, port, q, dtype)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=900) for _ in range(2))
+    results = {}
+    for _ in range(2):
+        rank, res = q.get(timeout=300)
+        if "_error" in res:
+            for p in procs:
+                p.kill()
+            pytest.fail("rank %d: %s" % (rank, res["_error"]))
+        results[rank] = res
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    assert results[0]["_loss_scale"] == results[1]["_loss_scale"]
+    assert (results[0]["_loss_scale"] == 1.0) == (dtype == "fp32")
     from vlfb.presets import load_preset
     from core.config import config as cfg
     from vlfb import rng as vrng
@@ -233,10 +256,12 @@ def test_ranks_with_different_roi_counts_sum_their_per_gpu_normalised_losses():
         total = {n: g.clone() for n, g in grads.items()} if total is None else {n: total[n] + grads[n] for n in total}
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     for rank in range(2):
-        assert abs(results[rank]["_loss"] - losses[rank]) < 1e-4 * abs(losses[rank]), (rank, results[rank]["_loss"], losses[rank])
+        assert abs(results[rank]["_loss"] - losses[rank]) < {"fp32": 1e-4, "mix": 1e-4, "fp16": 2e-3}[dtype] * abs(losses[rank]), \
+            (rank, results[rank]["_loss"], losses[rank])
+    tol = {"fp32": 5e-3, "mix": 1e-2, "fp16": 1e-1}[dtype]     # (the bars of test_model_gpu for each path at this size)
     for n in CHECK:
         assert np.array_equal(results[0][n], results[1][n]), "ranks disagree after all-reduce: " + n
-        assert rel(results[0][n], total[n].numpy()) < 5e-3, (n, rel(results[0][n], total[n].numpy()))   # fp32 path bar (test_model_gpu)
+        assert rel(results[0][n], total[n].numpy()) < tol, (n, rel(results[0][n], total[n].numpy()))
     assert not np.array_equal(results[0]["_mask_row0"], results[1]["_mask_row0"]), "replicas share a dropout mask"
 
 

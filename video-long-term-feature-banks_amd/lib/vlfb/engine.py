@@ -1090,7 +1090,13 @@ class LossStep(Step):
             # fp16: |dlogits| <= scale / normaliser (normaliser = #targets for the sigmoid loss, #rows for the
             # softmax loss); pick the power of two that puts that bound at 2^6, so that the gradients of a
             # production step (1/8 loss scale, ~1900 targets) and of a 2-clip test sit in the same fp16 range
-            norm = self.rows * self.cols if self.kernel == "vlfb_sigmoid_ce" else self.rows
+            # DATA PARALLEL: gradients scaled by this factor are SUMMED across ranks, so every rank must choose the same
+            # one.  The number of RoI rows differs from rank to rank and from step to step (lib/datasets/ava.py); the
+            # number of clips per GPU does not (misc.py:68-72).  A RoI head therefore sizes the bound for its nominal
+            # 3 RoIs per clip instead of the rows it happens to hold (a rank with fewer rows sits at most 2^1.6 higher).
+            clips = self.eng.plan_clips
+            rows = 3 * clips if (self.eng.plan_roi_rows and clips is not None) else self.rows
+            norm = rows * self.cols if self.kernel == "vlfb_sigmoid_ce" else rows
             self.eng.loss_scale = float(2.0 ** round(math.log2(64.0 * norm / self.scale)))
         if self.loss is not None:
             self.dlogits = torch.empty(self.rows * self.cols, device=self.eng.device, dtype=torch.float32)
@@ -1632,6 +1638,7 @@ class Engine(object):
         # (exact) and every parameter gradient carries that factor until the solver divides it out again
         # (lr / S, weight decay * S: lr/S * (S g + S wd p) = lr * (g + wd p)).  1 on the other paths.
         self.auto_loss_scale = loss_scale is None and self.btdtype == torch.float16   # set by LossStep.setup from the shapes
+        self.plan_clips, self.plan_roi_rows = None, False
         self.loss_scale = float(loss_scale if loss_scale is not None else 1.0)
         self.device = torch.device("meta") if self.dry_run else torch.device(device or ("cuda:%d" % dist.local_rank()))
         self.train = bool(model.train and not model.force_fw_only and model.loss_blob is not None)
@@ -1860,6 +1867,9 @@ class Engine(object):
             torch.cuda.set_device(self.device)
         self._trace = self._graph = None       # a recorded / captured step belongs to the buffers of ONE plan
         self._eager_steps = 0
+        data = [tuple(v) for k, v in input_shapes.items() if str(k).startswith("data")]
+        self.plan_clips = int(data[0][0]) if data else None     # clips per GPU of this plan (rank-independent)
+        self.plan_roi_rows = any(str(k).startswith("proposals") for k in input_shapes)   # head rows are RoIs, not clips
         low = Lowering(self, self.model, OrderedDict(input_shapes))
         self.steps = low.run()
         self.env = low.env
@@ -2527,6 +2537,12 @@ class Engine(object):
         if dist.world_size() != int(cfg.NUM_GPUS):
             raise hip.VlfbError("data parallel: %d ranks but cfg.NUM_GPUS = %d (loss scale and per-GPU batch come "
                                 "from NUM_GPUS)" % (dist.world_size(), int(cfg.NUM_GPUS)))
+        # the summed gradients carry the loss scale: it has to be the same number everywhere
+        ls = torch.tensor([self.loss_scale, -self.loss_scale], device=self.device, dtype=torch.float64)
+        td.all_reduce(ls, op=td.ReduceOp.MAX)
+        if float(ls[0]) != self.loss_scale or float(ls[1]) != -self.loss_scale:
+            raise hip.VlfbError("data parallel: the ranks chose different loss scales (%g here, %g .. %g in the job)"
+                                % (self.loss_scale, -float(ls[1]), float(ls[0])))
         td.broadcast(self.flat_param, 0)
         td.broadcast(self.flat_frozen, 0)
         self.refresh_operands(all_params=True)
