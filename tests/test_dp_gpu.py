@@ -52,7 +52,31 @@ def _run_replica(world, rank, clips_per_rank, all_inputs, params, seed_iter=0):
     return eng
 
 
+def _collect(q, procs, n, timeout=300):
+    out = []
+    for _ in range(n):
+        item = q.get(timeout=timeout)
+        if isinstance(item, tuple) and isinstance(item[1], dict) and "_error" in item[1]:
+            for p in procs:
+                p.kill()
+            pytest.fail("worker failed:\n" + item[1]["_error"])
+        out.append(item)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return out
+
+
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException:
+        import traceback
+        q.put((-1, {"_error": traceback.format_exc()}))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), VLFB_FORCE_DEVICE="0", VLFB_DIST_BACKEND="gloo")
@@ -84,10 +108,7 @@ def test_two_replicas_match_one_process_with_both_clips():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=600) for _ in range(2))
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    results = dict(_collect(q, procs, 2))
     # single process, both clips, NUM_GPUS = 1
     from vlfb.presets import load_preset
     from core.config import config as cfg
@@ -104,6 +125,15 @@ def test_two_replicas_match_one_process_with_both_clips():
 
 
 def _nccl_worker(port, q, handoff):
+    try:
+        _nccl_worker_body(port, q, handoff)
+    except BaseException:
+        import traceback
+        q.put((-1, {"_error": traceback.format_exc()}))
+        raise
+
+
+def _nccl_worker_body(port, q, handoff):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       VLFB_DIST_FORCE="1", VLFB_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -139,9 +169,7 @@ def test_rccl_bucketed_allreduce_one_rank(handoff):
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(port, q, handoff))
     p.start()
-    got = q.get(timeout=600)
-    p.join(120)
-    assert p.exitcode == 0
+    got = _collect(q, [p], 1)[0]
     from vlfb.presets import load_preset
     from core.config import config as cfg
     from oracle import model as om
@@ -229,17 +257,7 @@ def test_ranks_with_different_roi_counts_sum_their_per_gpu_normalised_losses(dty
     procs = [ctx.Process(target=_ava_worker, args=(r, 2, port, q, dtype)) for r in range(2)]
     for p in procs:
         p.start()
-    results = {}
-    for _ in range(2):
-        rank, res = q.get(timeout=300)
-        if "_error" in res:
-            for p in procs:
-                p.kill()
-            pytest.fail("rank %d: %s" % (rank, res["_error"]))
-        results[rank] = res
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    results = dict(_collect(q, procs, 2))
     assert results[0]["_loss_scale"] == results[1]["_loss_scale"]
     assert (results[0]["_loss_scale"] == 1.0) == (dtype == "fp32")
     from vlfb.presets import load_preset
