@@ -47,14 +47,12 @@ def test_builder_emits_the_reference_graph(g):
     from core.config import config as cfg
     from models import resnet_video
     from oracle.graph_recorder import RecordingModel
-    # the reference's effective configuration for this graph, through this repo's strict merge (unknown key / changed
-    # type = error): core.config here must know every key the reference has
-    C.reset_cfg()
-    tree = json.loads(json.dumps(g["cfg"]))
-    derived = tree["LFB"].pop("NUM_LFB_FEAT")           # (added by assert_and_infer_cfg, config.py:391)
-    C.merge_dicts(tree, C.config)
-    C.assert_and_infer_cfg()
-    assert cfg.LFB.NUM_LFB_FEAT == derived
+    from vlfb.presets import load_preset
+    # this repo's preset of the same name + the same overrides == the reference's effective configuration for this graph
+    # (its YAML through its own cfg_from_file / cfg_from_list / assert_and_infer_cfg), on every key incl. the derived ones
+    load_preset(g["config"], g["overrides"])
+    mine, want = _flat(json.loads(json.dumps(cfg))), _flat(g["cfg"])
+    assert sorted(mine) == sorted(want) and not {k: (want[k], mine[k]) for k in want if want[k] != mine[k]}
     model = RecordingModel(split=g["split"], train=(g["split"] == "train"), inplace_relu=cfg.MODEL.ALLOW_INPLACE_RELU)
     suffix = "_{}".format(g["split"])
     resnet_video.create_model(model=model, data="data" + suffix, labels="labels" + suffix, split=g["split"],

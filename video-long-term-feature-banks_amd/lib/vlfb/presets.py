@@ -1,4 +1,5 @@
-"""The experiment definitions BASELINE.json names, as override trees over core.config defaults.
+"""The reference's 26 experiment definitions (configs/*.yaml, incl. the ones BASELINE.json names), as override trees over
+core.config defaults.
 
 The reference's configs/*.yaml load unmodified through core.config.cfg_from_file; these presets
 exist because /root/reference (and its configs/) is not present on the GPU box.  Only keys that
@@ -66,47 +67,61 @@ _EPIC_NOUN = {
     "EPIC": {"CLASS_TYPE": "noun", "MAX_NUM_FEATS_PER_NOUN_LFB_FRAME": 10, "NOUN_LFB_FRAMES_PER_SECOND": 1},
 }
 
+_R101 = {"MODEL": {"DEPTH": 101, "VIDEO_ARC_CHOICE": 4}}
+_R101_K400 = {"TRAIN": {"PARAMS_FILE": "pretrained_weights/r101_k400_pretrained.pkl"}}
+_CHARADES_BASE = {
+    "TRAIN": {"PARAMS_FILE": "pretrained_weights/r50_k400_pretrained.pkl"},
+    "SOLVER": {"STEP_SIZES": [20000, 4000], "LRS": [1, 0.1], "MAX_ITER": 24000},
+    "CHECKPOINT": {"CONVERT_MODEL": True},
+}
+# Charades LFB models train the head on a frozen, already fine-tuned backbone (PARAMS_FILE is given on the command line)
+_CHARADES_LFB = {
+    "MODEL": {"FREEZE_BACKBONE": True},
+    "TRAIN": {"PARAMS_FILE": ""},
+    "SOLVER": {"STEP_SIZES": [10000, 2000], "LRS": [1, 0.1], "MAX_ITER": 12000},
+    "FBO_NL": {"PRE_ACT": False},
+}
+_CHARADES_R101 = {"MODEL": {"DILATIONS_AFTER_CONV5": False}}     # (the R101 Charades configs keep res5 undilated)
+
+
+def _lfb(fbo, window, **kw):
+    """LFB.ENABLED with feature-bank operator `fbo` over `window` bank steps; banks are written by the run unless loaded"""
+    d = {"ENABLED": True, "FBO_TYPE": fbo, "WINDOW_SIZE": window}
+    d.update(kw or {"WRITE_LFB": True})
+    return {"LFB": d}
+
+
+_EPIC_NOUN_BANK = {"LOAD_LFB": True, "LOAD_LFB_PATH": "data/epic/noun_lfb"}
+
+# one entry per configs/*.yaml of the reference (26), same names
 PRESETS = {
-    "charades_r50_baseline": [_COMMON, _CHARADES, {
-        "TRAIN": {"PARAMS_FILE": "pretrained_weights/r50_k400_pretrained.pkl"},
-        "SOLVER": {"STEP_SIZES": [20000, 4000], "LRS": [1, 0.1], "MAX_ITER": 24000},
-        "CHECKPOINT": {"CONVERT_MODEL": True},
-    }],
-    "charades_r50_lfb_nl": [_COMMON, _CHARADES, {
-        "MODEL": {"FREEZE_BACKBONE": True},
-        "TRAIN": {"PARAMS_FILE": ""},
-        "SOLVER": {"STEP_SIZES": [10000, 2000], "LRS": [1, 0.1], "MAX_ITER": 12000},
-        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 20},
-        "FBO_NL": {"PRE_ACT": False},
-    }],
-    "ava_r50_baseline": [_COMMON, _AVA, {}],
-    "ava_r50_lfb_nl": [_COMMON, _AVA, {
-        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 60},
-    }],
-    "charades_r50_lfb_avg": [_COMMON, _CHARADES, {
-        "MODEL": {"FREEZE_BACKBONE": True},
-        "TRAIN": {"PARAMS_FILE": ""},
-        "SOLVER": {"STEP_SIZES": [10000, 2000], "LRS": [1, 0.1], "MAX_ITER": 12000},
-        "LFB": {"ENABLED": True, "FBO_TYPE": "avg", "WRITE_LFB": True, "WINDOW_SIZE": 20},
-        "FBO_NL": {"PRE_ACT": False},
-    }],
-    "ava_r50_lfb_max": [_COMMON, _AVA, {
-        "LFB": {"ENABLED": True, "FBO_TYPE": "max", "WRITE_LFB": True, "WINDOW_SIZE": 60},
-    }],
+    "ava_r50_baseline": [_COMMON, _AVA],
+    "ava_r50_lfb_nl": [_COMMON, _AVA, _lfb("nl", 60)],
+    "ava_r50_lfb_nl_3l": [_COMMON, _AVA, _lfb("nl", 60), {"FBO_NL": {"NUM_LAYERS": 3}}],
+    "ava_r50_lfb_avg": [_COMMON, _AVA, _lfb("avg", 60)],
+    "ava_r50_lfb_max": [_COMMON, _AVA, _lfb("max", 60)],
+    "ava_r101_baseline": [_COMMON, _AVA, _R101, _R101_K400],
+    "ava_r101_lfb_nl": [_COMMON, _AVA, _R101, _R101_K400, _lfb("nl", 60)],
+    "ava_r101_lfb_nl_3l": [_COMMON, _AVA, _R101, _R101_K400, _lfb("nl", 60), {"FBO_NL": {"NUM_LAYERS": 3}}],
+    "ava_r101_lfb_avg": [_COMMON, _AVA, _R101, _R101_K400, _lfb("avg", 60)],
+    "ava_r101_lfb_max": [_COMMON, _AVA, _R101, _R101_K400, _lfb("max", 60)],
+    "charades_r50_baseline": [_COMMON, _CHARADES, _CHARADES_BASE],
+    "charades_r50_lfb_nl": [_COMMON, _CHARADES, _CHARADES_LFB, _lfb("nl", 20)],
+    "charades_r50_lfb_avg": [_COMMON, _CHARADES, _CHARADES_LFB, _lfb("avg", 20)],
+    "charades_r50_lfb_max": [_COMMON, _CHARADES, _CHARADES_LFB, _lfb("max", 20)],
+    "charades_r101_baseline": [_COMMON, _CHARADES, _CHARADES_BASE, _R101, _R101_K400, _CHARADES_R101],
+    "charades_r101_lfb_nl": [_COMMON, _CHARADES, _CHARADES_LFB, _R101, _CHARADES_R101, _lfb("nl", 20)],
+    "charades_r101_lfb_avg": [_COMMON, _CHARADES, _CHARADES_LFB, _R101, _CHARADES_R101, _lfb("avg", 20)],
+    "charades_r101_lfb_max": [_COMMON, _CHARADES, _CHARADES_LFB, _R101, _CHARADES_R101, _lfb("max", 20)],
     # EPIC-Kitchens: single-label heads (Softmax / SoftmaxWithLoss), clip-level pooling, no res5 dilation
-    "epic_verb_r50_baseline": [_COMMON, _EPIC, _EPIC_VERB, {}],
-    "epic_verb_r50_lfb_nl": [_COMMON, _EPIC, _EPIC_VERB, {
-        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 40},
-    }],
-    "epic_noun_r50_lfb_nl": [_COMMON, _EPIC, _EPIC_NOUN, {
-        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "LOAD_LFB": True, "LOAD_LFB_PATH": "data/epic/noun_lfb", "WINDOW_SIZE": 120},
-    }],
-    "ava_r101_lfb_nl_3l": [_COMMON, _AVA, {
-        "MODEL": {"DEPTH": 101, "VIDEO_ARC_CHOICE": 4},
-        "TRAIN": {"PARAMS_FILE": "pretrained_weights/r101_k400_pretrained.pkl"},
-        "LFB": {"ENABLED": True, "FBO_TYPE": "nl", "WRITE_LFB": True, "WINDOW_SIZE": 60},
-        "FBO_NL": {"NUM_LAYERS": 3},
-    }],
+    "epic_verb_r50_baseline": [_COMMON, _EPIC, _EPIC_VERB],
+    "epic_verb_r50_lfb_nl": [_COMMON, _EPIC, _EPIC_VERB, _lfb("nl", 40)],
+    "epic_verb_r50_lfb_avg": [_COMMON, _EPIC, _EPIC_VERB, _lfb("avg", 40)],
+    "epic_verb_r50_lfb_max": [_COMMON, _EPIC, _EPIC_VERB, _lfb("max", 40)],
+    "epic_noun_r50_baseline": [_COMMON, _EPIC, _EPIC_NOUN],
+    "epic_noun_r50_lfb_nl": [_COMMON, _EPIC, _EPIC_NOUN, _lfb("nl", 120, **_EPIC_NOUN_BANK)],
+    "epic_noun_r50_lfb_avg": [_COMMON, _EPIC, _EPIC_NOUN, _lfb("avg", 120, **_EPIC_NOUN_BANK)],
+    "epic_noun_r50_lfb_max": [_COMMON, _EPIC, _EPIC_NOUN, _lfb("max", 120, **_EPIC_NOUN_BANK)],
 }
 
 
