@@ -25,7 +25,8 @@ def plan(preset, overrides=("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2), rois=5, split
         if "lfb" + sfx in m.input_blob_names:
             sh["lfb" + sfx] = (rois, cfg.LFB.WINDOW_SIZE * cfg.AVA.LFB_MAX_NUM_FEAT_PER_STEP, 2048)
     else:
-        sh["labels" + sfx] = (n, cfg.MODEL.NUM_CLASSES)
+        # multi-hot rows (Charades) or one class index per clip (EPIC-Kitchens, resnet_video.py:339-350)
+        sh["labels" + sfx] = (n, cfg.MODEL.NUM_CLASSES) if cfg.MODEL.MULTI_LABEL else (n,)
         if "lfb" + sfx in m.input_blob_names:
             sh["lfb" + sfx] = (n, cfg.LFB.WINDOW_SIZE, 2048)
     eng = Engine(m, dtype, dry_run=True)
@@ -151,6 +152,32 @@ def test_spatial_bn_graph_lowers_to_bn_steps():
     assert m.param_init_net.fills["nonlocal_conv3_1_bn_s"].kwargs["value"] == cfg.NONLOCAL.BN_INIT_GAMMA
     cfg, m, eng = plan("ava_r50_lfb_nl", ov, split="test")
     assert all(st.is_test for st in eng.steps if type(st).__name__ == "BNStep")
+
+
+def test_every_shipped_config_plans_in_train_and_test_mode():
+    """all 26 presets (= the reference's configs/*.yaml, tests/test_ref_graph.py), train and test graph: the lowering
+    knows every operator sequence they emit, the backbone fuses to one launch per convolution (R50: 73 + head convs,
+    R101: 124 + head convs), FBO-NL heads get one attention step per layer, avg / max heads one extra pool + a concat"""
+    from vlfb.presets import PRESETS
+    small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TEST.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TEST.VIDEO_LENGTH", 8,
+             "TRAIN.CROP_SIZE", 64, "TEST.CROP_SIZE", 64)
+    assert len(PRESETS) == 26
+    for name in sorted(PRESETS):
+        for split in ("train", "test"):
+            cfg, m, eng = plan(name, small, split=split)
+            k = kinds(eng)
+            backbone = 73 if cfg.MODEL.DEPTH == 50 else 124
+            layers = cfg.FBO_NL.NUM_LAYERS if (cfg.LFB.ENABLED and cfg.LFB.FBO_TYPE == "nl") else 0
+            head_convs = (2 + 4 * layers) if layers else 0          # input reduction + lfb 1x1, theta / phi / g / out per layer
+            assert k["ConvStep"] == backbone + head_convs, (name, split, dict(k))
+            assert k["AttentionStep"] == 5 + layers, (name, split)
+            assert k.get("ConcatStep", 0) == int(bool(cfg.LFB.ENABLED)), (name, split)
+            assert k["PoolStep"] == 8 + int(cfg.LFB.ENABLED and cfg.LFB.FBO_TYPE in ("avg", "max")), (name, split)
+            assert k.get("RoiAlignMaxStep", 0) == int(cfg.DATASET == "ava") and k["LossStep"] == 1
+            assert (k.get("DropoutStep", 0) > 0) == (split == "train")
+            if split == "train":
+                frozen = bool(cfg.MODEL.FREEZE_BACKBONE)
+                assert ("conv1_w" in eng.trainable) == (not frozen), (name, frozen)
 
 
 def test_product_code_never_imports_the_oracle():
