@@ -1092,10 +1092,13 @@ class LossStep(Step):
             # production step (1/8 loss scale, ~1900 targets) and of a 2-clip test sit in the same fp16 range
             # DATA PARALLEL: gradients scaled by this factor are SUMMED across ranks, so every rank must choose the same
             # one.  The number of RoI rows differs from rank to rank and from step to step (lib/datasets/ava.py); the
-            # number of clips per GPU does not (misc.py:68-72).  A RoI head therefore sizes the bound for its nominal
-            # 3 RoIs per clip instead of the rows it happens to hold (a rank with fewer rows sits at most 2^1.6 higher).
+            # number of clips per GPU does not (misc.py:68-72).  A RoI head therefore sizes the bound for a nominal
+            # 2 RoIs per clip instead of the rows it happens to hold: the bound of |dlogits| then lies between 2^5 (4 RoIs
+            # per clip) and 2^7 (1 per clip).  Both ends matter on the `mix` path: one binade up and the fp16 intermediates
+            # of the non-local backward lose accuracy (measured at full size: theta_w 9.7e-4 -> 1.10e-3), one down and
+            # more of the small gradients are subnormal.
             clips = self.eng.plan_clips
-            rows = 3 * clips if (self.eng.plan_roi_rows and clips is not None) else self.rows
+            rows = 2 * clips if (self.eng.plan_roi_rows and clips is not None) else self.rows
             norm = rows * self.cols if self.kernel == "vlfb_sigmoid_ce" else rows
             self.eng.loss_scale = float(2.0 ** round(math.log2(64.0 * norm / self.scale)))
         if self.loss is not None:
