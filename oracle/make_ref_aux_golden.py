@@ -264,6 +264,14 @@ def section_lfb(config, reset, meta, arrays):
     arrays["lfb_ev_queries"] = np.array(q, dtype=np.int64)
     arrays["lfb_ev_samples"] = np.stack([np.asarray(epic.sample_verb_lfb(c, vbank), dtype=np.float64) for c in q])
     cases.append({"kind": "epic_verb", "dim": D, "window": 7})
+    # (a second verb bank on the frames the dataset really annotates, f % 30 == 0, epic.py:286-303: what the device bank
+    #  indexes by step = f / 30)
+    abank = {f: rng.standard_normal(D).astype(np.float32) for f in range(0, 900, 30) if f not in (120, 150, 600)}
+    q = [0, 29, 30, 31, 100, 135, 449, 450, 880, 899, 2000]
+    arrays["lfb_eva_bank_keys"] = np.array(sorted(abank), dtype=np.int64)
+    arrays["lfb_eva_bank_rows"] = np.array([abank[f] for f in sorted(abank)], dtype=np.float32)
+    arrays["lfb_eva_queries"] = np.array(q, dtype=np.int64)
+    arrays["lfb_eva_samples"] = np.stack([np.asarray(epic.sample_verb_lfb(c, abank), dtype=np.float64) for c in q])
     load("epic_noun_r50_lfb_nl", ["LFB.LFB_DIM", D, "LFB.WINDOW_SIZE", 12, "EPIC.MAX_NUM_FEATS_PER_NOUN_LFB_FRAME", 4,
                                   "EPIC.NOUN_LFB_FRAMES_PER_SECOND", 1])
     nbank, counts = {}, []

@@ -399,3 +399,91 @@ def test_parameter_update_rules(k):
     assert got_wd == want_wd
     if "NONLOCAL.USE_BN" in case["overrides"]:
         assert len(set(want_wd.values())) == 2          # (the batch-norm case exercises both classes)
+
+
+@pytest.mark.parametrize("k", range(len(META["prep"])))
+def test_product_clip_geometry_reproduces_the_reference_clip(k):
+    """the PRODUCT's host side of the device preprocessing (datasets.data_input_helper.plan_clip: the same np.random calls in
+    the same order -> resized size, window origin, walk direction, transformed boxes) against the reference's output:
+    boxes bit for bit, and the window it tells the kernel to read -- taken here from frames resized on the host by the
+    restated INTER_LINEAR -- is the reference's clip after the kernel's /255, mean / std and channel flip"""
+    from datasets import data_input_helper as dh
+    from oracle import preprocess as op
+    case = META["prep"][k]
+    cfg = _load("ava_r50_lfb_nl", ["TRAIN.JITTER_SCALES", str(case["jitter"]), "TEST.SCALE", case["test_scale"],
+                                   "DATASET", case["dataset"], "AVA.FORCE_TEST_FLIP", case["force_flip"],
+                                   "MODEL.USE_BGR", case["use_bgr"]])
+    h, w = case["frames"]
+    frames = list(Z["prep_frames_%dx%d" % (h, w)])
+    boxes = Z["prep_%d_boxes_in" % k].copy() if case["boxes"] else None
+    np.random.seed(case["np_seed"])
+    plan, out_boxes = dh.plan_clip(h, w, case["split"], case["crop"], case["shift"], boxes, np.random)
+    if case["boxes"]:
+        assert np.array_equal(np.asarray(out_boxes, dtype=np.float64), Z["prep_%d_boxes_out" % k])
+    else:
+        assert out_boxes is None
+    crop = case["crop"]
+    rs = [op.resize_u8(f, plan["resized_w"], plan["resized_h"]) if (plan["resized_h"], plan["resized_w"]) != (h, w) else f
+          for f in frames]
+    cols = plan["x0"] + (-1 if plan["flip"] else 1) * np.arange(crop)
+    win = np.stack([r[plan["y0"]:plan["y0"] + crop][:, cols] for r in rs]).astype(np.float32)      # (T, crop, crop, 3) BGR
+    mean = np.array(cfg.DATA_MEAN, dtype=np.float32)
+    std = np.array(cfg.DATA_STD, dtype=np.float32)
+    want = Z["prep_%d_clip" % k]                                  # (3, T, crop, crop), RGB unless MODEL.USE_BGR
+    got = ((win / np.float32(255.0)) - mean) / std                # (the kernel's arithmetic, csrc/vlfb_data.hip)
+    got = got.transpose(3, 0, 1, 2)
+    if not case["use_bgr"]:
+        got = got[::-1]
+    assert np.array_equal(np.ascontiguousarray(got), want)
+
+
+# ---- the product's bank-step arithmetic (host side of csrc/vlfb_lfb.hip) ----------------------------------------------------------
+def _compact(rows_by_step, lo, hi, window, dim, max_per_step=1):
+    """what the device gather does with a step range: occupied steps in order, up to max_per_step rows each, the first
+    `window` rows, zero padded (vlfb.lfb_bank.DeviceBank._sample_packed)"""
+    out = np.zeros((window, dim))
+    k = 0
+    for t in range(int(lo), int(hi) + 1):
+        for r in rows_by_step.get(t, [])[:max_per_step]:
+            if k < window:
+                out[k] = r
+                k += 1
+    return out
+
+
+def test_product_window_steps_select_what_the_reference_selects():
+    """vlfb.lfb_bank.{frame,epic_verb,epic_noun}_window_steps: the bank-step range handed to the gather kernel covers exactly
+    the frames the reference's samplers visit (rounding of the window start, inclusive ends, floor / ceil onto bank
+    steps, truncation toward zero in the noun window) -- reference outputs on synthetic banks as the judge"""
+    from vlfb import lfb_bank as lb
+    # Charades: bank step t holds frame sample_freq * (t + 1) - 1
+    case = _lfb_case("charades")
+    sf = lb.FPS // case["clips_per_second"]
+    banks = {}
+    for (v, f), row in zip(Z["lfb_ch_bank_keys"], Z["lfb_ch_bank_rows"]):
+        assert (f + 1) % sf == 0
+        banks.setdefault(int(v), {})[(int(f) + 1) // sf - 1] = [row]
+    q = Z["lfb_ch_queries"]
+    lo, hi = lb.frame_window_steps(q[:, 1], case["window"], case["clips_per_second"])
+    for i, (v, c) in enumerate(q):
+        got = _compact(banks[int(v)], lo[i], hi[i], case["window"], case["dim"])
+        assert np.array_equal(got, Z["lfb_ch_samples"][i]), (v, c)
+    # EPIC verb: bank step t holds frame 30 t
+    case = _lfb_case("epic_verb")
+    bank = {int(f) // lb.EPIC_FPS: [r] for f, r in zip(Z["lfb_eva_bank_keys"], Z["lfb_eva_bank_rows"])}
+    q = Z["lfb_eva_queries"]
+    lo, hi = lb.epic_verb_window_steps(q, case["window"])
+    for i, c in enumerate(q):
+        got = _compact(bank, lo[i], hi[i], case["window"], case["dim"])
+        assert np.array_equal(got.astype(np.float32), Z["lfb_eva_samples"][i].astype(np.float32)), c
+    # EPIC noun: up to max_per_frame detections per bank step, steps one detector frame apart
+    case = _lfb_case("epic_noun")
+    bank, at = {}, 0
+    for f, n in Z["lfb_en_counts"]:
+        bank[int(f) // (lb.EPIC_FPS // case["frames_per_second"])] = list(Z["lfb_en_rows"][at:at + n])
+        at += int(n)
+    q = Z["lfb_en_queries"]
+    lo, hi = lb.epic_noun_window_steps(q, case["window"], case["max_per_frame"], case["frames_per_second"])
+    for i, c in enumerate(q):
+        got = _compact(bank, lo[i], hi[i], case["window"], case["dim"], case["max_per_frame"])
+        assert np.array_equal(got, Z["lfb_en_samples"][i]), c
