@@ -487,3 +487,21 @@ def test_product_window_steps_select_what_the_reference_selects():
     for i, c in enumerate(q):
         got = _compact(bank, lo[i], hi[i], case["window"], case["dim"], case["max_per_frame"])
         assert np.array_equal(got, Z["lfb_en_samples"][i]), c
+
+
+@pytest.mark.parametrize("k", range(len(META["multicrop"])))
+def test_product_multi_crop_merge(k):
+    """vlfb.multicrop.{shift_validity, merge_shifts, merge_scales_and_flips} (the host arithmetic of the product's AVA
+    multi-crop tester) against the reference's merge of synthetic score files, exactly"""
+    from vlfb import multicrop as mc
+    case = META["multicrop"][k]
+    boxes, logits = Z["mc_%d_boxes" % k], Z["mc_%d_logits" % k]
+    per_pass = []
+    for si, scale in enumerate(case["scales"]):
+        for fi, flip in enumerate([False, True]):
+            valid = mc.shift_validity(boxes, flip, scale, case["height"], case["width"])
+            got = mc.merge_shifts(logits[si, fi], valid)
+            assert np.array_equal(got, Z["mc_%d_combined" % k][si, fi]), (scale, flip)
+            per_pass.append(got)
+    total = mc.merge_scales_and_flips(per_pass)
+    assert np.array_equal(np.array([[float("%f" % v) for v in row] for row in total]), Z["mc_%d_final" % k])
