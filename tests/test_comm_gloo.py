@@ -93,3 +93,49 @@ def test_failed_conversion_on_rank_0_raises_on_every_rank_instead_of_hanging(tmp
         p.join(120)
         assert p.exitcode == 0, "a rank hung or crashed"
     assert set(out.keys()) == {0, 1} and all(v != "returned" for v in out.values()), dict(out)
+
+
+def _nan_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "video-long-term-feature-banks_amd", "lib"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      VLFB_DIST_BACKEND="gloo")
+    from vlfb import dist
+    import utils.misc as misc
+    dist.init_from_env()
+
+    class Eng(object):
+        def __init__(self, losses):
+            self.model = type("M", (), {"scope": "gpu_%d/" % rank})()
+            self._l = losses
+
+        def recent_losses(self):
+            return self._l
+    m = type("M", (), {})()
+    m.engine = Eng([0.5, 0.4])
+    assert misc.check_nan_losses(m) == [0.5, 0.4]                       # nobody has a NaN: nobody raises
+    m.engine = Eng([0.5, float("nan")] if rank == 1 else [0.5, 0.4])   # rank 1 only
+    try:
+        misc.check_nan_losses(m)
+        out[rank] = "no error"
+    except FloatingPointError as e:
+        out[rank] = str(e)
+    dist.barrier()                                                      # (everybody is still here)
+    td.destroy_process_group()
+
+
+def test_nan_guard_stops_every_rank_together():
+    """utils.misc.check_nan_losses in a job: the rank that sees the NaN and the ranks that do not raise at the same call
+    (the reference is one process for all GPUs, misc.py:50-58; here a lone exit would leave the others in the next all-reduce)"""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(out) == {0: "NaN losses on another rank", 1: "NaN losses on gpu_1/"}

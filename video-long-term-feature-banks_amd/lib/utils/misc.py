@@ -37,11 +37,21 @@ def check_nan_losses(model=None):
         from vlfb import workspace
         engines = list(workspace._engines.values())
     seen = []
+    bad = None
     for eng in engines:
         if eng is None:
             continue
         losses = eng.recent_losses()
         seen.extend(losses)
-        if any(math.isnan(v) for v in losses):
-            raise FloatingPointError("NaN losses on %s" % (getattr(eng.model, "scope", "") or "gpu_0/"))
+        if bad is None and any(math.isnan(v) for v in losses):
+            bad = getattr(eng.model, "scope", "") or "gpu_0/"
+    # One process per GPU: the rank whose loss went NaN first must not leave alone -- its NaN gradient reaches the others
+    # only through the next all-reduce, which would then wait for a rank that is gone.  Every rank calls this at the same
+    # iterations, so the verdict is taken together (one int32 all-reduce) and every rank raises.
+    from vlfb import dist
+    if dist.initialized():
+        if not dist.all_ok(bad is None) and bad is None:
+            bad = "another rank"
+    if bad is not None:
+        raise FloatingPointError("NaN losses on %s" % bad)
     return seen
