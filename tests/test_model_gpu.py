@@ -542,6 +542,48 @@ def test_every_shipped_config_trains_on_the_default_path():
         torch.cuda.empty_cache()
 
 
+def test_a_batch_padded_with_ignored_rows_is_the_same_batch():
+    """How a ragged AVA batch runs on ONE plan: the engine is planned for a fixed number of RoI rows, and a step with fewer
+    RoIs pads `proposals` with any box of an existing clip, `labels` with -1 (ignored by SigmoidCrossEntropyLoss: no loss
+    term, no gradient, not counted by the normaliser -- Caffe2's semantics, restated in csrc/vlfb_head.hip and oracle/model.py)
+    and `lfb` with zeros.  Loss, the probabilities of the real rows and every parameter gradient are those of the unpadded
+    batch (in the fp64 oracle exactly; here up to the fp32 summation order of the head GEMMs, whose row count changed)."""
+    from vlfb.engine import Engine
+    cfg, model, eng, inputs, params, seed_fn = build("ava_r50_lfb_nl", "fp32", SMALL8)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    loss0 = float(eng.fetch("loss").reshape(-1)[0])
+    prob0 = eng.fetch("prob")
+    grads0 = {n: eng.fetch_grad(n) for n in eng.trainable}
+    del eng
+    torch.cuda.empty_cache()
+    extra, R = 3, inputs["proposals"].shape[0]
+    padded = dict(inputs)
+    padded["proposals"] = np.concatenate([inputs["proposals"], np.zeros((extra, 5), inputs["proposals"].dtype)])
+    padded["labels"] = np.concatenate([inputs["labels"], -np.ones((extra, inputs["labels"].shape[1]), inputs["labels"].dtype)])
+    padded["lfb"] = np.concatenate([inputs["lfb"], np.zeros((extra,) + inputs["lfb"].shape[1:], inputs["lfb"].dtype)])
+    eng = Engine(model, "fp32", base_seed=cfg.RNG_SEED)
+    eng.plan(collections.OrderedDict((k + "_train", v.shape) for k, v in padded.items() if (k + "_train") in model.input_blob_names))
+    eng.feed_params(params)
+    for k, v in padded.items():
+        if (k + "_train") in model.input_blob_names:
+            eng.feed(k + "_train", v)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    loss1 = float(eng.fetch("loss").reshape(-1)[0])
+    assert abs(loss1 - loss0) < 1e-6 * abs(loss0), (loss0, loss1)
+    prob1 = eng.fetch("prob")
+    assert prob1.shape[0] == R + extra and rel(prob1[:R], prob0) < 1e-6
+    gmax = max(float(np.linalg.norm(g)) for g in grads0.values())
+    for n, g0 in grads0.items():
+        g1 = eng.fetch_grad(n)
+        assert np.isfinite(g1).all(), n
+        assert np.linalg.norm(g1.astype(np.float64) - g0) <= 1e-5 * np.linalg.norm(g0) + 1e-7 * gmax, \
+            (n, float(np.linalg.norm(g1.astype(np.float64) - g0)), float(np.linalg.norm(g0)))
+
+
 def test_roi_head_integer_decisions_are_bit_exact():
     """RoIAlign batch index / sampling grid / bilinear corners inside the full AVA model"""
     from oracle import model as om
