@@ -582,6 +582,18 @@ def test_a_batch_padded_with_ignored_rows_is_the_same_batch():
         assert np.isfinite(g1).all(), n
         assert np.linalg.norm(g1.astype(np.float64) - g0) <= 1e-5 * np.linalg.norm(g0) + 1e-7 * gmax, \
             (n, float(np.linalg.norm(g1.astype(np.float64) - g0)), float(np.linalg.norm(g0)))
+    # Engine.feed pads by itself when a RoI input has fewer rows than the plan: feeding the UNPADDED arrays is the same step
+    grads1 = {n: eng.fetch_grad(n) for n in grads0}
+    for k in ("proposals", "labels", "lfb"):
+        eng.feed(k + "_train", inputs[k])
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert float(eng.fetch("loss").reshape(-1)[0]) == loss1
+    for n in grads0:
+        assert np.array_equal(eng.fetch_grad(n), grads1[n]), n
+    with pytest.raises(AssertionError, match="planned"):
+        eng.feed("proposals_train", np.zeros((R + extra + 1, 5), np.float32))       # more rows than the plan holds
 
 
 def test_roi_head_integer_decisions_are_bit_exact():

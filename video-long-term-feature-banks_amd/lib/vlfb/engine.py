@@ -2184,6 +2184,14 @@ class Engine(object):
             raise KeyError("%r is not an input blob of this model" % name)
         root = b.root
         t = torch.as_tensor(np.asarray(arr))
+        if tuple(t.shape) != tuple(root.shape) and self.plan_roi_rows and str(name).startswith(("labels", "proposals", "lfb")) \
+                and t.dim() == len(root.shape) and tuple(t.shape[1:]) == tuple(root.shape[1:]) and 0 < t.shape[0] < root.shape[0]:
+            # a RoI batch smaller than the plan (the number of AVA boxes changes from step to step): the missing rows are
+            # padding -- labels -1 (ignored by the loss: no term, no gradient, not in the normaliser), box 0 of clip 0,
+            # an empty bank window.  Loss and gradients are those of the unpadded batch ("Ragged batches").
+            fill = -1 if str(name).startswith("labels") else 0
+            pad = torch.full((root.shape[0] - t.shape[0],) + tuple(t.shape[1:]), fill, dtype=t.dtype)
+            t = torch.cat([t, pad], dim=0)
         assert tuple(t.shape) == tuple(root.shape), "feed %s: shape %r, planned %r" % (name, tuple(t.shape), root.shape)
         if root.kind == "i32":
             root.tensor.copy_(t.to(torch.int32).reshape(-1).to(self.device))
