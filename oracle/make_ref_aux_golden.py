@@ -166,6 +166,65 @@ def section_lr(config, mb, reset, meta, arrays):
     meta["lr"] = out
 
 
+CONFIG_CASES = [
+    ["TRAIN.BATCH_SIZE", "16"], ["SOLVER.BASE_LR", "0.1"], ["SOLVER.LRS", "[1, 0.1]"], ["DATASET", "charades"],
+    ["MODEL.USE_AFFINE", "True"], ["NUM_GPUS", "eight"], ["TRAIN.NOPE", "1"], ["NOPE.KEY", "1"], ["SOLVER.BASE_LR", "1"],
+    ["TRAIN.JITTER_SCALES", "[1, 2, 3]"], ["CHECKPOINT.DIR", "/tmp/x"], ["LFB.MODEL_PARAMS_FILE", "a.pkl"],
+    ["SOLVER.STEPS", "[0, 5]"], ["SOLVER.STEPS", "None"], ["MODEL.USE_AFFINE", "1"], ["NUM_GPUS", "4.0"],
+    ["TRAIN.BATCH_SIZE", "16", "TEST.BATCH_SIZE"], ["DATA_MEAN", "[0.5, 0.5, 0.5]"], ["LFB.FBO_TYPE", "'max'"],
+    ["AVA.DETECTION_SCORE_THRESH_EVAL", "[0.85]"], ["TRAIN.CROP_SIZE", "224", "TRAIN.CROP_SIZE", "112"],
+]
+MERGE_CASES = [
+    {"NUM_GPUS": 4}, {"NOT_A_KEY": 1}, {"TRAIN": {"NOPE": 1}}, {"NUM_GPUS": "eight"}, {"NUM_GPUS": "4"},
+    {"SOLVER": {"BASE_LR": 1}}, {"SOLVER": {"STEPS": [0, 3]}}, {"TRAIN": {"JITTER_SCALES": "[1, 2]"}},
+    {"DATASET": "epic", "MODEL": {"MULTI_LABEL": False}}, {"MODEL": {"MODEL_NAME": None}}, {"TRAIN": 3},
+]
+
+
+def section_config(config, reset, meta):
+    """lib/core/config.py:394-451 merge_dicts / cfg_from_list: what a YAML tree or a KEY VAL list does to the configuration --
+    the values it sets (string literals evaluated, types checked against the default's) and the error class it raises"""
+    def get(key):
+        node = config.config
+        for k in key.split("."):
+            node = node[k]
+        return node
+    out_list = []
+    for args in CONFIG_CASES:
+        reset()
+        try:
+            config.cfg_from_list(list(args))
+            res = {"values": {k: get(k) for k in args[0::2]}}
+        except BaseException as e:
+            res = {"raises": type(e).__name__}
+        out_list.append({"args": args, "result": res})
+    out_merge = []
+    for tree in MERGE_CASES:
+        reset()
+        try:
+            config.merge_dicts(_attr(config, tree), config.config)
+            flat = {}
+
+            def walk(t, prefix=""):
+                for k, v in t.items():
+                    if isinstance(v, dict):
+                        walk(v, prefix + k + ".")
+                    else:
+                        flat[prefix + k] = get(prefix + k)
+            walk(tree)
+            res = {"values": flat}
+        except BaseException as e:
+            res = {"raises": type(e).__name__}
+        out_merge.append({"tree": tree, "result": res})
+    meta["config"] = {"cfg_from_list": out_list, "merge_dicts": out_merge}
+
+
+def _attr(config, tree):
+    """what yaml.load hands to merge_dicts: an AttrDict at the top, plain dicts below (cfg_from_file, config.py:427)"""
+    from utils.collections import AttrDict
+    return AttrDict(tree)
+
+
 def section_misc(config, reset, meta):
     import utils.misc as misc
     out = []
@@ -608,6 +667,7 @@ def main():
     meta, arrays = {"generator": "oracle/make_ref_aux_golden.py"}, {}
     section_lr(config, mb, reset, meta, arrays)
     section_misc(config, reset, meta)
+    section_config(config, reset, meta)
     section_lfb(config, reset, meta, arrays)
     section_prep(config, reset, meta, arrays)
     section_ckpt(config, reset, meta, arrays)

@@ -505,3 +505,50 @@ def test_product_multi_crop_merge(k):
             per_pass.append(got)
     total = mc.merge_scales_and_flips(per_pass)
     assert np.array_equal(np.array([[float("%f" % v) for v in row] for row in total]), Z["mc_%d_final" % k])
+
+
+# ---- configuration semantics ---------------------------------------------------------------------------------------------------
+def _get(cfg, dotted):
+    node = cfg
+    for k in dotted.split("."):
+        node = node[k]
+    return node
+
+
+@pytest.mark.parametrize("case", META["config"]["cfg_from_list"], ids=lambda c: " ".join(c["args"])[:40])
+def test_cfg_from_list_like_the_reference(case):
+    """lib/core/config.py:431-451 on KEY VAL lists: literals evaluated, the type of the default enforced (an int for a float
+    key is refused, so is a float for an int), None-default keys accept anything, unknown keys / odd lists are assertions"""
+    from core import config as C
+    C.reset_cfg()
+    want = case["result"]
+    if "raises" in want:
+        with pytest.raises(BaseException) as e:
+            C.cfg_from_list(list(case["args"]))
+        assert type(e.value).__name__ == want["raises"]
+    else:
+        C.cfg_from_list(list(case["args"]))
+        for k, v in want["values"].items():
+            got = _get(C.config, k)
+            assert got == v and type(got) is type(v), (k, got, v)
+    C.reset_cfg()
+
+
+@pytest.mark.parametrize("case", META["config"]["merge_dicts"], ids=lambda c: json.dumps(c["tree"])[:40])
+def test_merge_dicts_like_the_reference(case):
+    """lib/core/config.py:394-421 on YAML-shaped trees: values set, and the error CLASS where it refuses (KeyError for an
+    unknown top-level key, ValueError for a type change -- also for a list on the None-default SOLVER.STEPS --, a plain
+    Exception for anything that goes wrong below the top level)"""
+    from core import config as C
+    C.reset_cfg()
+    want = case["result"]
+    if "raises" in want:
+        with pytest.raises(BaseException) as e:
+            C.merge_dicts(case["tree"], C.config)
+        assert type(e.value).__name__ == want["raises"]
+    else:
+        C.merge_dicts(case["tree"], C.config)
+        for k, v in want["values"].items():
+            got = _get(C.config, k)
+            assert got == v and type(got) is type(v), (k, got, v)
+    C.reset_cfg()

@@ -131,11 +131,8 @@ def test_composites_expand_like_the_reference_composites(g):
         pass
     for meth in ("Relu_", "Conv3dBN", "Conv3dAffine"):
         setattr(Expanded, meth, ModelBuilder.__dict__[meth])
-    C.reset_cfg()
-    tree = json.loads(json.dumps(g["cfg"]))
-    tree["LFB"].pop("NUM_LFB_FEAT")
-    C.merge_dicts(tree, C.config)
-    C.assert_and_infer_cfg()
+    from vlfb.presets import load_preset
+    load_preset(g["config"], g["overrides"])
     model = Expanded(split=g["split"], train=(g["split"] == "train"), inplace_relu=cfg.MODEL.ALLOW_INPLACE_RELU)
     suffix = "_{}".format(g["split"])
     resnet_video.create_model(model=model, data="data" + suffix, labels="labels" + suffix, split=g["split"],

@@ -147,7 +147,10 @@ def _coerce(value):
 
 
 def merge_dicts(src, dst, path=""):
-    """Strict merge of `src` into `dst`: unknown keys and type changes are errors."""
+    """Strict merge of `src` into `dst` with the reference's rules (config.py:394-421): an unknown key is a KeyError, a
+    value whose type is not exactly the default's a ValueError (so a key whose default is None -- SOLVER.STEPS -- can only
+    be set through cfg_from_list), string values are evaluated as literals first, and whatever goes wrong below the top
+    level surfaces as `Exception('Error under config key: ...')`."""
     for key, raw in src.items():
         where = path + key
         if key not in dst:
@@ -157,10 +160,13 @@ def merge_dicts(src, dst, path=""):
             if not isinstance(dst[key], dict):
                 raise ValueError("Type mismatch (dict vs. {}) for config key: {}".format(
                     type(dst[key]), where))
-            merge_dicts(value, dst[key], where + ".")
+            try:
+                merge_dicts(value, dst[key], where + ".")
+            except BaseException as e:
+                raise Exception("Error under config key: {} ({})".format(where, e))
             continue
         old = dst[key]
-        if value is not None and old is not None and type(old) is not type(value):
+        if value is not None and type(old) is not type(value):
             raise ValueError("Type mismatch ({} vs. {}) for config key: {}".format(
                 type(old), type(value), where))
         dst[key] = value
