@@ -526,6 +526,77 @@ def section_ckpt(config, reset, meta, arrays):
     meta["ckpt"] = {"shapes": {n: list(s) for n, s in shapes.items()}, "params": params, "computed": ["bn_rm"],
                     "frozen": frozen, "runs": runs}
 
+    # -- start-of-training policy (checkpoints.py:180-236) and checkpoint discovery (:51-80) ---------------------------------------
+    # which file is loaded, with or without momentum, the iteration training starts from and model.current_lr, over
+    # CHECKPOINT.RESUME x TRAIN.PARAMS_FILE x checkpoints present x CHECKPOINT.CONVERT_MODEL x TRAIN.RESET_START_ITER
+    policy = []
+    calls = []
+    real_init = ck.initialize_params_from_file
+
+    def logged_init(model, weights_file, load_momentum=True):
+        calls.append([os.path.basename(weights_file), bool(load_momentum)])
+        return real_init(model=model, weights_file=weights_file, load_momentum=load_momentum)
+    ck.initialize_params_from_file = logged_init
+    pre = dict(file_blobs)
+    pre.update({"model_iter": 777, "lr": np.float32(0.02),
+                # (a classification checkpoint carries the BN statistics convert_model folds, checkpoints.py:88-116)
+                "res2_0_branch2a_bn_rm": rng.standard_normal(4).astype(np.float32),
+                "res2_0_branch2a_bn_riv": rng.uniform(0.1, 2.0, 4).astype(np.float32)})
+    ckpts = {"c2_model_iter100.pkl": (100, 0.003), "c2_model_iter2000.pkl": (2000, 0.0005), "c2_model_iter30.pkl": (30, 0.01)}
+    k = 0
+    for resume in (False, True):
+        for params_file in (False, True):
+            for have_ckpt in (False, True):
+                for convert in (False, True):
+                    for reset_iter in (True, False):
+                        if convert and not params_file:
+                            continue
+                        work = tempfile.mkdtemp()
+                        os.makedirs(os.path.join(work, "checkpoints"))
+                        pf = os.path.join(work, "pretrained.pkl")
+                        with open(pf, "wb") as f:
+                            pickle.dump({"blobs": pre}, f, protocol=2)
+                        if have_ckpt:
+                            for name, (it, lr) in ckpts.items():
+                                b = dict(file_blobs)
+                                b.update({"model_iter": it, "lr": np.float32(lr)})
+                                with open(os.path.join(work, "checkpoints", name), "wb") as f:
+                                    pickle.dump({"blobs": b}, f, protocol=2)
+                            open(os.path.join(work, "checkpoints", "notes.txt"), "w").close()
+                            open(os.path.join(work, "checkpoints", "c2_model_iter99999.txt"), "w").close()
+                        reset()
+                        config.cfg_from_file(os.path.join(REF, "configs", "ava_r50_lfb_nl.yaml"))
+                        config.cfg_from_list(["NUM_GPUS", "1", "TRAIN.BATCH_SIZE", "8", "TEST.BATCH_SIZE", "8",
+                                              "CHECKPOINT.DIR", work, "CHECKPOINT.RESUME", str(resume),
+                                              "CHECKPOINT.CONVERT_MODEL", str(convert), "TRAIN.RESET_START_ITER", str(reset_iter),
+                                              "TRAIN.PARAMS_FILE", pf if params_file else ""])
+                        config.assert_and_infer_cfg()
+                        ws = DictWorkspace()
+                        ws.install(pyws)
+                        for n, v in init.items():
+                            ws.FeedBlob("gpu_0/" + n, v)
+                        for n, v in init_mom.items():
+                            ws.FeedBlob("gpu_0/" + n + "_momentum", v)
+                        model = FakeModel("train", params, ["bn_rm"], frozen)
+                        model.current_lr = -1.0
+                        del calls[:]
+                        assert ck.find_checkpoint() == have_ckpt
+                        latest = ck.get_checkpoint_resume_file()
+                        start = ck.load_model_from_params_file(model)
+                        for n in ("res2_0_branch2a_w", "res2_0_branch2a_bn_s", "pred_w", "pred_w_momentum"):
+                            arrays["ckpt_policy%d/%s" % (k, n)] = np.asarray(ws.blobs["gpu_0/" + n])
+                        policy.append({"resume": resume, "params_file": params_file, "have_checkpoints": have_ckpt,
+                                       "convert": convert, "reset_start_iter": reset_iter, "start_iter": int(start),
+                                       "current_lr": float(model.current_lr), "loads": [list(c) for c in calls],
+                                       "latest": os.path.basename(latest) if latest else None,
+                                       "lr_blob": float(ws.blobs["gpu_0/lr"]) if "gpu_0/lr" in ws.blobs else None})
+                        k += 1
+    ck.initialize_params_from_file = real_init
+    meta["ckpt"]["policy"] = policy
+    meta["ckpt"]["policy_checkpoints"] = {n: list(v) for n, v in ckpts.items()}
+    for n, v in pre.items():
+        arrays["ckpt_pre/" + n] = np.asarray(v)
+
 
 def section_multicrop(config, reset, meta, arrays):
     """lib/utils/metrics.py:623-711 on synthetic score files.  Python-2 leftovers in that module: `map` must return a

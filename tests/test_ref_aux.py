@@ -552,3 +552,59 @@ def test_merge_dicts_like_the_reference(case):
             got = _get(C.config, k)
             assert got == v and type(got) is type(v), (k, got, v)
     C.reset_cfg()
+
+
+# ---- start of training: which file, with or without momentum, from which iteration ----------------------------------------------
+@pytest.mark.parametrize("k", range(len(META["ckpt"]["policy"])),
+                         ids=lambda k: "".join("%s%d" % (n[0], META["ckpt"]["policy"][k][n]) for n in
+                                               ("resume", "params_file", "have_checkpoints", "convert", "reset_start_iter")))
+def test_start_of_training_policy(k, tmp_path):
+    """checkpoints.py:180-236 load_model_from_params_file (+ :51-80 checkpoint discovery, :149-177 convert_model) run over
+    CHECKPOINT.RESUME x TRAIN.PARAMS_FILE x checkpoints on disk x CHECKPOINT.CONVERT_MODEL x TRAIN.RESET_START_ITER: the file
+    that gets loaded (the newest c2_model_iter*.pkl by NUMBER, the pre-trained file, the converted file), whether momentum
+    comes with it, the iteration training starts from, model.current_lr and the loaded values"""
+    from utils import checkpoints as ck
+    info, case = META["ckpt"], META["ckpt"]["policy"][k]
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "checkpoints"))
+    pre = {n: _scalar_or_array(v) for n, v in _group("ckpt_pre/").items()}
+    pf = os.path.join(work, "pretrained.pkl")
+    with open(pf, "wb") as fh:
+        pickle.dump({"blobs": pre}, fh, protocol=2)
+    if case["have_checkpoints"]:
+        base = {n: _scalar_or_array(v) for n, v in _group("ckpt_file/").items()}
+        for name, (it, lr) in info["policy_checkpoints"].items():
+            b = dict(base)
+            b.update({"model_iter": it, "lr": np.float32(lr)})
+            with open(os.path.join(work, "checkpoints", name), "wb") as fh:
+                pickle.dump({"blobs": b}, fh, protocol=2)
+        open(os.path.join(work, "checkpoints", "notes.txt"), "w").close()
+        open(os.path.join(work, "checkpoints", "c2_model_iter99999.txt"), "w").close()
+    _load("ava_r50_lfb_nl", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 8, "TEST.BATCH_SIZE", 8, "CHECKPOINT.DIR", work,
+                             "CHECKPOINT.RESUME", case["resume"], "CHECKPOINT.CONVERT_MODEL", case["convert"],
+                             "TRAIN.RESET_START_ITER", case["reset_start_iter"],
+                             "TRAIN.PARAMS_FILE", pf if case["params_file"] else ""])
+    model = _Model(info, True)
+    model.engine = _Engine(_group("ckpt_init/"), True)
+    model.current_lr = -1.0
+    loads = []
+    real = ck.initialize_params_from_file
+
+    def logged(model, weights_file, load_momentum=True):
+        loads.append([os.path.basename(weights_file), bool(load_momentum)])
+        return real(model=model, weights_file=weights_file, load_momentum=load_momentum)
+    ck.initialize_params_from_file = logged
+    try:
+        assert ck.find_checkpoint() == case["have_checkpoints"]
+        latest = ck.get_checkpoint_resume_file()
+        assert (os.path.basename(latest) if latest else None) == case["latest"]
+        start = ck.load_model_from_params_file(model)
+    finally:
+        ck.initialize_params_from_file = real
+    assert start == case["start_iter"] and loads == case["loads"]
+    assert float(model.current_lr) == case["current_lr"]
+    if case["lr_blob"] is not None:
+        assert float(model.engine.lr) == case["lr_blob"]
+    for n, want in _group("ckpt_policy%d/" % k).items():
+        got = model.engine.m[n[:-len("_momentum")]] if n.endswith("_momentum") else model.engine.p[n]
+        assert np.array_equal(got, want), n
