@@ -225,6 +225,48 @@ def _attr(config, tree):
     return AttrDict(tree)
 
 
+def section_lr_updates(config, mb, reset, meta):
+    """model_builder_video.py:252-290 SetCurrentLr / UpdateWorkspaceLr / _SetNewLr taken from the reference's class and
+    driven over a training run: at which iterations the learning-rate blob is rewritten, with what value, and when the
+    update history is rescaled (SOLVER.SCALE_MOMENTUM: ratio above SCALE_MOMENTUM_THRESHOLD and lr above 1e-7) and by which
+    factor.  _CorrectMomentum itself (Scale operators on the momentum blobs, :292-315) is replaced by a recorder."""
+    pyws = sys.modules["caffe2.python"].workspace
+    cases = [("ava_r50_lfb_nl", [], list(range(0, 12)) + [1999, 2000, 2001, 99999, 100000, 100001, 119999, 120000, 139999]),
+             ("ava_r50_lfb_nl", ["SOLVER.SCALE_MOMENTUM", False], [0, 1, 2, 99999, 100000, 120000]),
+             ("charades_r50_baseline", [], [0, 1, 19999, 20000, 20001, 23999]),
+             ("charades_r50_baseline", ["SOLVER.SCALE_MOMENTUM_THRESHOLD", 20.0], [0, 19999, 20000]),
+             ("ava_r50_lfb_nl", ["SOLVER.WARMUP.WARMUP_START_LR", 0.001, "SOLVER.WARMUP.WARMUP_END_ITER", 5], [0, 1, 2, 3, 4, 5, 6])]
+    out = []
+    for name, overrides, iters in cases:
+        reset()
+        config.cfg_from_file(os.path.join(REF, "configs", name + ".yaml"))
+        config.cfg_from_list(["NUM_GPUS", "2", "TRAIN.BATCH_SIZE", "16", "TEST.BATCH_SIZE", "16"] + [str(o) for o in overrides])
+        config.assert_and_infer_cfg()
+        ws = DictWorkspace()
+        ws.install(pyws)
+        events = []
+
+        class M(object):
+            SetCurrentLr = mb.ModelBuilder.__dict__["SetCurrentLr"]
+            UpdateWorkspaceLr = mb.ModelBuilder.__dict__["UpdateWorkspaceLr"]
+            _SetNewLr = mb.ModelBuilder.__dict__["_SetNewLr"]
+
+            def _CorrectMomentum(self, correction):
+                events.append(["correct_momentum", float(correction)])
+        m = M()
+        m.current_lr = 0
+        m.SetCurrentLr(iters[0])
+        trace = [{"iter": iters[0], "set_current": float(m.current_lr)}]
+        for it in iters[1:]:
+            del events[:]
+            before = dict(ws.blobs)
+            m.UpdateWorkspaceLr(it)
+            fed = {k: float(v) for k, v in ws.blobs.items() if k not in before or float(before[k]) != float(v)}
+            trace.append({"iter": it, "current_lr": float(m.current_lr), "fed": fed, "events": [list(e) for e in events]})
+        out.append({"config": name, "overrides": overrides, "trace": trace})
+    meta["lr_updates"] = out
+
+
 def section_misc(config, reset, meta):
     import utils.misc as misc
     out = []
@@ -738,6 +780,7 @@ def main():
     meta, arrays = {"generator": "oracle/make_ref_aux_golden.py"}, {}
     section_lr(config, mb, reset, meta, arrays)
     section_misc(config, reset, meta)
+    section_lr_updates(config, mb, reset, meta)
     section_config(config, reset, meta)
     section_lfb(config, reset, meta, arrays)
     section_prep(config, reset, meta, arrays)

@@ -608,3 +608,36 @@ def test_start_of_training_policy(k, tmp_path):
     for n, want in _group("ckpt_policy%d/" % k).items():
         got = model.engine.m[n[:-len("_momentum")]] if n.endswith("_momentum") else model.engine.p[n]
         assert np.array_equal(got, want), n
+
+
+# ---- learning-rate updates and momentum correction over a run --------------------------------------------------------------------
+@pytest.mark.parametrize("k", range(len(META["lr_updates"])))
+def test_lr_updates_and_momentum_correction_follow_the_reference(k):
+    """model_builder_video.py:252-290 of the reference driven over the iterations of a run (warm-up, the two decays, the
+    end): this repo's ModelBuilder.SetCurrentLr / UpdateWorkspaceLr must hand the engine a new learning rate at exactly
+    the iterations the reference rewrites its lr blobs, with the same float32 value, and rescale the update history at the
+    same iterations by the same factor (SOLVER.SCALE_MOMENTUM / SCALE_MOMENTUM_THRESHOLD)"""
+    from models.model_builder_video import ModelBuilder
+    case = META["lr_updates"][k]
+    _load(case["config"], ["NUM_GPUS", 2, "TRAIN.BATCH_SIZE", 16, "TEST.BATCH_SIZE", 16] + case["overrides"])
+    events = []
+
+    class Eng(object):
+        def set_lr(self, lr):
+            events.append(["set_lr", float(np.float32(lr))])
+
+        def scale_momentum(self, f):
+            events.append(["correct_momentum", float(f)])
+    m = ModelBuilder(train=True, split="train", name="t")
+    m.engine = Eng()
+    trace = case["trace"]
+    m.current_lr = 0
+    m.SetCurrentLr(trace[0]["iter"])
+    assert float(m.current_lr) == trace[0]["set_current"]
+    for t in trace[1:]:
+        del events[:]
+        m.UpdateWorkspaceLr(t["iter"])
+        assert float(m.current_lr) == t["current_lr"], t
+        fed = sorted(set(t["fed"].values()))
+        assert [e[1] for e in events if e[0] == "set_lr"] == fed, (t, events)       # one lr per GPU there, one engine here
+        assert [e for e in events if e[0] == "correct_momentum"] == t["events"], (t, events)
