@@ -14,11 +14,13 @@ committed fixtures (generators beside this file; the fixtures travel to the GPU 
     model helper (oracle/graph_recorder.py) -- every operator call with its arguments, for all 26 configs (train / test /
     LFB-extraction graphs) and the option switches; plus lib/core/config.py's defaults and the effective configuration of
     every YAML.  tests/test_ref_graph.py holds THIS repo's builders, config defaults and presets to them, call for call.
-  * oracle/make_ref_aux_golden.py -> tests/golden/ref_aux.npz: lr_policy.py, misc.py, tools/lfb_loader.py and the
+  * oracle/make_ref_aux_golden.py -> tests/golden/ref_aux.npz: lr_policy.py and the ModelBuilder's lr-update / momentum-
+    correction methods over a run, misc.py, config.py's merge_dicts / cfg_from_list rules, tools/lfb_loader.py and the
     datasets' LFB samplers, data_input_helper.py / image_processor.py (clip + box preprocessing), checkpoints.py (BN fold,
-    inflation, classifier rule, momentum policy, save format), metrics.py's multi-crop merge, add_parameter_update_ops --
-    on seeded synthetic inputs.  tests/test_ref_aux.py holds the product's host logic and oracle/{lfb,preprocess,
-    multicrop}.py to them, bit for bit.
+    inflation, classifier rule, momentum policy, save format, checkpoint discovery, the start-of-training policy),
+    metrics.py's multi-crop merge, add_parameter_update_ops -- on seeded synthetic inputs.  tests/test_ref_aux.py holds
+    the product's host logic and oracle/{lfb,preprocess,multicrop}.py to them, bit for bit; tests/test_ref_lfb_gpu.py
+    holds the feature-bank kernels to the same banks and samples.
   * AffineNd, the one operator the reference ships itself, is held bit for bit to the reference's own .cu compiled in
     place (oracle/build_ref.py, tests/test_ref_affine_gpu.py).
 STILL PARITY-UNPINNED: the arithmetic of the Caffe2 operators (Conv, MaxPool, AveragePool, BatchMatMul, Softmax,
