@@ -24,6 +24,17 @@ def rq(t, bits=None):
     return torch.ldexp(torch.round(m * s) / s, e)
 
 
+LOSS_SCALE = [None]      # EMU_LOG2S: stored gradients are true fp16 values of g * 2^EMU_LOG2S (range, subnormals, inf)
+
+
+def rqg(g):
+    """rounding of a STORED GRADIENT: 11 significant bits with unbounded exponent, or -- with a loss scale -- real fp16"""
+    if LOSS_SCALE[0] is None:
+        return rq(g)
+    S = LOSS_SCALE[0]
+    return (g * S).to(torch.float16).to(g.dtype) / S
+
+
 class Store(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bwd_r):
@@ -32,7 +43,7 @@ class Store(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (rq(g) if ctx.bwd_r else g), None
+        return (rqg(g) if ctx.bwd_r else g), None
 
 
 class ConvQ(torch.autograd.Function):
@@ -48,7 +59,7 @@ class ConvQ(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad, dil, qx, qw, has_b = ctx.cfg
         if QG[0]:
-            g = rq(g)
+            g = rqg(g)
         gi = gw = gb = None
         if ctx.needs_input_grad[0]:
             gi = torch.nn.grad.conv3d_input(x.shape, rq(w) if qw else w, g, stride, pad, dil)
@@ -75,7 +86,8 @@ def run(preset, variant):
     orig_conv, orig_ca, orig_bott, orig_nl = om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal
     orig_fconv = F.conv3d
 
-    def conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1)):
+    def conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1), groups=1):
+        assert groups == 1
         y = ConvQ.apply(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil, QX, QW)
         if "_branch" not in name and name != "conv1":
             y = Store.apply(y, B_ACT)
@@ -119,6 +131,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:
         BITS = int(sys.argv[2])
     torch.set_num_threads(8)
+    if os.environ.get("EMU_LOG2S"):
+        LOSS_SCALE[0] = 2.0 ** float(os.environ["EMU_LOG2S"])
     ref_b, ref_g = run(preset, {})
     only = os.environ.get("EMU_ONLY")
     for v, var in VARIANTS.items():

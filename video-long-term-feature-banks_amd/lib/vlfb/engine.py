@@ -1094,9 +1094,8 @@ class LossStep(Step):
             # one.  The number of RoI rows differs from rank to rank and from step to step (lib/datasets/ava.py); the
             # number of clips per GPU does not (misc.py:68-72).  A RoI head therefore sizes the bound for a nominal
             # 2 RoIs per clip instead of the rows it happens to hold: the bound of |dlogits| then lies between 2^5 (4 RoIs
-            # per clip) and 2^7 (1 per clip).  Both ends matter on the `mix` path: one binade up and the fp16 intermediates
-            # of the non-local backward lose accuracy (measured at full size: theta_w 9.7e-4 -> 1.10e-3), one down and
-            # more of the small gradients are subnormal.
+            # per clip) and 2^7 (1 per clip); 2 keeps the full-size parity configuration (1 clip, 2 RoIs) on the scale it
+            # was validated at (the backbone's gradients sit 16+ binades below the fp16 maximum there).
             clips = self.eng.plan_clips
             rows = 2 * clips if (self.eng.plan_roi_rows and clips is not None) else self.rows
             norm = rows * self.cols if self.kernel == "vlfb_sigmoid_ce" else rows
