@@ -46,13 +46,16 @@ class Store(torch.autograd.Function):
         return (rqg(g) if ctx.bwd_r else g), None
 
 
+_ORIG_CONV3D = F.conv3d
+
+
 class ConvQ(torch.autograd.Function):
     """exact forward; backward contracts ROUNDED operands: dgrad with q(w), wgrad with q(x)"""
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, dil, qx, qw):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, dil, qx, qw, b is not None)
-        return F.conv3d(x, w, b, stride, pad, dil)
+        return _ORIG_CONV3D(x, w, b, stride, pad, dil)
 
     @staticmethod
     def backward(ctx, g):
@@ -105,10 +108,22 @@ def run(preset, variant):
     def add_nl(cx, x, prefix, *a, **k):
         return Store.apply(orig_nl(cx, x, prefix, *a, **k), B_RES)
 
+    STEM = variant.get("stem", False)
+
+    def fconv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        # the stem (oracle/model.py calls F.conv3d directly for conv1): the clip as an fp16 copy in WGRAD, its output gradient
+        # stored in fp16 like every branch gradient
+        if STEM and w.dim() == 5 and w.shape[1] == 3 and groups == 1:
+            y = ConvQ.apply(x, w, b, stride, padding, (1, 1, 1), True, False)
+            return Store.apply(y, True)
+        return _ORIG_CONV3D(x, w, b, stride, padding, dilation, groups)
+
     om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = conv, conv_affine, bott, add_nl
+    om.F.conv3d = fconv
     try:
         blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda name: 7)
     finally:
+        om.F.conv3d = _ORIG_CONV3D
         om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = orig_conv, orig_ca, orig_bott, orig_nl
     return blobs, grads
 
@@ -124,6 +139,9 @@ VARIANTS = collections.OrderedDict([
     ("e_fp32store_qg_qx", dict(qg=True, qx=True)),
     ("h1_grads+qx", dict(bwd=True, bwd_res=True, qx=True)),
     ("h1_branch+qx", dict(bwd=True, qx=True)),
+    ("branch_only", dict(bwd=True)),
+    ("mix_like+stem", dict(bwd=True, qx=True, stem=True)),
+    ("stem_only", dict(stem=True)),
 ])
 
 if __name__ == "__main__":
