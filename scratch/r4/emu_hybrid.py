@@ -102,11 +102,29 @@ def run(preset, variant):
             return y
         return Store.apply(y, B_ACT)
 
+    STAGE = variant.get("stage", False)     # single-term fp16 trunk gradients where the engine has no two-term slot:
+    # the inputs of the stage-first blocks (two conv contributors: rounded twice) and the tensors the pools write
+
     def bott(cx, x, prefix, *a, **k):
-        return Store.apply(orig_bott(cx, x, prefix, *a, **k), B_RES)
+        y = Store.apply(orig_bott(cx, x, prefix, *a, **k), B_RES)
+        if STAGE and prefix == "res2_2":
+            y = Store.apply(y, True)                      # written by the pool2 backward
+        return y
 
     def add_nl(cx, x, prefix, *a, **k):
-        return Store.apply(orig_nl(cx, x, prefix, *a, **k), B_RES)
+        y = Store.apply(orig_nl(cx, x, prefix, *a, **k), B_RES)
+        if STAGE and prefix in ("nonlocal_conv3_3", "nonlocal_conv4_5"):
+            y = Store.apply(Store.apply(y, True), True)   # input of res4_0 / res5_0: shortcut dgrad, then + 2a dgrad
+        return y
+
+    orig_pool = om._max_pool
+
+    def max_pool(cx, x, name, *a, **k):
+        y = orig_pool(cx, x, name, *a, **k)
+        if STAGE and name in ("pool1", "pool2"):
+            y = Store.apply(Store.apply(y, True), True)   # input of res2_0 / res3_0
+        return y
+    om._max_pool = max_pool
 
     STEM = variant.get("stem", False)
 
@@ -124,6 +142,7 @@ def run(preset, variant):
         blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda name: 7)
     finally:
         om.F.conv3d = _ORIG_CONV3D
+        om._max_pool = orig_pool
         om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = orig_conv, orig_ca, orig_bott, orig_nl
     return blobs, grads
 
@@ -142,6 +161,7 @@ VARIANTS = collections.OrderedDict([
     ("branch_only", dict(bwd=True)),
     ("mix_like+stem", dict(bwd=True, qx=True, stem=True)),
     ("stem_only", dict(stem=True)),
+    ("mix_like+stem+stage", dict(bwd=True, qx=True, stem=True, stage=True)),
 ])
 
 if __name__ == "__main__":
