@@ -111,7 +111,12 @@ def run(preset, variant):
             y = Store.apply(y, True)                      # written by the pool2 backward
         return y
 
+    NLIN = variant.get("nlin", False)       # ... and one rounding of the trunk gradient at the input of every non-local block
+    # (its slot is two-term, but the pool-backward contribution of the phi / g branch is added to the high term only)
+
     def add_nl(cx, x, prefix, *a, **k):
+        if NLIN:
+            x = Store.apply(x, True)
         y = Store.apply(orig_nl(cx, x, prefix, *a, **k), B_RES)
         if STAGE and prefix in ("nonlocal_conv3_3", "nonlocal_conv4_5"):
             y = Store.apply(Store.apply(y, True), True)   # input of res4_0 / res5_0: shortcut dgrad, then + 2a dgrad
@@ -162,6 +167,7 @@ VARIANTS = collections.OrderedDict([
     ("mix_like+stem", dict(bwd=True, qx=True, stem=True)),
     ("stem_only", dict(stem=True)),
     ("mix_like+stem+stage", dict(bwd=True, qx=True, stem=True, stage=True)),
+    ("mix_like+stem+stage+nlin", dict(bwd=True, qx=True, stem=True, stage=True, nlin=True)),
 ])
 
 if __name__ == "__main__":
