@@ -73,6 +73,23 @@ class ConvQ(torch.autograd.Function):
         return gi, gw, gb, None, None, None, None, None
 
 
+_ORIG_LINEAR = F.linear
+
+
+class LinQ(torch.autograd.Function):
+    """the classifier (FCStep): fp16 dlogits, single-term fp16 weights in the input gradient, fp16 operands in the weight gradient"""
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return _ORIG_LINEAR(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = rqg(g)
+        return rqg(g @ rq(w)), g.t() @ rq(x), g.sum(0)
+
+
 def rel(a, b):
     d = float(b.norm())
     return float((a - b).norm()) / (d if d > 0 else 1.0)
@@ -141,13 +158,44 @@ def run(preset, variant):
             return Store.apply(y, True)
         return _ORIG_CONV3D(x, w, b, stride, padding, dilation, groups)
 
+    HEAD = variant.get("head", False)       # the head's fp16 gradient storage: classifier, dropout, pools, RoIAlign, FBO core
+    orig_avg, orig_roi, orig_drop, orig_ln, orig_core = F.avg_pool3d, om.roi_align_torch, om._dropout, om._layer_norm, om._nl_core
+
+    HEAD_FC = variant.get("head_fc", HEAD)      # the classifier alone
+    HEAD_REST = variant.get("head_rest", HEAD)  # everything between the classifier and res5
+
+    def st(t):
+        return Store.apply(t, True) if (HEAD_REST and torch.is_tensor(t) and t.requires_grad) else t
+
+    def linear(x, w, b=None):
+        return LinQ.apply(x, w, b) if HEAD_FC else _ORIG_LINEAR(x, w, b)
+
+    def avg_pool3d(x, *a, **k):
+        return st(orig_avg(st(x), *a, **k))
+
+    def roi_align(x, *a, **k):
+        return st(orig_roi(st(x), *a, **k))
+
+    def dropout(cx, x, *a, **k):
+        return st(orig_drop(cx, st(x), *a, **k))
+
+    def layer_norm(x):
+        return st(orig_ln(st(x)))
+
+    def nl_core(cx, A, Bk, *a, **k):
+        return st(orig_core(cx, st(A), st(Bk), *a, **k))
+
     om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = conv, conv_affine, bott, add_nl
+    om.F.linear, om.F.avg_pool3d, om.roi_align_torch, om._dropout, om._layer_norm, om._nl_core = \
+        linear, avg_pool3d, roi_align, dropout, layer_norm, nl_core
     om.F.conv3d = fconv
     try:
         blobs, grads = om.run(cfg, params, inputs, "train", torch.float64, True, lambda name: 7)
     finally:
         om.F.conv3d = _ORIG_CONV3D
         om._max_pool = orig_pool
+        om.F.linear, om.F.avg_pool3d, om.roi_align_torch, om._dropout, om._layer_norm, om._nl_core = \
+            _ORIG_LINEAR, orig_avg, orig_roi, orig_drop, orig_ln, orig_core
         om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal = orig_conv, orig_ca, orig_bott, orig_nl
     return blobs, grads
 
@@ -168,6 +216,11 @@ VARIANTS = collections.OrderedDict([
     ("stem_only", dict(stem=True)),
     ("mix_like+stem+stage", dict(bwd=True, qx=True, stem=True, stage=True)),
     ("mix_like+stem+stage+nlin", dict(bwd=True, qx=True, stem=True, stage=True, nlin=True)),
+    ("mix_like+head", dict(bwd=True, qx=True, head=True)),
+    ("head_only", dict(head=True)),
+    ("head_fc_only", dict(head_fc=True, head_rest=False)),
+    ("head_rest_only", dict(head_fc=False, head_rest=True)),
+    ("mix_like+stem+stage+head", dict(bwd=True, qx=True, stem=True, stage=True, head=True)),
 ])
 
 if __name__ == "__main__":
