@@ -180,6 +180,31 @@ def test_every_shipped_config_plans_in_train_and_test_mode():
                 assert ("conv1_w" in eng.trainable) == (not frozen), (name, frozen)
 
 
+def test_fp32_head_switch_is_off_and_marks_the_direct_path_when_on(monkeypatch):
+    """Engine.MIX_HEAD_F32 (written at the end of round 4 without GPU time to validate it: default OFF): with the switch on,
+    the gradient slots of the head's direct path -- classifier input, dropout input, the RoI features, the pooled res5 map --
+    are fp32 and the FBO branch keeps fp16; the backbone is untouched"""
+    from vlfb.engine import Engine
+    small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64)
+    assert Engine.MIX_HEAD_F32 is False
+    cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype="mix")
+    assert eng.head_f32 == []
+    nl_f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32)      # (the non-local theta / phi / g slots)
+    monkeypatch.setattr(Engine, "MIX_HEAD_F32", True)
+    cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype="mix")
+    assert eng.head_f32 == ["pool5_dropout", "pool5", "roi_feat_1d", "blob_pooled"]
+    assert sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32) == sorted(nl_f32 + eng.head_f32)
+    import torch
+    for b in eng.all_blobs:
+        if b.root is b and b.name in eng.head_f32:
+            assert b.slot.buf.dtype == torch.float32 and not b.slot.two_term
+    cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
+    assert eng.head_f32 == ["pool5_dropout", "res5_2_branch2c_bn_pooled"]
+    for dtype in ("fp16", "split"):                       # a `mix` switch: nothing happens on the other paths
+        cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype=dtype)
+        assert eng.head_f32 == []
+
+
 def test_product_code_never_imports_the_oracle():
     import os
     import re
