@@ -1740,8 +1740,9 @@ class Engine(object):
     # "mix" dtype: fp32 gradients on the DIRECT path of the head -- classifier, dropout, concat, RoIAlign + max, the temporal /
     # global average pool -- with one rounding to fp16 where the gradient enters res5 (PoolStep.bwd).  Those are five fp16
     # storages in series whose error is common to every backbone gradient; the CPU emulation attributes the median error of
-    # `mix` to them ("Located: it is the HEAD").  OFF: written without GPU time left in round 4 -- enable,
-    # run tests/test_model_gpu.py::test_full_size_clip_matches_oracle and compare with the emulation before making it default.
+    # `mix` to them ("Located: it is the HEAD").  OFF: written with 16 s of GPU time left in round 4 -- it
+    # executes and moves the gradients by a median 4.3e-4 (scratch/r4/head_f32_try.py); enable, run
+    # tests/test_model_gpu.py::test_full_size_clip_matches_oracle and compare with the emulation before making it default.
     MIX_HEAD_F32 = os.environ.get("VLFB_MIX_HEAD_F32", "0") == "1"
     # "mix" dtype: the residual-stream gradient as two fp16 terms (GradSlot.two_term)
     MIX_TRUNK2 = os.environ.get("VLFB_MIX_TRUNK2", "1") != "0"
