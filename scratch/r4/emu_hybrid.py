@@ -106,9 +106,12 @@ def run(preset, variant):
     orig_conv, orig_ca, orig_bott, orig_nl = om._conv, om._conv_affine, om._bottleneck, om._add_nonlocal
     orig_fconv = F.conv3d
 
+    QW_IN = variant.get("qw_in")            # single-term fp16 DGRAD weights only in the layers whose name starts with one of these
+
     def conv(x, P, name, stride=(1, 1, 1), pad=(0, 0, 0), dil=(1, 1, 1), groups=1):
         assert groups == 1
-        y = ConvQ.apply(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil, QX, QW)
+        qw = QW or (QW_IN is not None and name.startswith(tuple(QW_IN)))
+        y = ConvQ.apply(x, P[name + "_w"], P.get(name + "_b"), stride, pad, dil, QX, qw)
         if "_branch" not in name and name != "conv1":
             y = Store.apply(y, B_ACT)
         return y
@@ -216,6 +219,9 @@ VARIANTS = collections.OrderedDict([
     ("stem_only", dict(stem=True)),
     ("mix_like+stem+stage", dict(bwd=True, qx=True, stem=True, stage=True)),
     ("mix_like+stem+stage+nlin", dict(bwd=True, qx=True, stem=True, stage=True, nlin=True)),
+    ("w2_off_res2", dict(bwd=True, qx=True, stem=True, qw_in=("res2",))),
+    ("w2_off_res23", dict(bwd=True, qx=True, stem=True, qw_in=("res2", "res3", "nonlocal_conv3"))),
+    ("w2_off_res234", dict(bwd=True, qx=True, stem=True, qw_in=("res2", "res3", "nonlocal_conv3", "res4", "nonlocal_conv4"))),
     ("mix_like+head", dict(bwd=True, qx=True, head=True)),
     ("head_only", dict(head=True)),
     ("head_fc_only", dict(head_fc=True, head_rest=False)),
