@@ -15,3 +15,8 @@ for on in 0 1; do
   VLFB_MIX_HEAD_F32=$on timeout 200 python bench.py --dtype mix --steps 30 --warmup 4 --no-cpu-baseline --no-fp32-line --no-split-line > gpurun_out/r5a/bench_head$on.json 2>/dev/null
   python -c "import json; d=json.loads(open('gpurun_out/r5a/bench_head$on.json').read().splitlines()[-1]); print('head_f32=$on', d['value'], 'clips/s', d['ms_per_step'], 'ms')"
 done
+# then, with the fp32 head: plain fp16 DGRAD weights in res2 (+ res3)  (emulated max 6.6e-4 / 7.5e-4; expect 241-248 clips/s)
+for skip in res2 res2,res3; do
+  VLFB_MIX_HEAD_F32=1 VLFB_MIX_W2_SKIP=$skip MIX_FULL=1 timeout 400 python scratch/r4/mix_check.py ava_r50_lfb_nl 2>&1 | grep "^\[" | cut -c1-260
+  VLFB_MIX_HEAD_F32=1 VLFB_MIX_W2_SKIP=$skip timeout 200 python bench.py --dtype mix --steps 30 --warmup 4 --no-cpu-baseline --no-fp32-line --no-split-line 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().splitlines()[-1]); print('skip=$skip', d['value'], 'clips/s')"
+done

@@ -317,7 +317,7 @@ class ConvStep(Step):
             dg = dict(geom)
             alpha = 1.0 / self.gscale
             rows = dict(N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo)
-            if eng.mix and eng.MIX_W2:
+            if eng.mix and eng.MIX_W2 and not self.wname.startswith(eng.MIX_W2_SKIP or ("\0",)):
                 # two-term fp16 weights (hip.MIX_W2): the same convolution with a doubled OUTERMOST tap dimension of
                 # dilation 0, i.e. every tap is contracted with Wh and with Wl by the plain fp16 DGRAD kernels
                 k_, s_, p_, d_ = self.k, self.s, self.p, self.d
@@ -389,6 +389,9 @@ class ConvStep(Step):
         # per group, so the term planes of a group lie next to each other)
         self.wf_npl = 3 if eng.split else 1
         self.wd_npl = (2 if self.w2 else 1) if eng.mix else (2 if eng.split else 1)
+        # the format vlfb_weight_prep writes this conv's operand copies in ("mix": two-term or plain fp16 DGRAD copy, per conv --
+        # Engine.MIX_W2_SKIP; a conv without a DGRAD copy goes with the engine's default)
+        self.wcode = eng.wcode if not eng.mix else (hip.MIX if (self.w_d is not None and not self.w2) else eng.wcode)
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
@@ -408,7 +411,7 @@ class ConvStep(Step):
         s = eng.param_tensor(self.sname) if self.sname else None
         for g in range(self.group):
             hip.call("vlfb_weight_prep", _at(w, g * self.wblk), _at(s, g * self.Cog), self.wf_ptr(g), self.wd_ptr(g),
-                     eng.wcode, self.Cog, self.taps(), self.Cin_k)
+                     self.wcode, self.Cog, self.taps(), self.Cin_k)
         self.refresh_bias()
 
     def wf_ptr(self, g):
@@ -1736,6 +1739,10 @@ class Engine(object):
     MIX_W2 = os.environ.get("VLFB_MIX_W2", "1") != "0"
     # "mix" dtype: gradients of theta / phi / g of the non-local blocks in fp32, their weight gradients and the dP product of
     # the attention backward as split-bf16 products, the softmax backward on the fp32 probabilities
+    # "mix" dtype: parameter-name prefixes whose convs keep PLAIN fp16 DGRAD weights although MIX_W2 is on (e.g. "res2,res3").
+    # The emulation says the two-term weights can go in res2 (+ res3) once the head is fp32; res2 is where they
+    # cost most, because they take the streaming and direct-convolution kernels away.  Empty: two-term weights everywhere.
+    MIX_W2_SKIP = tuple(x for x in os.environ.get("VLFB_MIX_W2_SKIP", "").split(",") if x)
     MIX_NL_F32 = os.environ.get("VLFB_MIX_NL_F32", "1") != "0"
     # "mix" dtype: fp32 gradients on the DIRECT path of the head -- classifier, dropout, concat, RoIAlign + max, the temporal /
     # global average pool -- with one rounding to fp16 where the gradient enters res5 (PoolStep.bwd).  Those are five fp16
@@ -2229,7 +2236,16 @@ class Engine(object):
             self.flat_mom[off:off + cnt].view(shape).copy_(self._to_kernel_layout(name, arr).to(self.device))
 
     def _wprep_table(self, convs):
-        """device table for vlfb_weight_prep_batched over these conv steps: (tensor, items, tiles) or None"""
+        """device tables for vlfb_weight_prep_batched over these conv steps, one per operand format in use (one, unless
+        Engine.MIX_W2_SKIP mixes two-term and plain fp16 DGRAD copies): [(tensor, items, tiles, format), ...] or None"""
+        codes = []
+        for st in convs:
+            if st.wcode not in codes:
+                codes.append(st.wcode)
+        tabs = [t for t in (self._wprep_table_of([st for st in convs if st.wcode == c], c) for c in codes) if t is not None]
+        return tabs or None
+
+    def _wprep_table_of(self, convs, wcode):
         items, tile = [], 0
         for st in convs:
             cout, taps, cin = st.Cog, st.taps(), st.Cin_k
@@ -2247,7 +2263,7 @@ class Engine(object):
         arr = (hip.WPrepItem * len(items))(*items)
         raw = bytes(memoryview(arr))
         dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-        return (dev, len(items), tile)
+        return (dev, len(items), tile, wcode)
 
     def _build_wprep_tables(self):
         """device tables for vlfb_weight_prep_batched: all convs / only those with trainable weights"""
@@ -2261,9 +2277,8 @@ class Engine(object):
         if getattr(self, "_wprep", None) is None:
             self._build_wprep_tables()
         tab = self._wprep["all" if all_params else "trainable"]
-        if tab is not None:
-            dev, n, tiles = tab
-            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.wcode)
+        for dev, n, tiles, wcode in tab or ():
+            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, wcode)
         for st in self.steps:
             if isinstance(st, ConvStep) and st.eff_bias is not None and (all_params or st.params):
                 st.refresh_bias()
@@ -2570,9 +2585,8 @@ class Engine(object):
         S = self.loss_scale                       # gradients carry the fp16 loss scale: lr/S * (S g + S wd p)
         for off, end, wd in b["wd"]:
             self._sgd_launch(off, end, wd, lr)
-        if b["wprep"] is not None:
-            dev, n, tiles = b["wprep"]
-            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, self.wcode)
+        for dev, n, tiles, wcode in b["wprep"] or ():
+            hip.call("vlfb_weight_prep_batched", hip.ptr(dev), n, tiles, wcode)
         for st in b["bias_steps"]:
             st.refresh_bias()
 
