@@ -301,6 +301,12 @@ int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax
  * kt*kh*kw / (st*sh*sw) times less mask traffic. */
 int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax, const void* y, void* dx,
                           vlfb_stream_t stream);
+/* vlfb_maxpool_bwd for a TWO-TERM pooled gradient dy + dy_lo (16-bit dtypes: the "mix" path keeps a 16-bit gradient that is
+ * the sum of several conv DGRADs -- the input of a projection block, resnet_helper.py:86-119 -- as hi + lo, see
+ * vlfb_conv_args.O_lo): the terms are added in fp32 before the scatter, dx is rounded once.  y (may be NULL): the pooled
+ * forward values as the ReLU mask of the input, as in vlfb_maxpool_relu_bwd; add / mask as in vlfb_maxpool_bwd. */
+int vlfb_maxpool_bwd_lo(const vlfb_pool_desc* d, const void* dy, const void* dy_lo, const void* argmax, const void* y,
+                        void* dx, const void* add, const void* mask, vlfb_stream_t stream);
 /* average over the window (pad 0 only, as every AveragePool in the reference) */
 int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream);
 int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* dx, const void* add,

@@ -7,8 +7,8 @@ in float32 in the operator's own operation order, because the integer decisions 
 size, bilinear corner indices, the out-of-range predicate) must match the HIP kernel bit for bit.
 
 `roi_align_loop` is the literal scalar restatement; `roi_align_vec` is an independent vectorised
-one.  tests/test_oracle_roi.py requires them to agree exactly on every integer and to 1e-6 on
-values (SURVEY.md 8c iii).
+one.  tests/test_oracle.py::test_two_roialign_implementations_agree_bit_exactly requires them to
+agree exactly on every integer and to 1e-6 on values (SURVEY.md 8c iii).
 """
 import numpy as np
 

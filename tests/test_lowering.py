@@ -180,29 +180,52 @@ def test_every_shipped_config_plans_in_train_and_test_mode():
                 assert ("conv1_w" in eng.trainable) == (not frozen), (name, frozen)
 
 
-def test_fp32_head_switch_is_off_and_marks_the_direct_path_when_on(monkeypatch):
-    """Engine.MIX_HEAD_F32 (written at the end of round 4 without GPU time to validate it: default OFF): with the switch on,
-    the gradient slots of the head's direct path -- classifier input, dropout input, the RoI features, the pooled res5 map --
+def test_mix_keeps_fp32_gradients_on_the_direct_path_of_the_head():
+    """Engine._plan_head_f32 (validated on the GPU at full size in round 5 and made part of the `mix` dtype: no switch): the
+    gradient slots of the head's direct path -- classifier input, dropout input, the RoI features, the pooled res5 map --
     are fp32 and the FBO branch keeps fp16; the backbone is untouched"""
     from vlfb.engine import Engine
     small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64)
-    assert Engine.MIX_HEAD_F32 is False
-    cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype="mix")
-    assert eng.head_f32 == []
-    nl_f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32)      # (the non-local theta / phi / g slots)
-    monkeypatch.setattr(Engine, "MIX_HEAD_F32", True)
+    assert not hasattr(Engine, "MIX_HEAD_F32") and not hasattr(Engine, "MIX_W2_SKIP")     # no default-off parity switches
     cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype="mix")
     assert eng.head_f32 == ["pool5_dropout", "pool5", "roi_feat_1d", "blob_pooled"]
-    assert sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32) == sorted(nl_f32 + eng.head_f32)
+    f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32)
+    nl_f32 = [n for n in f32 if n.rsplit("_", 1)[-1] in ("theta", "phi", "g", "y")]        # (the non-local theta / phi / g / y slots)
+    assert f32 == sorted(nl_f32 + eng.head_f32)
     import torch
     for b in eng.all_blobs:
         if b.root is b and b.name in eng.head_f32:
             assert b.slot.buf.dtype == torch.float32 and not b.slot.two_term
     cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
     assert eng.head_f32 == ["pool5_dropout", "res5_2_branch2c_bn_pooled"]
-    for dtype in ("fp16", "split"):                       # a `mix` switch: nothing happens on the other paths
+    for dtype in ("fp16", "split"):                       # part of `mix`: nothing happens on the other paths
         cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype=dtype)
         assert eng.head_f32 == []
+
+
+def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_not_plan(monkeypatch):
+    """ConvStep._w2_geometry: a conv whose two-term DGRAD launch (doubled outermost tap dimension) the library refuses keeps a
+    plain fp16 DGRAD copy instead of failing the graph; every conv of the shipped widths is two-term.  (The refusal is
+    injected: the shipped widths all plan.)"""
+    from vlfb import hip
+    from vlfb.engine import ConvStep
+    small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64)
+    cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
+    convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.d_d is not None]
+    assert convs and all(s.w2 and s.wcode == hip.MIX_W2 for s in convs)
+    real = hip.conv_workspace_bytes
+
+    def refuse_some(d):
+        if d.mode == hip.DGRAD and d.kt == 2 and d.dt == 0 and d.Cn == 64:
+            raise hip.VlfbError("injected: the doubled-tap form of this conv does not plan")
+        return real(d)
+    monkeypatch.setattr(hip, "conv_workspace_bytes", refuse_some)
+    cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
+    convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.d_d is not None]
+    plain = [s for s in convs if not s.w2]
+    assert plain and all(s.d_d.Cn == 64 and s.wcode == hip.MIX and s.d_d.kt == s.k[0] and s.wd_npl == 1 for s in plain)
+    assert all(s.wcode == hip.MIX_W2 and s.wd_npl == 2 for s in convs if s.w2) and any(s.w2 for s in convs)
+    assert sorted({s.wcode for s in convs}) == sorted([hip.MIX, hip.MIX_W2])    # (one weight-prep batch per format: Engine._wprep_table)
 
 
 def test_product_code_never_imports_the_oracle():
@@ -248,16 +271,21 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert (a.d_d.kt, a.d_d.dt, a.d_d.kh, a.d_d.kw, a.d_d.ph) == (2, 0, 3, 1, 1)
     assert (a.d_d.Tr, a.d_d.Hr, a.d_d.Wr, a.d_d.Ts, a.d_d.Hs, a.d_d.Ws) == (1, T, H * W, 1, T, H * W)
     # fp32 gradients and split products around the non-local softmax
-    f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32)
-    assert len(f32) == 15 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g") for n in f32), f32
+    f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32 and b.name not in eng.head_f32)
+    assert len(f32) == 20 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g", "y") for n in f32), f32
+    oc = [c for c in convs.values() if c.wname == "nonlocal_conv4_1_out_w"][0]       # (fused with its AffineNd + Sum: named by the sum)
+    assert oc.dx_f32 and oc.d_d.out_dtype == hip.F32 and oc.x.root.slot.buf.dtype == torch.float32
     th = convs["nonlocal_conv4_1_theta"]
     assert th.bwd_f32 and (th.d_w.dtype, th.d_w.math, th.d_w.wgrad_bias) == (hip.F32, hip.MATH_BF16X3, 1)
     assert th.out.root.slot.buf.dtype == torch.float32
     att = [s for s in eng.steps if isinstance(s, AttentionStep) and not s.single][0]
     assert att.precise and not att.fused_bwd and (att.d_dp.dtype, att.d_dp.math) == (hip.F32, hip.MATH_BF16X3)
-    # the residual stream: the identity operands of the residual Sums
+    # the residual stream: the identity operands of the residual Sums (17), and every other 16-bit slot that is the sum of
+    # several conv DGRADs -- the inputs of the four projection blocks (pool1, pool2, the last blobs of res3 / res4), the pooled
+    # maps in front of phi / g (5), three blobs of the FBO head
     two = [b.name for b in eng.all_blobs if b.root is b and b.slot.two_term]
-    assert len(two) == 17 and "res2_0_branch2c_bn" in two and "nonlocal_conv4_3_sum" in two and "res5_2_branch2c_bn" not in two
+    assert len(two) == 29 and "res2_0_branch2c_bn" in two and "nonlocal_conv4_3_sum" in two and "res5_2_branch2c_bn" not in two
+    assert all(n in two for n in ("pool1", "pool2", "nonlocal_conv3_3_sum", "nonlocal_conv4_5_sum", "nonlocal_conv4_1_pool"))
     assert all(eng.env[n].root.slot.buf_lo is not None and eng.env[n].root.slot.buf.dtype == torch.float16 for n in two)
     # every launch has a plan; the table is a pure function of the descriptors (what bench.py and the plan test compare)
     table = eng.plan_table()

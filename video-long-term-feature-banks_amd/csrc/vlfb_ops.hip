@@ -314,7 +314,10 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 template <typename T, bool IS_MAX, typename IdxT>
 __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict__ argmax,
                                 T* dx, const T* add, const T* __restrict__ mask, PoolP p,
-                                float inv_window, const T* __restrict__ ymask = nullptr) {
+                                float inv_window, const T* __restrict__ ymask = nullptr,
+                                const T* __restrict__ dy_lo = nullptr) {
+  // dy_lo: low term of a two-term gradient (dy + dy_lo, the "mix" path's 16-bit slots that sum several conv DGRADs):
+  // added in fp32 before anything else, so the pooled gradient enters with ~22 bits instead of 11
   constexpr int V = Vec16<T>::N;
   const int cchunks = p.C / V;
   const long long total = (long long)p.N * p.Ti * p.Hi * p.Wi * cchunks;
@@ -345,6 +348,12 @@ __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict
           const long long o = (((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
           float g[V];
           Vec16<T>::load(dy + o * p.C + cc * V, g);
+          if (dy_lo) {
+            float gl[V];
+            Vec16<T>::load(dy_lo + o * p.C + cc * V, gl);
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] += gl[k];
+          }
           if (IS_MAX && ymask) {
             // max-pool of a ReLU output: the selected element IS the pooled value, so "the input passed its
             // ReLU" can be read from the (window-times smaller) pooled tensor instead of the input
@@ -414,10 +423,11 @@ __device__ __forceinline__ void unpack_vec(const uint4& t, float (&v)[Vec16<T>::
   }
 }
 
-template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, bool YMASK>
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, bool YMASK, bool LO = false>
 __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
                                                                 T* dx, const T* add, const T* __restrict__ mask, PoolP p,
-                                                                const T* __restrict__ ymask) {
+                                                                const T* __restrict__ ymask, const T* __restrict__ dy_lo = nullptr) {
+  // LO: dy_lo holds the low term of a two-term gradient (see pool_bwd_kernel)
   constexpr int V = Vec16<T>::N;
   constexpr int CT = (KT + ST - 1) / ST, CH = (KH + SH - 1) / SH, CW = (KW + SW - 1) / SW;
   const int cchunks = p.C / V;
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
         const int ho = ho_hi - jh, b = hi + p.ph - ho * SH;
         if (ho < 0 || ho >= p.Ho || b >= KH) continue;
         const int orow = ((n * p.To + to) * p.Ho + ho) * p.Wo;
-        uint4 gq[CW], yq[CW];
+        uint4 gq[CW], yq[CW], lq[LO ? CW : 1];
         uint2 aq[CW];
         int tapq[CW];
 #pragma unroll
@@ -468,6 +478,7 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
           const bool ok = wo >= 0 && wo < p.Wo && c < KW;
           const long long o = ok ? (long long)(orow + wo) * p.C + cc * V : (long long)(cc * V);
           tapq[jw] = ok ? (a * KH + b) * KW + c : 255;
+          if (LO) lq[LO ? jw : 0] = *reinterpret_cast<const uint4*>(dy_lo + o);
           if (sizeof(T) == 2) {
             gq[jw] = *reinterpret_cast<const uint4*>(dy + o);
             if (YMASK) yq[jw] = *reinterpret_cast<const uint4*>(ymask + o);
@@ -482,6 +493,12 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
         for (int jw = 0; jw < CW; ++jw) {
           float g[V];
           unpack_vec<T>(gq[jw], g);
+          if (LO) {
+            float gl[V];
+            unpack_vec<T>(lq[LO ? jw : 0], gl);
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] += gl[k];
+          }
           if (YMASK) {
             float yv[V];
             unpack_vec<T>(yq[jw], yv);
@@ -633,13 +650,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_band_kernel(const T* __restri
 // launches the fixed-shape kernel when the window is one of the compiled shapes (one-byte arg-max); false = use the generic one
 template <typename T>
 bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax, void* dx, const void* add, const void* mask,
-                              const void* ymask, hipStream_t s) {
+                              const void* ymask, hipStream_t s, const void* dy_lo = nullptr) {
   const long long rows = (long long)p.N * p.Ti * p.Hi;
   if (rows >= (1ll << 31) || (long long)p.N * p.To * p.Ho * p.Wo >= (1ll << 31)) return false;
   const dim3 grid((unsigned)rows), block(128);
   // (with a residual operand and a ReLU mask streamed beside it the row kernel is the faster one: 271 vs 357 us)
   if (p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 2 && p.sw == 2 && p.pt == 0 && p.To == p.Ti && !add &&
-      !mask) {
+      !mask && !dy_lo) {        // (a two-term gradient would double the staged rows: it takes the row kernel)
     // band kernel: as many input-row pairs per workgroup as 64 KB of LDS hold pooled rows for (R + 2 rows staged)
     const long long row_bytes = (long long)p.Wo * p.C * (sizeof(T) + 1);
     // R = 3: measured 226 us at R = 2 and 3, 259 us at R = 4 (two 64 KB workgroups per CU leave the load and the store
@@ -662,6 +679,20 @@ bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax
   }
 #define VLFB_POOL_FIXED(KT_, KH_, KW_, ST_, SH_, SW_)                                                                      \
   if (p.kt == KT_ && p.kh == KH_ && p.kw == KW_ && p.st == ST_ && p.sh == SH_ && p.sw == SW_) {                           \
+    if (dy_lo) {                                                                                                         \
+      if constexpr (sizeof(T) == 2) {                                                                                    \
+        if (ymask)                                                                                                       \
+          hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, true, true>), grid, block, 0, s, \
+                             (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p,             \
+                             (const T*)ymask, (const T*)dy_lo);                                                          \
+        else                                                                                                             \
+          hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, false, true>), grid, block, 0, s,\
+                             (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p,             \
+                             (const T*)ymask, (const T*)dy_lo);                                                          \
+        return true;                                                                                                     \
+      }                                                                                                                  \
+      return false;                                                                                                      \
+    }                                                                                                                    \
     if (ymask)                                                                                                           \
       hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, true>), grid, block, 0, s,           \
                          (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p, (const T*)ymask); \
@@ -1218,6 +1249,26 @@ extern "C" int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, co
   else
     VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)nullptr, (const T16*)nullptr, p, 1.f, (const T16*)y));
   return check_launch("maxpool_relu_bwd");
+}
+extern "C" int vlfb_maxpool_bwd_lo(const vlfb_pool_desc* d, const void* dy, const void* dy_lo, const void* argmax,
+                                   const void* y, void* dx, const void* add, const void* mask, vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(dy && dy_lo && argmax && dx, "maxpool_bwd_lo: null pointer");
+  VLFB_REQUIRE(d->dtype == VLFB_F16 || d->dtype == VLFB_BF16, "maxpool_bwd_lo: two-term gradients are 16-bit");
+  PoolP p = to_poolp(d);
+  const bool wide = vlfb_pool_argmax_bytes(d) == 2;
+  int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / 8), 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (!wide) {
+    bool done;
+    VLFB_WITH_T16(d->dtype, done = launch_maxpool_bwd_fixed<T16>(p, dy, argmax, dx, add, mask, y, s, dy_lo));
+    if (done) return check_launch("maxpool_bwd_lo (fixed window)");
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint8_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f, (const T16*)y, (const T16*)dy_lo));
+  } else {
+    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f, (const T16*)y, (const T16*)dy_lo));
+  }
+  return check_launch("maxpool_bwd_lo");
 }
 extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream) {
   int rc = check_pool(d);

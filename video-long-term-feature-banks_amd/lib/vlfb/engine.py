@@ -225,7 +225,7 @@ class Step(object):
     def out_grad(self, i=0):
         return self.outputs[i].root.slot.value()
 
-    # "mix" dtype, Engine.MIX_HEAD_F32: a step of the head may find its output gradient and / or the slot it contributes to in
+    # "mix" dtype (Engine._plan_head_f32): a step of the head may find its output gradient and / or the slot it contributes to in
     # fp32 (Blob.grad_f32).  It computes in the dtype of the slot it WRITES; an incoming gradient of the other dtype goes
     # through a private buffer (fp32 -> fp16 is the one rounding where the gradient re-enters the fp16 backward).
     def gcode(self, blob):
@@ -283,6 +283,7 @@ class ConvStep(Step):
         ld_f = dict(lda=Cin, ldo=Cout, ldr=Cout) if G > 1 else {}
         ld_d = dict(lda=Cout, ldo=Cin, ldr=Cin) if G > 1 else {}
         ld_w = dict(lda=Cin, ldp=Cout) if G > 1 else {}
+        self._ld_d = ld_d
         self.pack = 8 if self.stem else 0
         code, bcode = eng.code, eng.bcode
         geom = self._geom()
@@ -317,23 +318,16 @@ class ConvStep(Step):
             dg = dict(geom)
             alpha = 1.0 / self.gscale
             rows = dict(N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo)
-            if eng.mix and eng.MIX_W2 and not self.wname.startswith(eng.MIX_W2_SKIP or ("\0",)):
-                # two-term fp16 weights (hip.MIX_W2): the same convolution with a doubled OUTERMOST tap dimension of
-                # dilation 0, i.e. every tap is contracted with Wh and with Wl by the plain fp16 DGRAD kernels
-                k_, s_, p_, d_ = self.k, self.s, self.p, self.d
-                if k_[0] == 1:
-                    dg.update(kt=2, dt=0)
-                else:
-                    # k x 1 x 1 (the first conv of a bottleneck): T plays the role of H, H x W are one pointwise axis,
-                    # and the (size-1) T axis carries the term dimension
-                    assert k_[1] == 1 and k_[2] == 1 and tuple(s_) == (1, 1, 1) and p_[1] == 0 and p_[2] == 0, \
-                        "MIX_W2: unexpected conv geometry %r / %r / %r" % (k_, s_, p_)
-                    dg.update(kt=2, kh=k_[0], kw=1, st=1, sh=1, sw=1, pt=0, ph=p_[0], pw=0, dt=0, dh=d_[0], dw=1)
-                    rows = dict(N=N, Tr=1, Hr=T, Wr=H * W, Ts=1, Hs=To, Ws=Ho * Wo)
+            w2 = self._w2_geometry(dg, rows) if (eng.mix and eng.MIX_W2) else None
+            if w2 is not None:
+                dg, rows = w2
                 alpha /= hip.MIX_W2_SCALE
                 self.w2 = True
-            self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=bcode, Cs=self.Cog, Cn=Cin // G, alpha=alpha, math=mb,
-                                     **rows, **bplanes, **dg, **ld_d)
+            # ("mix": an input whose gradient slot is fp32 -- box_pooled, the attention output of a non-local block -- gets
+            # the fp32 accumulators of the fp16 DGRAD as they are, not their fp16 rounding)
+            self.dx_f32 = bool(eng.mix and self.x.root.grad_f32)
+            self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=hip.F32 if self.dx_f32 else bcode, Cs=self.Cog,
+                                     Cn=Cin // G, alpha=alpha, math=mb, **rows, **bplanes, **dg, **ld_d)
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
@@ -390,13 +384,41 @@ class ConvStep(Step):
         self.wf_npl = 3 if eng.split else 1
         self.wd_npl = (2 if self.w2 else 1) if eng.mix else (2 if eng.split else 1)
         # the format vlfb_weight_prep writes this conv's operand copies in ("mix": two-term or plain fp16 DGRAD copy, per conv --
-        # Engine.MIX_W2_SKIP; a conv without a DGRAD copy goes with the engine's default)
+        # ConvStep._w2_geometry; a conv without a DGRAD copy goes with the engine's default)
         self.wcode = eng.wcode if not eng.mix else (hip.MIX if (self.w_d is not None and not self.w2) else eng.wcode)
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
         if self.cbname and eng.is_trainable(self.cbname):
             self.cb_tmp = torch.empty(Cout, device=eng.device, dtype=torch.float32)
+
+    def _w2_geometry(self, dg, rows):
+        """"mix", two-term fp16 DGRAD weights (hip.MIX_W2): the same convolution with a doubled OUTERMOST tap dimension of
+        dilation 0, i.e. every tap is contracted with Wh and with Wl by the plain fp16 DGRAD kernels.  Returns (geometry,
+        row dims) of that launch, or None when the doubled-tap form of THIS conv is not one the library plans (a k x 1 x 1
+        conv that is strided / padded in H, W, a channel count the gathered kernels refuse, ...): the conv then keeps a
+        plain fp16 DGRAD copy (11-bit weights) instead of failing the whole graph."""
+        eng = self.eng
+        k_, s_, p_, d_ = self.k, self.s, self.p, self.d
+        N, _, T, H, W = self.x.shape
+        _, _, To, Ho, Wo = self.out.shape
+        dg = dict(dg)
+        if k_[0] == 1:
+            dg.update(kt=2, dt=0)
+        elif k_[1] == 1 and k_[2] == 1 and tuple(s_) == (1, 1, 1) and p_[1] == 0 and p_[2] == 0:
+            # k x 1 x 1 (the first conv of a bottleneck): T plays the role of H, H x W are one pointwise axis,
+            # and the (size-1) T axis carries the term dimension
+            dg.update(kt=2, kh=k_[0], kw=1, st=1, sh=1, sw=1, pt=0, ph=p_[0], pw=0, dt=0, dh=d_[0], dw=1)
+            rows = dict(N=N, Tr=1, Hr=T, Wr=H * W, Ts=1, Hs=To, Ws=Ho * Wo)
+        else:
+            return None
+        probe = hip.conv_desc(mode=hip.DGRAD, dtype=eng.bcode, out_dtype=eng.bcode, Cs=self.Cog, Cn=self.Cin_k,
+                              alpha=1.0, math=hip.MATH_NATIVE, **rows, **dg, **self._ld_d)
+        try:
+            hip.conv_workspace_bytes(probe)        # (the planner is a pure host function of the descriptor)
+        except hip.VlfbError:
+            return None
+        return dg, rows
 
     def has_bias(self):
         return bool(self.cbname or self.bname)
@@ -499,17 +521,11 @@ class ConvStep(Step):
             # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
             eng.issue_param_grads(lambda: self._param_grads(g_w, gp))
         if self.d_d is not None and eng.mix and self.x.root.grad_f32:
-            # Engine.MIX_HEAD_F32: the input's gradient slot is fp32 (box_pooled).  The fp16 DGRAD runs as it is into a private
-            # fp16 buffer and is widened into the slot (GradSlot adds it to what is there in fp32).
-            assert self.group == 1
-            n = self.x.numel
-            if getattr(self, "_dx16", None) is None:
-                self._dx16 = torch.empty(n, device=eng.device, dtype=eng.btdtype)
-
-            def dgrad32(out, add, mask):
-                hip.conv_run(self.d_d, g, self.w_d, None, self._dx16)
-                hip.call("vlfb_cast", hip.ptr(self._dx16), eng.bcode, hip.ptr(out), hip.F32, n)
-            self.x.root.slot.contribute(dgrad32, supports_add=False, supports_mask=False)
+            # (Engine._plan_head_f32, AttentionStep) the input's gradient slot is fp32: the fp16 DGRAD writes its fp32
+            # accumulators there (out_dtype F32; GradSlot adds an earlier contribution in fp32)
+            assert self.group == 1 and self.dx_f32
+            self.x.root.slot.contribute(lambda out, add, mask: hip.conv_run(self.d_d, g, self.w_d, None, out),
+                                        supports_add=False, supports_mask=False)
         elif self.d_d is not None:
             # the gradient operand as planes when it has them and this launch can take them (plain rows or taps that
             # span whole k-tiles at unit stride); the input gradient's planes when this is its last contribution
@@ -610,8 +626,17 @@ class PoolStep(Step):
     def bwd(self):
         if not self.grad_inputs():
             return
-        g = self.g_as(self.out_grad(), self.out, self.x)      # (MIX_HEAD_F32: where the head's fp32 gradient re-enters fp16)
-        if self.is_max:
+        g = self.g_as(self.out_grad(), self.out, self.x)      # ("mix": where the head's fp32 gradient re-enters fp16)
+        g_lo = self.out.root.slot.value_lo() if self.is_max else None
+        if g_lo is not None:
+            # a two-term pooled gradient (pool1 / pool2 in front of a projection block: GradSlot.two_term): hi + lo are added
+            # in fp32 inside the kernel, the input gradient is rounded once
+            def fn(out, add, mask):
+                relu_of_input = mask is not None and add is None
+                hip.call("vlfb_maxpool_bwd_lo", C.byref(self.desc_b), hip.ptr(g), hip.ptr(g_lo), hip.ptr(self.argmax),
+                         self.out.bptr() if relu_of_input else None, hip.ptr(out), hip.ptr(add),
+                         None if relu_of_input else hip.ptr(mask))
+        elif self.is_max:
             def fn(out, add, mask):
                 if mask is not None and add is None:
                     # sole consumer of a ReLU output: the mask is `pooled value > 0` (see vlfb_maxpool_relu_bwd)
@@ -710,7 +735,8 @@ class AttentionStep(Step):
                                  o_bstride=L1 * L2, math=mb, alpha=self.ds_scale / L2, **bpl)
         if not (self.fused_fwd and self.fused_bwd):
             eng.need_scratch_f32(B * L1 * L2 + (B * L1 * Ci if self.precise else 0))
-        eng.need_scratch_act(B * L1 * L2 + B * Ci * L2)
+        self.dy_f32 = bool(self.out.root.grad_f32)         # ("mix": dY arrives in fp32; the fp16 products read a cast)
+        eng.need_scratch_act(B * L1 * L2 + B * Ci * L2 + (B * L1 * Ci if self.dy_f32 else 0))
 
     def _planes(self, src, nplanes, transpose):
         """bf16 term planes of a (B, L2, Ci) fp32 activation (optionally transposed per batch element): the B
@@ -764,6 +790,12 @@ class AttentionStep(Step):
                      eng.bcode, B, L2, Ci, Ci, self.scale)
             return
         P = self.prob.bstorage()
+        dY32 = None
+        if self.dy_f32:
+            # fp32 dY (the `out` conv's DGRAD accumulators): the split product dP reads it as it is, the fp16 products a cast
+            dY32 = dY
+            dY = eng.scratch_act(B * L1 * L2 + B * Ci * L2 + B * L1 * Ci)[B * L1 * L2 + B * Ci * L2:]
+            hip.call("vlfb_cast", hip.ptr(dY32), hip.F32, hip.ptr(dY), eng.bcode, B * L1 * Ci)
         if self.dot:
             # dot-product variant: dS = dP / L2 is the scores-gradient product itself (alpha), no softmax Jacobian
             gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
@@ -772,8 +804,10 @@ class AttentionStep(Step):
             dS, phT = act[:B * L1 * L2], act[B * L1 * L2:]
             if self.precise:
                 f32 = eng.scratch_f32(B * L1 * L2 + B * L1 * Ci)
-                dP, dY32 = f32[:B * L1 * L2], f32[B * L1 * L2:]
-                hip.call("vlfb_cast", hip.ptr(dY), eng.bcode, hip.ptr(dY32), hip.F32, B * L1 * Ci)
+                dP = f32[:B * L1 * L2]
+                if dY32 is None:
+                    dY32 = f32[B * L1 * L2:]
+                    hip.call("vlfb_cast", hip.ptr(dY), eng.bcode, hip.ptr(dY32), hip.F32, B * L1 * Ci)
                 hip.conv_run(self.d_dp, dY32, self._planes(self.g.storage(), 2, False), None, dP)
                 hip.call("vlfb_cast", hip.ptr(dP), hip.F32, hip.ptr(dS), eng.bcode, B * L1 * L2)
             else:
@@ -789,8 +823,10 @@ class AttentionStep(Step):
             return
         if self.precise:
             f32 = eng.scratch_f32(B * L1 * L2 + B * L1 * Ci)
-            dP, dY32 = f32[:B * L1 * L2], f32[B * L1 * L2:]
-            hip.call("vlfb_cast", hip.ptr(dY), eng.bcode, hip.ptr(dY32), hip.F32, B * L1 * Ci)
+            dP = f32[:B * L1 * L2]
+            if dY32 is None:
+                dY32 = f32[B * L1 * L2:]
+                hip.call("vlfb_cast", hip.ptr(dY), eng.bcode, hip.ptr(dY32), hip.F32, B * L1 * Ci)
             hip.conv_run(self.d_dp, dY32, self._planes(self.g.storage(), 2, False), None, dP)
         elif not self.fused_bwd:
             dP = eng.scratch_f32(B * L1 * L2)
@@ -1059,7 +1095,7 @@ class ConcatStep(Step):
                                                                   hip.ptr(out), p.C, gc, self.rows, p.C),
                         supports_add=False, supports_mask=False)
                 else:
-                    # (MIX_HEAD_F32: a part whose producer keeps an fp16 gradient below an fp32 concat gradient, or the reverse)
+                    # ("mix", fp32 head: a part whose producer keeps an fp16 gradient below an fp32 concat gradient, or the reverse)
                     key = "_part%d" % k
                     if getattr(self, key, None) is None:
                         setattr(self, key, torch.empty(self.rows * p.C, device=self.eng.device, dtype=g.dtype))
@@ -1101,7 +1137,7 @@ class FCStep(Step):
         train = eng.is_trainable(self.wname)
         dw = eng.grad_tensor(self.wname) if train else None
         db = eng.grad_tensor(self.bname) if train else None
-        f32 = bool(eng.mix and self.x.root.grad_f32)          # (MIX_HEAD_F32: fp32 input values and an fp32 input gradient)
+        f32 = bool(eng.mix and self.x.root.grad_f32)          # ("mix", fp32 head: fp32 input values and an fp32 input gradient)
         xp, xc = (self.x.ptr(), eng.code) if f32 else (self.x.bptr(), eng.bcode)
         if dw is not None:
             hip.call("vlfb_fc_bwd", xp, xc, hip.ptr(w), hip.ptr(dl), None, hip.ptr(dw), hip.ptr(db),
@@ -1506,6 +1542,12 @@ class Lowering(object):
         prob = self.new_blob(prob_name, (B, L1, L2), 2, "f32" if single else "act")
         out = self.new_blob(mm.outputs[0], (B, Ci, L1), 1)
         out.needs_grad = True
+        if not single and self.eng.mix and self.eng.MIX_NL_F32:
+            # ... and so does the gradient of the attention output: dP = dY . g^T feeds the softmax Jacobian, whose
+            # cancellation amplifies the 11-bit rounding of a stored fp16 dY into the theta / phi weight gradients (they
+            # moved between 2e-4 and 9e-4 from one rounding pattern to the next).  The `out` conv's fp16 DGRAD writes its
+            # fp32 accumulators (ConvStep.dx_f32).
+            out.root.grad_f32 = True
         assert not (dot and single), "the dot-product variant belongs to the space-time non-local block"
         self.add_step(AttentionStep(self.eng, theta, phi, g, prob, out, scale, dot=dot))
         self.env[prob_name] = prob
@@ -1739,18 +1781,7 @@ class Engine(object):
     MIX_W2 = os.environ.get("VLFB_MIX_W2", "1") != "0"
     # "mix" dtype: gradients of theta / phi / g of the non-local blocks in fp32, their weight gradients and the dP product of
     # the attention backward as split-bf16 products, the softmax backward on the fp32 probabilities
-    # "mix" dtype: parameter-name prefixes whose convs keep PLAIN fp16 DGRAD weights although MIX_W2 is on (e.g. "res2,res3").
-    # The emulation says the two-term weights can go in res2 (+ res3) once the head is fp32; res2 is where they
-    # cost most, because they take the streaming and direct-convolution kernels away.  Empty: two-term weights everywhere.
-    MIX_W2_SKIP = tuple(x for x in os.environ.get("VLFB_MIX_W2_SKIP", "").split(",") if x)
     MIX_NL_F32 = os.environ.get("VLFB_MIX_NL_F32", "1") != "0"
-    # "mix" dtype: fp32 gradients on the DIRECT path of the head -- classifier, dropout, concat, RoIAlign + max, the temporal /
-    # global average pool -- with one rounding to fp16 where the gradient enters res5 (PoolStep.bwd).  Those are five fp16
-    # storages in series whose error is common to every backbone gradient; the CPU emulation attributes the median error of
-    # `mix` to them ("Located: it is the HEAD").  OFF: written with 16 s of GPU time left in round 4 -- it
-    # executes and moves the gradients by a median 4.3e-4 (scratch/r4/head_f32_try.py); enable, run
-    # tests/test_model_gpu.py::test_full_size_clip_matches_oracle and compare with the emulation before making it default.
-    MIX_HEAD_F32 = os.environ.get("VLFB_MIX_HEAD_F32", "0") == "1"
     # "mix" dtype: the residual-stream gradient as two fp16 terms (GradSlot.two_term)
     MIX_TRUNK2 = os.environ.get("VLFB_MIX_TRUNK2", "1") != "0"
     # "split" dtype: conv epilogues also write the bf16 term planes of their outputs / input gradients, and the DGRAD / WGRAD
@@ -1959,12 +1990,15 @@ class Engine(object):
         return self
 
     def _plan_head_f32(self):
-        """Engine.MIX_HEAD_F32: mark the blobs of the head's direct path whose gradient stays in fp32 (Blob.grad_f32).  Walk
-        back from the classifier's input through dropout / concat / RoIAlign + max; the output of the average pool that reads
-        res5 is the last one (its PoolStep casts down).  A blob is only marked when every step that contributes to its
-        gradient can write fp32."""
+        """"mix" dtype: fp32 gradients on the DIRECT path of the head -- classifier, dropout, concat, RoIAlign + max, the
+        temporal / global average pool -- with one rounding to fp16 where the gradient enters res5 (PoolStep.bwd).  Those
+        were five fp16 storages in series whose error is common to EVERY backbone gradient (measured at full size, round 5:
+        identical-decisions median 4.0e-4 -> 3.0e-4, second-worst tensor 9.6e-4 -> 6.9e-4, at the same clips/s).  Marks the
+        blobs whose gradient stays in fp32 (Blob.grad_f32): walk back from the classifier's input through dropout / concat /
+        RoIAlign + max; the output of the average pool that reads res5 is the last one (its PoolStep casts down).  A blob
+        is only marked when every step that contributes to its gradient can write fp32."""
         self.head_f32 = []
-        if not (self.train and self.mix and self.MIX_HEAD_F32):
+        if not (self.train and self.mix):
             return
         fcs = [st for st in self.steps if isinstance(st, FCStep)]
         if len(fcs) != 1:
@@ -2118,6 +2152,17 @@ class Engine(object):
                     r = st.residual.root
                     if r.kind == "act" and not r.grad_f32 and r.slot.expected > 1:
                         r.slot.two_term = True
+            # ... and the INPUT of a block with a projection shortcut (pool1, pool2, the last blob of res3 / res4): there is no
+            # identity operand, the whole gradient is the sum of two conv DGRADs (branch1, branch2a).  Stored as one fp16
+            # value it was rounded twice at full magnitude (the first contribution on its own, then the sum) -- the
+            # error profile of the trunk gradient along the backward chain (scratch/r5/diag_mix.py, full-size clip) grows
+            # by as much across each of these four blobs as across all identity blocks of a stage together.  The DGRAD
+            # epilogues write hi + lo for nothing but the 2 B / element of the second store.
+            for st in self.bwd_steps:
+                if isinstance(st, ConvStep) and st.x.needs_grad and not st.x.detached:
+                    r = st.x.root
+                    if r.kind == "act" and not r.grad_f32 and r.slot.expected > 1 and r.grad_scale == 1.0:
+                        r.slot.two_term = True
 
     def _allocate(self):
         dev = self.device
@@ -2236,8 +2281,8 @@ class Engine(object):
             self.flat_mom[off:off + cnt].view(shape).copy_(self._to_kernel_layout(name, arr).to(self.device))
 
     def _wprep_table(self, convs):
-        """device tables for vlfb_weight_prep_batched over these conv steps, one per operand format in use (one, unless
-        Engine.MIX_W2_SKIP mixes two-term and plain fp16 DGRAD copies): [(tensor, items, tiles, format), ...] or None"""
+        """device tables for vlfb_weight_prep_batched over these conv steps, one per operand format in use ("mix": two-term fp16
+        DGRAD copies, and plain ones for the convs whose doubled-tap form the library does not plan): [(tensor, items, tiles, format), ...] or None"""
         codes = []
         for st in convs:
             if st.wcode not in codes:
