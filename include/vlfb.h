@@ -301,16 +301,17 @@ int vlfb_maxpool_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax
  * kt*kh*kw / (st*sh*sw) times less mask traffic. */
 int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, const void* argmax, const void* y, void* dx,
                           vlfb_stream_t stream);
-/* vlfb_maxpool_bwd for a TWO-TERM pooled gradient dy + dy_lo (16-bit dtypes: the "mix" path keeps a 16-bit gradient that is
- * the sum of several conv DGRADs -- the input of a projection block, resnet_helper.py:86-119 -- as hi + lo, see
- * vlfb_conv_args.O_lo): the terms are added in fp32 before the scatter, dx is rounded once.  y (may be NULL): the pooled
- * forward values as the ReLU mask of the input, as in vlfb_maxpool_relu_bwd; add / mask as in vlfb_maxpool_bwd. */
-int vlfb_maxpool_bwd_lo(const vlfb_pool_desc* d, const void* dy, const void* dy_lo, const void* argmax, const void* y,
-                        void* dx, const void* add, const void* mask, vlfb_stream_t stream);
 /* average over the window (pad 0 only, as every AveragePool in the reference) */
 int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream);
 int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* dx, const void* add,
                      const void* mask, vlfb_stream_t stream);
+
+/* The average-pool backward from an fp32 pooled gradient dy into a TWO-TERM 16-bit input gradient (d->dtype = VLFB_F16 /
+ * VLFB_BF16): dx = (mask > 0 ? sum dy / window : 0), dx_hi = round(dx), dx_lo = round(dx - dx_hi) -- see vlfb_conv_args.O_lo.
+ * Where the "mix" path's fp32 head gradient (head_helper.py:37-40, 92-98: the pools over res5) re-enters the 16-bit backward:
+ * every position of a channel receives the same value, so a one-term rounding is an error common to all positions. */
+int vlfb_avgpool_bwd_two_term(const vlfb_pool_desc* d, const float* dy, void* dx_hi, void* dx_lo, const void* mask,
+                              vlfb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row softmax with pre-scale: P[r][:] = softmax(scale * S[r][:]).

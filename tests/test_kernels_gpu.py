@@ -322,56 +322,6 @@ def test_maxpool_fwd_bwd(name, dtype):
     assert torch.equal(D1, D2) and float(D1.float().abs().sum()) > 0
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name", sorted(POOLS))
-def test_maxpool_bwd_of_a_two_term_gradient(name, dtype):
-    """vlfb_maxpool_bwd_lo: dy + dy_lo are added in fp32 before the scatter and the result is rounded ONCE -- against the
-    fp64 pool backward of the 22-bit gradient (error of one 16-bit rounding of the OUTPUT, an order below what the hi term
-    alone gives), with a residual + mask and with the ReLU mask read from the pooled values; a zero low term reproduces
-    vlfb_maxpool_bwd / vlfb_maxpool_relu_bwd bit for bit (every window family: fixed rows, generic)"""
-    import ctypes as C
-    k, s, p, (N, T, H, W) = POOLS[name]
-    Cc = 16
-    gen = torch.Generator().manual_seed(12)
-    code = hip.dtype_code(dtype)
-    x = torch.relu(q(torch.randn(N, Cc, T, H, W, generator=gen), dtype))
-    xd = x.double().requires_grad_(True)
-    y_ref = F.max_pool3d(xd, k, s, p)
-    To, Ho, Wo = y_ref.shape[2:]
-    X = gpu(to_nthwc(x), dtype)
-    Y = torch.empty(N, To, Ho, Wo, Cc, device=dev(), dtype=dtype)
-    AM = torch.empty(N, To, Ho, Wo, Cc, device=dev(), dtype=torch.uint8)
-    d = hip.pool_desc(code, N, T, H, W, Cc, To, Ho, Wo, k, s, p)
-    hip.call("vlfb_maxpool_fwd", C.byref(d), hip.ptr(X), hip.ptr(Y), hip.ptr(AM))
-    g = torch.randn(N, Cc, To, Ho, Wo, generator=gen)
-    hi = q(g, dtype)
-    lo = q(g - hi.float(), dtype)
-    g2 = hi.double() + lo.double()
-    (gx,) = torch.autograd.grad(y_ref, (xd,), g2)
-    HI, LO = gpu(to_nthwc(hi), dtype), gpu(to_nthwc(lo), dtype)
-    DX, D1 = (torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype) for _ in range(2))
-    # (a) ReLU mask from the pooled values
-    hip.call("vlfb_maxpool_bwd_lo", C.byref(d), hip.ptr(HI), hip.ptr(LO), hip.ptr(AM), hip.ptr(Y), hip.ptr(DX), None, None)
-    ref = torch.where(x.double() > 0, gx, torch.zeros_like(gx))
-    e2 = rel_err(to_ncthw(DX.float()), ref)
-    hip.call("vlfb_maxpool_relu_bwd", C.byref(d), hip.ptr(HI), hip.ptr(AM), hip.ptr(Y), hip.ptr(D1))
-    e1 = rel_err(to_ncthw(D1.float()), ref)
-    assert e2 < TOL[dtype] and e2 <= e1 * 1.0001, (e1, e2)
-    # (b) residual operand + explicit mask
-    add = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
-    ADD = gpu(to_nthwc(add), dtype)
-    hip.call("vlfb_maxpool_bwd_lo", C.byref(d), hip.ptr(HI), hip.ptr(LO), hip.ptr(AM), None, hip.ptr(DX), hip.ptr(ADD), hip.ptr(X))
-    ref = torch.where(x.double() > 0, gx + add.double(), torch.zeros_like(gx))
-    assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
-    # (c) a zero low term is the one-term backward, bit for bit
-    Z = torch.zeros_like(LO)
-    hip.call("vlfb_maxpool_bwd_lo", C.byref(d), hip.ptr(HI), hip.ptr(Z), hip.ptr(AM), hip.ptr(Y), hip.ptr(DX), None, None)
-    assert torch.equal(DX, D1)
-    hip.call("vlfb_maxpool_bwd_lo", C.byref(d), hip.ptr(HI), hip.ptr(Z), hip.ptr(AM), None, hip.ptr(DX), hip.ptr(ADD), hip.ptr(X))
-    hip.call("vlfb_maxpool_bwd", C.byref(d), hip.ptr(HI), hip.ptr(AM), hip.ptr(D1), hip.ptr(ADD), hip.ptr(X))
-    assert torch.equal(DX, D1)
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_global_and_temporal(dtype):
     import ctypes as C

@@ -187,12 +187,24 @@ def test_mix_keeps_fp32_gradients_on_the_direct_path_of_the_head():
     from vlfb.engine import Engine
     small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64)
     assert not hasattr(Engine, "MIX_HEAD_F32") and not hasattr(Engine, "MIX_W2_SKIP")     # no default-off parity switches
+    import torch
     cfg, m, eng = plan("ava_r50_lfb_nl", small, dtype="mix")
     assert eng.head_f32 == ["pool5_dropout", "pool5", "roi_feat_1d", "blob_pooled"]
     f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32)
-    nl_f32 = [n for n in f32 if n.rsplit("_", 1)[-1] in ("theta", "phi", "g", "y")]        # (the non-local theta / phi / g / y slots)
-    assert f32 == sorted(nl_f32 + eng.head_f32)
-    import torch
+    nl_f32 = [n for n in f32 if n.startswith("nonlocal_") and n.rsplit("_", 1)[-1] in ("theta", "phi", "g", "y")]
+    fbo = eng.head_f32_fbo                              # the FBO branch between the concat and box_pooled: all of it, in fp32
+    assert len(fbo) == 22 and all(n.startswith(("lfb_", "box_pooled_fbonl_")) for n in fbo)
+    assert f32 == sorted(nl_f32 + eng.head_f32 + fbo)
+    from vlfb.engine import ConvStep
+    from vlfb import hip
+    convs = {s.wname: s for s in eng.steps if isinstance(s, ConvStep)}
+    th = convs["lfb_nl0_theta_w"]                       # a conv between fp32 slots: the `split` backward, bf16 term planes of W
+    assert th.bwd_split and not th.w2 and th.wcode == hip.SPLIT and th.w_d.dtype == torch.bfloat16
+    assert (th.d_d.dtype, th.d_d.out_dtype, th.d_d.math) == (hip.F32, hip.F32, hip.MATH_BF16X3)
+    assert (th.d_w.dtype, th.d_w.math) == (hip.F32, hip.MATH_BF16X3)
+    bank = convs["lfb_1x1_w"]                           # reads the fed bank: no DGRAD, the split WGRAD on fp32 operands
+    assert bank.d_d is None and bank.bwd_f32 and not bank.bwd_split
+    assert not convs["res5_2_branch2c_w"].bwd_split and convs["res5_2_branch2c_w"].w2
     for b in eng.all_blobs:
         if b.root is b and b.name in eng.head_f32:
             assert b.slot.buf.dtype == torch.float32 and not b.slot.two_term
@@ -258,7 +270,7 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     for b in halves:
         assert (id(b) in by_conv) + (id(b) in posted) + (id(b) in fed) == 1, b.name
         assert b.half.dtype == torch.float16 and b.half.numel() == b.tensor.numel()
-    assert sorted(b.name for b in eng._half_inputs) == ["data_train", "lfb_train"]
+    assert sorted(b.name for b in eng._half_inputs) == ["data_train"]     # (the bank is read by fp32 steps only: the FBO head)
     convs = {s.out.name: s for s in eng.steps if isinstance(s, ConvStep)}
     c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
     assert (c.d_f.dtype, c.d_f.math, c.d_f.kt) == (hip.F32, hip.MATH_BF16X3, 1)
@@ -271,7 +283,7 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert (a.d_d.kt, a.d_d.dt, a.d_d.kh, a.d_d.kw, a.d_d.ph) == (2, 0, 3, 1, 1)
     assert (a.d_d.Tr, a.d_d.Hr, a.d_d.Wr, a.d_d.Ts, a.d_d.Hs, a.d_d.Ws) == (1, T, H * W, 1, T, H * W)
     # fp32 gradients and split products around the non-local softmax
-    f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32 and b.name not in eng.head_f32)
+    f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32 and b.name not in eng.head_f32 + eng.head_f32_fbo)
     assert len(f32) == 20 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g", "y") for n in f32), f32
     oc = [c for c in convs.values() if c.wname == "nonlocal_conv4_1_out_w"][0]       # (fused with its AffineNd + Sum: named by the sum)
     assert oc.dx_f32 and oc.d_d.out_dtype == hip.F32 and oc.x.root.slot.buf.dtype == torch.float32
@@ -282,9 +294,11 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert att.precise and not att.fused_bwd and (att.d_dp.dtype, att.d_dp.math) == (hip.F32, hip.MATH_BF16X3)
     # the residual stream: the identity operands of the residual Sums (17), and every other 16-bit slot that is the sum of
     # several conv DGRADs -- the inputs of the four projection blocks (pool1, pool2, the last blobs of res3 / res4), the pooled
-    # maps in front of phi / g (5), three blobs of the FBO head
+    # maps in front of phi / g (5); the FBO head keeps fp32 slots
     two = [b.name for b in eng.all_blobs if b.root is b and b.slot.two_term]
-    assert len(two) == 29 and "res2_0_branch2c_bn" in two and "nonlocal_conv4_3_sum" in two and "res5_2_branch2c_bn" not in two
+    assert len(two) == 27 and "res2_0_branch2c_bn" in two and "nonlocal_conv4_3_sum" in two
+    # ... and the last blob of res5: the fp32 pooled gradient of the head re-enters the 16-bit backward as hi + lo
+    assert "res5_2_branch2c_bn" in two and [s for s in eng.steps if s.name() == "avgpool:blob_pooled"][0].two_term_dx
     assert all(n in two for n in ("pool1", "pool2", "nonlocal_conv3_3_sum", "nonlocal_conv4_5_sum", "nonlocal_conv4_1_pool"))
     assert all(eng.env[n].root.slot.buf_lo is not None and eng.env[n].root.slot.buf.dtype == torch.float16 for n in two)
     # every launch has a plan; the table is a pure function of the descriptors (what bench.py and the plan test compare)

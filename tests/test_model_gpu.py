@@ -123,14 +123,15 @@ def test_forward_backward_matches_oracle(preset, dtype):
         print("[%s %s] gradients on identical ReLU / max-pool decisions: median %.2e worst %s"
               % (preset, dtype, float(np.median([x for x, _ in cond])), ["%s=%.2e" % (n, x) for x, n in cond[:4]]))
         if dtype == "mix":
-            # "mix" = the split forward (same decisions, same saved activations) + an fp16 backward: fp16 gradient storage
-            # (two terms on the residual stream), 11-bit MFMA operands (two-term weights in DGRAD, fp32 gradients / split
-            # products around the non-local softmax).  Measured at this size: median 2.3e-4 .. 3.1e-4, p90 6.0e-4 .. 6.2e-4,
-            # max 9.5e-4 (AVA, conv1_w) / 1.02e-3 (Charades, one non-local theta bias): the 11-bit operands leave no margin
-            # below 1e-3, so the regression gate is 1.5e-3 here; the claim against the bar is made at the benchmarked size
-            # (test_full_size_clip_matches_oracle: 9.7e-4 / 6.7e-4).
+            # "mix" = the split forward (same decisions, same saved activations) + an fp16 backward with every storage point
+            # that was found to matter kept wider: two-term weights in DGRAD, two-term gradients on the
+            # residual stream and wherever several conv DGRADs are summed, fp32 gradients + split products around the
+            # non-local softmax, the whole head in fp32.  Measured at this size (round 5): median 0.8e-4 .. 1.3e-4, max
+            # 8.6e-4 (the theta weights of ONE non-local block, whichever the rounding pattern hits) -- EVERY gradient inside
+            # the north-star bar here too (round 4: 1.02e-3 with a 1.5e-3 gate); the benchmarked size has more margin
+            # (test_full_size_clip_matches_oracle: 7.1e-4 / 4.5e-4).
             ce = np.sort([x for x, _ in cond])
-            assert float(np.median(ce)) < 5e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 8e-4 and cond[0][0] < 1.5e-3, cond[:5]
+            assert float(np.median(ce)) < 2.5e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 6e-4 and cond[0][0] < 1e-3, cond[:5]
         else:
             assert cond[0][0] < 1e-3, cond[:5]
     else:
@@ -320,10 +321,12 @@ def test_full_size_clip_matches_oracle(preset):
         a = dict(acts)
         if dtype == "mix":
             assert max(a.values()) < 1e-3, acts
-            # split forward + fp16 backward: EVERY gradient inside the north-star bar at the benchmarked size -- measured
-            # median 3.7e-4 / 4.0e-4, p90 4.9e-4 / 6.2e-4, max 6.7e-4 (Charades) / 9.7e-4 (AVA: conv1_w, the end of the
-            # chain); raw median 1.7e-3 (AVA: ties, as on the split path).  No margin to speak of: 11-bit operands.
-            assert float(np.median(ce)) < 6e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 8e-4 and float(ce[-1]) < 1e-3, \
+            # split forward + fp16 backward: EVERY gradient inside the north-star bar at the benchmarked size, with margin --
+            # measured (round 5) median 1.06e-4 (AVA) / 5.4e-5 (Charades), p90 1.8e-4 / 1.9e-4, max 7.1e-4 / 4.5e-4 (conv1_w
+            # both: the end of the chain, and a sum of random-sign terms on the noise clip, so its relative error IS the
+            # element-wise error of the trunk gradient); round 4: 4.0e-4 / 6.2e-4 / 9.7e-4.  Gate = measured max x 1.15.
+            # Raw median 1.6e-3 (AVA: ties, as on the split path).
+            assert float(np.median(ce)) < 2e-4 and float(ce[int(0.9 * (len(ce) - 1))]) < 3.5e-4 and float(ce[-1]) < 8.2e-4, \
                 sorted(cond, key=lambda x: -x[1])[:5]
             assert med < 3e-3 and mx < 2e-2, (med, mx)
         elif dtype in ("fp32", "split"):

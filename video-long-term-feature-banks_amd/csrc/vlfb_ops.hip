@@ -314,10 +314,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 template <typename T, bool IS_MAX, typename IdxT>
 __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict__ argmax,
                                 T* dx, const T* add, const T* __restrict__ mask, PoolP p,
-                                float inv_window, const T* __restrict__ ymask = nullptr,
-                                const T* __restrict__ dy_lo = nullptr) {
-  // dy_lo: low term of a two-term gradient (dy + dy_lo, the "mix" path's 16-bit slots that sum several conv DGRADs):
-  // added in fp32 before anything else, so the pooled gradient enters with ~22 bits instead of 11
+                                float inv_window, const T* __restrict__ ymask = nullptr) {
   constexpr int V = Vec16<T>::N;
   const int cchunks = p.C / V;
   const long long total = (long long)p.N * p.Ti * p.Hi * p.Wi * cchunks;
@@ -348,12 +345,6 @@ __global__ void pool_bwd_kernel(const T* __restrict__ dy, const IdxT* __restrict
           const long long o = (((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
           float g[V];
           Vec16<T>::load(dy + o * p.C + cc * V, g);
-          if (dy_lo) {
-            float gl[V];
-            Vec16<T>::load(dy_lo + o * p.C + cc * V, gl);
-#pragma unroll
-            for (int k = 0; k < V; ++k) g[k] += gl[k];
-          }
           if (IS_MAX && ymask) {
             // max-pool of a ReLU output: the selected element IS the pooled value, so "the input passed its
             // ReLU" can be read from the (window-times smaller) pooled tensor instead of the input
@@ -423,11 +414,10 @@ __device__ __forceinline__ void unpack_vec(const uint4& t, float (&v)[Vec16<T>::
   }
 }
 
-template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, bool YMASK, bool LO = false>
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, bool YMASK>
 __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
                                                                 T* dx, const T* add, const T* __restrict__ mask, PoolP p,
-                                                                const T* __restrict__ ymask, const T* __restrict__ dy_lo = nullptr) {
-  // LO: dy_lo holds the low term of a two-term gradient (see pool_bwd_kernel)
+                                                                const T* __restrict__ ymask) {
   constexpr int V = Vec16<T>::N;
   constexpr int CT = (KT + ST - 1) / ST, CH = (KH + SH - 1) / SH, CW = (KW + SW - 1) / SW;
   const int cchunks = p.C / V;
@@ -469,7 +459,7 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
         const int ho = ho_hi - jh, b = hi + p.ph - ho * SH;
         if (ho < 0 || ho >= p.Ho || b >= KH) continue;
         const int orow = ((n * p.To + to) * p.Ho + ho) * p.Wo;
-        uint4 gq[CW], yq[CW], lq[LO ? CW : 1];
+        uint4 gq[CW], yq[CW];
         uint2 aq[CW];
         int tapq[CW];
 #pragma unroll
@@ -478,7 +468,6 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
           const bool ok = wo >= 0 && wo < p.Wo && c < KW;
           const long long o = ok ? (long long)(orow + wo) * p.C + cc * V : (long long)(cc * V);
           tapq[jw] = ok ? (a * KH + b) * KW + c : 255;
-          if (LO) lq[LO ? jw : 0] = *reinterpret_cast<const uint4*>(dy_lo + o);
           if (sizeof(T) == 2) {
             gq[jw] = *reinterpret_cast<const uint4*>(dy + o);
             if (YMASK) yq[jw] = *reinterpret_cast<const uint4*>(ymask + o);
@@ -493,12 +482,6 @@ __global__ __launch_bounds__(128) void maxpool_bwd_fixed_kernel(const T* __restr
         for (int jw = 0; jw < CW; ++jw) {
           float g[V];
           unpack_vec<T>(gq[jw], g);
-          if (LO) {
-            float gl[V];
-            unpack_vec<T>(lq[LO ? jw : 0], gl);
-#pragma unroll
-            for (int k = 0; k < V; ++k) g[k] += gl[k];
-          }
           if (YMASK) {
             float yv[V];
             unpack_vec<T>(yq[jw], yv);
@@ -650,13 +633,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_band_kernel(const T* __restri
 // launches the fixed-shape kernel when the window is one of the compiled shapes (one-byte arg-max); false = use the generic one
 template <typename T>
 bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax, void* dx, const void* add, const void* mask,
-                              const void* ymask, hipStream_t s, const void* dy_lo = nullptr) {
+                              const void* ymask, hipStream_t s) {
   const long long rows = (long long)p.N * p.Ti * p.Hi;
   if (rows >= (1ll << 31) || (long long)p.N * p.To * p.Ho * p.Wo >= (1ll << 31)) return false;
   const dim3 grid((unsigned)rows), block(128);
   // (with a residual operand and a ReLU mask streamed beside it the row kernel is the faster one: 271 vs 357 us)
   if (p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 2 && p.sw == 2 && p.pt == 0 && p.To == p.Ti && !add &&
-      !mask && !dy_lo) {        // (a two-term gradient would double the staged rows: it takes the row kernel)
+      !mask) {
     // band kernel: as many input-row pairs per workgroup as 64 KB of LDS hold pooled rows for (R + 2 rows staged)
     const long long row_bytes = (long long)p.Wo * p.C * (sizeof(T) + 1);
     // R = 3: measured 226 us at R = 2 and 3, 259 us at R = 4 (two 64 KB workgroups per CU leave the load and the store
@@ -679,20 +662,6 @@ bool launch_maxpool_bwd_fixed(const PoolP& p, const void* dy, const void* argmax
   }
 #define VLFB_POOL_FIXED(KT_, KH_, KW_, ST_, SH_, SW_)                                                                      \
   if (p.kt == KT_ && p.kh == KH_ && p.kw == KW_ && p.st == ST_ && p.sh == SH_ && p.sw == SW_) {                           \
-    if (dy_lo) {                                                                                                         \
-      if constexpr (sizeof(T) == 2) {                                                                                    \
-        if (ymask)                                                                                                       \
-          hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, true, true>), grid, block, 0, s, \
-                             (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p,             \
-                             (const T*)ymask, (const T*)dy_lo);                                                          \
-        else                                                                                                             \
-          hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, false, true>), grid, block, 0, s,\
-                             (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p,             \
-                             (const T*)ymask, (const T*)dy_lo);                                                          \
-        return true;                                                                                                     \
-      }                                                                                                                  \
-      return false;                                                                                                      \
-    }                                                                                                                    \
     if (ymask)                                                                                                           \
       hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KT_, KH_, KW_, ST_, SH_, SW_, true>), grid, block, 0, s,           \
                          (const T*)dy, (const uint8_t*)argmax, (T*)dx, (const T*)add, (const T*)mask, p, (const T*)ymask); \
@@ -1250,26 +1219,6 @@ extern "C" int vlfb_maxpool_relu_bwd(const vlfb_pool_desc* d, const void* dy, co
     VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)nullptr, (const T16*)nullptr, p, 1.f, (const T16*)y));
   return check_launch("maxpool_relu_bwd");
 }
-extern "C" int vlfb_maxpool_bwd_lo(const vlfb_pool_desc* d, const void* dy, const void* dy_lo, const void* argmax,
-                                   const void* y, void* dx, const void* add, const void* mask, vlfb_stream_t stream) {
-  int rc = check_pool(d);
-  if (rc) return rc;
-  VLFB_REQUIRE(dy && dy_lo && argmax && dx, "maxpool_bwd_lo: null pointer");
-  VLFB_REQUIRE(d->dtype == VLFB_F16 || d->dtype == VLFB_BF16, "maxpool_bwd_lo: two-term gradients are 16-bit");
-  PoolP p = to_poolp(d);
-  const bool wide = vlfb_pool_argmax_bytes(d) == 2;
-  int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / 8), 256);
-  hipStream_t s = (hipStream_t)stream;
-  if (!wide) {
-    bool done;
-    VLFB_WITH_T16(d->dtype, done = launch_maxpool_bwd_fixed<T16>(p, dy, argmax, dx, add, mask, y, s, dy_lo));
-    if (done) return check_launch("maxpool_bwd_lo (fixed window)");
-    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint8_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint8_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f, (const T16*)y, (const T16*)dy_lo));
-  } else {
-    VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, true, uint16_t>), dim3(grid), dim3(256), 0, s, (const T16*)dy, (const uint16_t*)argmax, (T16*)dx, (const T16*)add, (const T16*)mask, p, 1.f, (const T16*)y, (const T16*)dy_lo));
-  }
-  return check_launch("maxpool_bwd_lo");
-}
 extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y, vlfb_stream_t stream) {
   int rc = check_pool(d);
   if (rc) return rc;
@@ -1310,6 +1259,74 @@ extern "C" int vlfb_avgpool_bwd(const vlfb_pool_desc* d, const void* dy, void* d
   else
     VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((pool_bwd_kernel<T16, false, uint8_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T16*)dy, (const uint8_t*)nullptr, (T16*)dx, (const T16*)add, (const T16*)mask, p, inv));
   return check_launch("avgpool_bwd");
+}
+
+// Average-pool backward from an fp32 pooled gradient into a TWO-TERM 16-bit input gradient: dx = mask > 0 ? sum dy / window : 0,
+// hi = T(dx), lo = T(dx - hi).  Where the "mix" path's fp32 head gradient re-enters the 16-bit backward (the temporal / global
+// average pool over res5): every position of a channel receives the SAME value, so a one-term rounding is an error common to all
+// positions -- and to every backbone gradient behind it (it was their median error).
+template <typename T>
+__global__ void avgpool_bwd_two_term_kernel(const float* __restrict__ dy, T* __restrict__ dx_hi, T* __restrict__ dx_lo,
+                                            const T* __restrict__ mask, PoolP p, float inv_window) {
+  constexpr int V = 8;
+  const int cchunks = p.C / V;
+  const long long total = (long long)p.N * p.Ti * p.Hi * p.Wi * cchunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long q = i / cchunks;
+    const int wi = (int)(q % p.Wi); long long r = q / p.Wi;
+    const int hi = (int)(r % p.Hi); r /= p.Hi;
+    const int ti = (int)(r % p.Ti);
+    const int n = (int)(r / p.Ti);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    const int t_lo = max(0, (ti - p.kt + p.st) / p.st), t_hi = min(p.To - 1, ti / p.st);
+    const int h_lo = max(0, (hi - p.kh + p.sh) / p.sh), h_hi = min(p.Ho - 1, hi / p.sh);
+    const int w_lo = max(0, (wi - p.kw + p.sw) / p.sw), w_hi = min(p.Wo - 1, wi / p.sw);
+    for (int to = t_lo; to <= t_hi; ++to) {
+      if (ti - to * p.st >= p.kt) continue;
+      for (int ho = h_lo; ho <= h_hi; ++ho) {
+        if (hi - ho * p.sh >= p.kh) continue;
+        for (int wo = w_lo; wo <= w_hi; ++wo) {
+          if (wi - wo * p.sw >= p.kw) continue;
+          const float* g = dy + ((((long long)n * p.To + to) * p.Ho + ho) * p.Wo + wo) * p.C + cc * V;
+          const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
+          acc[0] += g0.x * inv_window; acc[1] += g0.y * inv_window; acc[2] += g0.z * inv_window; acc[3] += g0.w * inv_window;
+          acc[4] += g1.x * inv_window; acc[5] += g1.y * inv_window; acc[6] += g1.z * inv_window; acc[7] += g1.w * inv_window;
+        }
+      }
+    }
+    const long long off = q * p.C + cc * V;
+    if (mask) {
+      float mk[V];
+      Vec16<T>::load(mask + off, mk);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] = mk[k] > 0.f ? acc[k] : 0.f;
+    }
+    Vec16<T>::store(dx_hi + off, acc);
+    float h[V];
+    Vec16<T>::load(dx_hi + off, h);                  // (the rounded values, as stored)
+#pragma unroll
+    for (int k = 0; k < V; ++k) h[k] = acc[k] - h[k];
+    Vec16<T>::store(dx_lo + off, h);
+  }
+}
+
+extern "C" int vlfb_avgpool_bwd_two_term(const vlfb_pool_desc* d, const float* dy, void* dx_hi, void* dx_lo, const void* mask,
+                                         vlfb_stream_t stream) {
+  int rc = check_pool(d);
+  if (rc) return rc;
+  VLFB_REQUIRE(dy && dx_hi && dx_lo, "avgpool_bwd_two_term: null pointer");
+  VLFB_REQUIRE(d->pt == 0 && d->ph == 0 && d->pw == 0, "avgpool: padding is not supported");
+  VLFB_REQUIRE(d->dtype == VLFB_F16 || d->dtype == VLFB_BF16, "avgpool_bwd_two_term: the input gradient is 16-bit (hi + lo)");
+  PoolP p = to_poolp(d);
+  VLFB_REQUIRE(p.C % 8 == 0, "avgpool_bwd_two_term: channels must be a multiple of 8");
+  const float inv = 1.0f / (float)(p.kt * p.kh * p.kw);
+  int grid = grid_for((long long)p.N * p.Ti * p.Hi * p.Wi * (p.C / 8), 256);
+  VLFB_WITH_T16(d->dtype, hipLaunchKernelGGL((avgpool_bwd_two_term_kernel<T16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                             dy, (T16*)dx_hi, (T16*)dx_lo, (const T16*)mask, p, inv));
+  return check_launch("avgpool_bwd_two_term");
 }
 
 extern "C" int vlfb_softmax_fwd(const float* s, void* p, int dtype, int64_t rows, int64_t cols,

@@ -152,7 +152,8 @@ class GradSlot(object):
         if self.count > self.expected:
             raise RuntimeError("too many gradient contributions for %s" % self.blob.name)
         last = self.count == self.expected
-        mask = self.blob.bstorage() if (last and self.blob.relu) else None
+        # (the mask operand has the dtype of the gradient: the fp16 copy of the values on the 16-bit backward of "mix")
+        mask = (self.blob.storage() if self.blob.grad_f32 else self.blob.bstorage()) if (last and self.blob.relu) else None
         return self.cur, mask
 
     def contribute(self, fn, supports_add=True, supports_mask=True, writes_planes=False):
@@ -308,6 +309,7 @@ class ConvStep(Step):
                                  **planes, **geom, **ld_f)
         self.d_d = None
         self.w2 = False
+        self.bwd_split = False
         self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
         if self.bwd_f32:
             eng.need_scratch_act(self.out.numel)
@@ -318,7 +320,10 @@ class ConvStep(Step):
             dg = dict(geom)
             alpha = 1.0 / self.gscale
             rows = dict(N=N, Tr=T, Hr=H, Wr=W, Ts=To, Hs=Ho, Ws=Wo)
-            w2 = self._w2_geometry(dg, rows) if (eng.mix and eng.MIX_W2) else None
+            # "mix", a conv BETWEEN fp32 gradient slots (the FBO head, Engine._plan_head_f32): its whole backward runs as
+            # on the `split` dtype -- fp32 gradient in and out, three bf16 products per product, bf16 term planes of W
+            self.bwd_split = bool(eng.mix and self.out.root.grad_f32 and self.x.root.grad_f32 and G == 1)
+            w2 = self._w2_geometry(dg, rows) if (eng.mix and eng.MIX_W2 and not self.bwd_split) else None
             if w2 is not None:
                 dg, rows = w2
                 alpha /= hip.MIX_W2_SCALE
@@ -328,6 +333,9 @@ class ConvStep(Step):
             self.dx_f32 = bool(eng.mix and self.x.root.grad_f32)
             self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=hip.F32 if self.dx_f32 else bcode, Cs=self.Cog,
                                      Cn=Cin // G, alpha=alpha, math=mb, **rows, **bplanes, **dg, **ld_d)
+            if self.bwd_split:
+                self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, Cs=self.Cog, Cn=Cin // G, alpha=alpha,
+                                         math=hip.MATH_BF16X3, **rows, **planes, **dg, **ld_d)
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
@@ -374,7 +382,9 @@ class ConvStep(Step):
             self.w_f = torch.empty(wshape, device=eng.device, dtype=eng.tdtype)
         self.w_d = None
         if self.d_d is not None:
-            if eng.mix:
+            if eng.mix and self.bwd_split:
+                self.w_d = torch.empty(2 * _prod(wshape), device=eng.device, dtype=torch.bfloat16)
+            elif eng.mix:
                 self.w_d = torch.empty((2 if self.w2 else 1) * _prod(wshape), device=eng.device, dtype=torch.float16)
             else:
                 self.w_d = (torch.empty(2 * _prod(wshape), device=eng.device, dtype=torch.bfloat16) if eng.split else
@@ -382,10 +392,11 @@ class ConvStep(Step):
         # one group's weight-operand block: [planes][wblk] elements, group g at g * planes * wblk (vlfb_weight_prep* is run
         # per group, so the term planes of a group lie next to each other)
         self.wf_npl = 3 if eng.split else 1
-        self.wd_npl = (2 if self.w2 else 1) if eng.mix else (2 if eng.split else 1)
+        self.wd_npl = (2 if (self.w2 or self.bwd_split) else 1) if eng.mix else (2 if eng.split else 1)
         # the format vlfb_weight_prep writes this conv's operand copies in ("mix": two-term or plain fp16 DGRAD copy, per conv --
         # ConvStep._w2_geometry; a conv without a DGRAD copy goes with the engine's default)
-        self.wcode = eng.wcode if not eng.mix else (hip.MIX if (self.w_d is not None and not self.w2) else eng.wcode)
+        self.wcode = eng.wcode if not eng.mix else (hip.SPLIT if self.bwd_split else
+                                                    hip.MIX if (self.w_d is not None and not self.w2) else eng.wcode)
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
@@ -510,7 +521,7 @@ class ConvStep(Step):
         if self.bwd_f32:
             # fp32 gradient ("mix", non-local theta / phi / g): WGRAD and the bias sum read it as it is, DGRAD its fp16 copy
             g_w = g
-            if self.d_d is not None:
+            if self.d_d is not None and not self.bwd_split:
                 g = eng.scratch_act(self.out.numel)
                 hip.call("vlfb_cast", hip.ptr(g_w), hip.F32, hip.ptr(g), eng.bcode, self.out.numel)
         gp = self.out.root.slot.value_planes()         # term planes of the finished output gradient, or None
@@ -520,7 +531,11 @@ class ConvStep(Step):
             # weight / bias gradients are leaves of the backward graph: they run on the side stream
             # and overlap the dgrad chain (they only have to be finished before all-reduce / solver)
             eng.issue_param_grads(lambda: self._param_grads(g_w, gp))
-        if self.d_d is not None and eng.mix and self.x.root.grad_f32:
+        if self.d_d is not None and self.bwd_split:
+            # (the FBO head) fp32 gradient operand, fp32 slot: the split-bf16 DGRAD with the slot's earlier contribution and
+            # the fp32 values as the ReLU mask in its epilogue
+            self.x.root.slot.contribute(lambda out, add, mask: hip.conv_run(self.d_d, g_w, self.w_d, None, out, R=add, mask=mask))
+        elif self.d_d is not None and eng.mix and self.x.root.grad_f32:
             # (Engine._plan_head_f32, AttentionStep) the input's gradient slot is fp32: the fp16 DGRAD writes its fp32
             # accumulators there (out_dtype F32; GradSlot adds an earlier contribution in fp32)
             assert self.group == 1 and self.dx_f32
@@ -626,17 +641,17 @@ class PoolStep(Step):
     def bwd(self):
         if not self.grad_inputs():
             return
+        if getattr(self, "two_term_dx", False):
+            # "mix": the fp32 pooled gradient -> a two-term fp16 input gradient (Engine._analyse_grads)
+            g32, xs = self.out_grad(), self.x.root.slot
+
+            def fn2(out, add, mask, planes):
+                assert add is None and xs.out_lo is not None
+                hip.call("vlfb_avgpool_bwd_two_term", C.byref(self.desc_b), hip.ptr(g32), hip.ptr(out), hip.ptr(xs.out_lo), hip.ptr(mask))
+            xs.contribute(fn2, writes_planes=True)
+            return
         g = self.g_as(self.out_grad(), self.out, self.x)      # ("mix": where the head's fp32 gradient re-enters fp16)
-        g_lo = self.out.root.slot.value_lo() if self.is_max else None
-        if g_lo is not None:
-            # a two-term pooled gradient (pool1 / pool2 in front of a projection block: GradSlot.two_term): hi + lo are added
-            # in fp32 inside the kernel, the input gradient is rounded once
-            def fn(out, add, mask):
-                relu_of_input = mask is not None and add is None
-                hip.call("vlfb_maxpool_bwd_lo", C.byref(self.desc_b), hip.ptr(g), hip.ptr(g_lo), hip.ptr(self.argmax),
-                         self.out.bptr() if relu_of_input else None, hip.ptr(out), hip.ptr(add),
-                         None if relu_of_input else hip.ptr(mask))
-        elif self.is_max:
+        if self.is_max:
             def fn(out, add, mask):
                 if mask is not None and add is None:
                     # sole consumer of a ReLU output: the mask is `pooled value > 0` (see vlfb_maxpool_relu_bwd)
@@ -785,6 +800,13 @@ class AttentionStep(Step):
             for s in (th, ph, gg):
                 s._flags()
                 s.cur = s.buf
+            if self.theta.root.grad_f32:
+                # (the FBO head of "mix", Engine._plan_head_f32: fp32 gradients in and out, the fp32 forward values)
+                assert self.phi.root.grad_f32 and self.g.root.grad_f32 and self.out.root.grad_f32
+                hip.call("vlfb_fbo_attn_bwd", hip.ptr(dY), self.theta.ptr(), self.phi.ptr(), self.g.ptr(),
+                         self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), hip.ptr(self.ds_ws),
+                         hip.F32, B, L2, Ci, Ci, self.scale)
+                return
             hip.call("vlfb_fbo_attn_bwd", hip.ptr(dY), self.theta.bptr(), self.phi.bptr(), self.g.bptr(),
                      self.prob.ptr(), hip.ptr(th.buf), hip.ptr(ph.buf), hip.ptr(gg.buf), hip.ptr(self.ds_ws),
                      eng.bcode, B, L2, Ci, Ci, self.scale)
@@ -974,10 +996,12 @@ class LayerNormStep(Step):
     def bwd(self):
         if not self.grad_inputs():
             return
-        g = self.out_grad()
+        g = self.g_as(self.out_grad(), self.out, self.x)
+        f32 = bool(self.x.root.grad_f32)              # ("mix", the FBO head: fp32 gradient, the fp32 normalised values)
         self.x.root.slot.contribute(
-            lambda out, add, mask: hip.call("vlfb_layernorm_bwd", hip.ptr(g), self.out.bptr(), hip.ptr(self.rstd),
-                                            hip.ptr(out), self.eng.bcode, self.rows, self.cols),
+            lambda out, add, mask: hip.call("vlfb_layernorm_bwd", hip.ptr(g), self.out.ptr() if f32 else self.out.bptr(),
+                                            hip.ptr(self.rstd), hip.ptr(out), hip.F32 if f32 else self.eng.bcode,
+                                            self.rows, self.cols),
             supports_add=False, supports_mask=False)
 
 
@@ -2032,6 +2056,41 @@ class Engine(object):
             b.grad_f32 = True
             self.head_f32.append(b.name)
             work += nxt
+        self._plan_fbo_f32(consumers)
+
+    def _plan_fbo_f32(self, consumers):
+        """... and the FBO branch of the head (lfb_helper.py:170-338: reduc conv, lfb_1x1, per layer theta / phi / g, the
+        one-query attention, LayerNorm, ReLU, out conv, dropouts, the Sum) between the fp32 concat gradient and the fp32
+        RoI features: a dozen fp16 storages in series that left a 2.2e-4 error on the gradient of `box_pooled` -- common
+        to EVERY backbone gradient (scratch/r5/diag_mix.py, full-size clip) -- for < 2 % of the step's FLOPs.  Its steps
+        run their backward in fp32 (ConvStep.bwd_split: the split-bf16 DGRAD / WGRAD of the `split` dtype; the other
+        steps: their fp32 kernels on the fp32 forward values).  All or nothing: the branch is only marked when every blob
+        between the concat and an fp32 slot / a fed blob is produced AND consumed by steps that can do that."""
+        self.head_f32_fbo = []
+        f32_ok = lambda st: isinstance(st, (AddStep, DropoutStep, ReluStep, LayerNormStep, ConcatStep)) or \
+            (isinstance(st, AttentionStep) and st.theta.shape[2] == 1) or \
+            (isinstance(st, ConvStep) and st.group == 1 and not st.stem)    # (incl. an out conv fused with the Sum)
+        for cat in [st for st in self.steps if isinstance(st, ConcatStep) and st.out.root.grad_f32]:
+            for part in cat.parts:
+                cand, work, ok = {}, [part.root], True
+                while work and ok:
+                    b = work.pop()
+                    if id(b) in cand or b.grad_f32 or b.producer is None:
+                        continue                     # an fp32 slot already (box_pooled) or a fed blob (the bank)
+                    st = b.producer
+                    if b.kind != "act" or not f32_ok(st) or b.grad_scale != 1.0:
+                        ok = False
+                        break
+                    cand[id(b)] = b
+                    work += [i.root for i in st.inputs]
+                for b in cand.values():                # every consumer writes into a slot of the set (or the concat)
+                    for c in consumers.get(id(b), []):
+                        outs_ok = all(id(o.root) in cand or o.root.grad_f32 for o in c.outputs)
+                        ok = ok and f32_ok(c) and outs_ok
+                if ok:
+                    for b in cand.values():
+                        b.grad_f32 = True
+                        self.head_f32_fbo.append(b.name)
 
     def _plan_params(self):
         """flat fp32 buckets: trainables ordered by backward completion; frozen ones separately"""
@@ -2163,6 +2222,15 @@ class Engine(object):
                     r = st.x.root
                     if r.kind == "act" and not r.grad_f32 and r.slot.expected > 1 and r.grad_scale == 1.0:
                         r.slot.two_term = True
+            # ... and where the fp32 gradient of the head re-enters the 16-bit backward: the average pool over res5 hands every
+            # position of a channel the SAME value, so a one-term rounding is common to all positions (it was the median error
+            # of every backbone gradient: 2.8e-4 on Charades' dense loss gradient).  PoolStep.bwd writes hi + lo.
+            for st in self.bwd_steps:
+                if isinstance(st, PoolStep) and not st.is_max and st.out.root.grad_f32 and st.grad_inputs():
+                    r = st.x.root
+                    if r.kind == "act" and not r.grad_f32 and r.slot.expected == 1 and r.C % 8 == 0:
+                        r.slot.two_term = True
+                        st.two_term_dx = True
 
     def _allocate(self):
         dev = self.device

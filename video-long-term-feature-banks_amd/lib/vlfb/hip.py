@@ -122,9 +122,9 @@ _SIGS = {
     "vlfb_maxpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "vlfb_maxpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P, _P]),
     "vlfb_maxpool_relu_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P]),
-    "vlfb_maxpool_bwd_lo": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "vlfb_avgpool_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
     "vlfb_avgpool_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P]),
+    "vlfb_avgpool_bwd_two_term": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P, _P]),
     "vlfb_softmax_fwd": (C.c_int, [_P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_softmax_bwd": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
     "vlfb_softmax_bwd_p32": (C.c_int, [_P, _P, _P, C.c_int, _I64, _I64, C.c_float, _P]),
