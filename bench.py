@@ -8,13 +8,24 @@ R50-I3D-NL + LFB-NL on synthetic 32 x 224^2 clips (BASELINE.json `metric`), one 
 
 Rank 0 prints ONE JSON line.  `value` is the whole-job clips/s with the inputs already resident in
 HBM (weak scaling: 8 clips per GPU, i.e. global batch 64 at 8 GPUs as the north star asks).
-`roofline` is the live HIP-event measurement of the dominant kernel family (the implicit-GEMM
-NT kernels: conv fprop + dgrad + the batched attention GEMMs): algorithmic FLOPs / summed launch
-time against the dense bf16 MFMA peak.  The events bracket every launch of the LAST TIMED STEP on the
-stream it is launched on, in the normal two-stream schedule (wgrads overlap the dgrad chain), i.e.
-they are the durations a rocprofv3 kernel trace of the same command shows (profiles/).
+
+The default dtype is `mix` (split-bf16 forward on fp32 storage + fp16 backward): the
+fastest path whose outputs AND parameter gradients are inside the north star's 1e-3 at the benchmarked
+size (`parity`, quoted from the committed full-size comparison while the kernel sources are the ones it
+was measured on).  The 16-bit paths are faster and miss that gate by an order of magnitude: they are
+sub-records (`fp16_path`; `--dtype bf16` for the other one), as are `split_path` / `fp32_path`.
+
+`roofline` is a live HIP-event measurement of the dominant kernel family of the benchmarked dtype --
+for `mix` the split-bf16 NT kernels of the forward pass -- on ONE extra step behind the timed region
+(same two-stream schedule, every GEMM launch bracketed on the stream it is launched on: the durations
+a rocprofv3 kernel trace of this command shows, profiles/): `achieved` = algorithmic FLOP / launch
+time, `peak` = 2.5 PFLOP/s dense 16-bit MFMA / MFMA instructions per algorithmic product of that
+family (3 for a split-bf16 product, 2 for an fp16 DGRAD with two-term weights, 1 otherwise; the
+exact-fp32 kernels: 157.3 TFLOP/s), so `frac` is the fraction of the MFMA roof the family's
+instructions reach.  `roofline_families` has every family of the step, `roofline_wgrad` the dominant
+TN (weight-gradient) family.
 `cpu_baseline` is the fp32 CPU oracle (a port: the reference has no runnable CPU path) timed on this
-box's host cores on ONE clip; `fp32_path` is the same GPU step on the exact-fp32 parity path.
+box's host cores on ONE clip, and the same clip's outputs on the GPU checked against it.
 """
 import argparse
 import collections
@@ -28,7 +39,16 @@ for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT)
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "split": 2500.0, "mix": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+MFMA16_PEAK, MFMA32_PEAK = 2500.0, 157.3         # MI355X dense MFMA peaks, TFLOP/s: 16-bit operands / exact fp32 (MI355X_MICROARCH.md)
+FAMILY_KERNELS = collections.OrderedDict([
+    ("nt_split", "gemm_nt_sp_kernel / gemm_nt_pl_kernel (split-bf16 implicit-GEMM conv FPROP / DGRAD + NT attention products on fp32 storage)"),
+    ("nt_16", "gemm_nt_kernel / gemm_nt8_kernel / gemm_nts_kernel / stem_fprop_kernel / conv_rows64_kernel / gemm_skinny_nt_kernel "
+              "(16-bit implicit-GEMM conv FPROP + DGRAD, NT attention products)"),
+    ("nt_f32", "gemm_nt_kernel<float> (exact-fp32 MFMA conv FPROP + DGRAD, NT attention products)"),
+    ("tn_16", "gemm_tn_tr_kernel / gemm_tn8_kernel / stem_wgrad_kernel / wgrad_rows_kernel (16-bit implicit-GEMM conv WGRAD, TN attention products)"),
+    ("tn_split", "gemm_tn_sp_kernel / gemm_tn_tr_kernel<SP> (split-bf16 conv WGRAD + TN attention products on fp32 storage)"),
+    ("tn_f32", "gemm_tn_kernel<float> (exact-fp32 MFMA conv WGRAD)"),
+])
 HBM_PEAK_GBPS = 8000.0                           # HBM3E spec peak (same guide; ~6.3 TB/s measured copy)
 
 
@@ -39,9 +59,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ava_r50_lfb_nl",
                     help="ava_r50_lfb_nl (metric config) | charades_r50_baseline | charades_r50_lfb_nl | ava_r101_lfb_nl_3l")
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "split", "mix"],
-                    help="fp16 (default: the 16-bit path -- same speed as bf16, gradients 3x closer to the oracle), bf16, the "
-                         "parity-grade paths split / mix, or fp32 (exact-fp32 MFMA)")
+    ap.add_argument("--dtype", default="mix", choices=["mix", "fp16", "bf16", "split", "fp32"],
+                    help="mix (default: split-bf16 forward + fp16 backward -- the fastest path inside the 1e-3 gradient gate), the "
+                         "16-bit throughput paths fp16 / bf16 (outside it), split (all split-bf16, 25x inside it) or fp32 (exact-fp32 MFMA)")
     ap.add_argument("--clips-per-gpu", type=int, default=8)
     ap.add_argument("--rois-per-clip", type=int, default=0,
                     help="0 = SURVEY 8d C4 draw U{1..5} per clip (seeded per rank); N > 0 = exactly N per clip")
@@ -74,8 +94,10 @@ def parse():
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 parity-path measurement")
     ap.add_argument("--dp-steps", type=int, default=10,
                     help="data-parallel jobs: timed steps of the same step WITHOUT the gradient exchange (exposed all-reduce time)")
-    ap.add_argument("--mix-steps", type=int, default=20, help="timed steps of the extra 'mix' (split forward + fp16 backward) measurement")
+    ap.add_argument("--mix-steps", type=int, default=20, help="timed steps of the extra 'mix' measurement (when --dtype is another path)")
     ap.add_argument("--no-mix-line", action="store_true", help="skip the extra 'mix' path measurement")
+    ap.add_argument("--fp16-steps", type=int, default=20, help="timed steps of the extra fp16 throughput-path measurement")
+    ap.add_argument("--no-fp16-line", action="store_true", help="skip the extra fp16 path measurement")
     return ap.parse_args()
 
 
@@ -168,6 +190,7 @@ def data_parallel_report(eng, args, lr, step_s, device):
     rep["allreduce_alone_busbw_GBps"] = round(2.0 * (world - 1) / world * buf.numel() * 4 / alone / 1e9, 1) if world > 1 else None
     # (c) the same step without the exchange (LAST: the ranks' weights diverge from here on)
     comm, eng.comm = eng.comm, None
+    trace, eng.STEP_TRACE = eng.STEP_TRACE, False          # same host path as the timed data-parallel step (stream objects)
     try:
         for _ in range(2):
             eng.train_step(lr)
@@ -180,19 +203,25 @@ def data_parallel_report(eng, args, lr, step_s, device):
         no_comm = vmax((time.perf_counter() - t0) / max(args.dp_steps, 1))
     finally:
         eng.comm = comm
+        eng.STEP_TRACE = trace
     rep["ms_per_step_without_allreduce"] = round(no_comm * 1e3, 3)
     rep["exposed_allreduce_ms"] = round((step_s - no_comm) * 1e3, 3)
     rep["hidden_fraction"] = round(max(0.0, min(1.0, 1.0 - (step_s - no_comm) / alone)), 3) if alone > 0 else None
     return rep
 
 
-def cpu_baseline(workload, frames, crop, rois_per_clip):
+def cpu_baseline(workload, frames, crop, rois_per_clip, dtype=None, device=None):
     """the fp32 torch-CPU oracle forward+backward of ONE full clip on the host cores (bounded: at most
     3 runs / ~30 s).  32 threads: torch's CPU conv3d collapses when all 256 hardware threads of the
-    GPU box are used (measured: 0.2 s at 16 threads vs 137 s at 256 for an 8x64^2 clip)."""
+    GPU box are used (measured: 0.2 s at 16 threads vs 137 s at 256 for an 8x64^2 clip).
+    The oracle is the checker here as well: the same clip goes through a one-clip engine of the benchmarked dtype on the GPU
+    and its outputs are compared with the timed run's (`gpu_outputs_vs_this_run`; never the thing measured)."""
+    import collections as _c
+    import numpy as np
     import torch
     from vlfb.presets import load_preset
     from core.config import config as cfg
+    from vlfb import rng as vrng
     from oracle import model as om
     load_preset(workload, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1, "TRAIN.VIDEO_LENGTH", frames,
                            "TRAIN.CROP_SIZE", crop])
@@ -201,19 +230,138 @@ def cpu_baseline(workload, frames, crop, rois_per_clip):
     inputs = om.synth_inputs(cfg, 1, "train", seed=2, rois_per_clip=[rois_per_clip] if cfg.DATASET == "ava" else None,
                              crop=crop, frames=frames)
     params = om.synth_params(cfg, seed=2)
+    seed_fn = lambda name: vrng.dropout_seed(cfg.RNG_SEED, name, 0)       # the masks the engine draws at iteration 0
     times = []
     budget = time.time() + 30.0
     t0 = time.time()
-    om.run(cfg, params, inputs, "train", torch.float32, True, lambda name: 1)      # warm-up
+    blobs, _ = om.run(cfg, params, inputs, "train", torch.float32, True, seed_fn)      # warm-up
     warm = time.time() - t0
     while len(times) < 3 and (not times or time.time() + times[-1] < budget):
         t0 = time.time()
-        om.run(cfg, params, inputs, "train", torch.float32, True, lambda name: 1)
+        blobs, _ = om.run(cfg, params, inputs, "train", torch.float32, True, seed_fn)
         times.append(time.time() - t0)
     best = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / best, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "fp32 torch-CPU oracle fwd+bwd of one %dx%dx%d clip: 1 warm-up (%.2f s) + %d timed run(s), median %.2f s, "
-                      "%d threads of %d" % (frames, crop, crop, warm, len(times), best, cores, os.cpu_count() or 1)}
+    rec = {"value": 1.0 / best, "unit": "clips/s", "cores": cores, "kind": "port",
+           "sample": "fp32 torch-CPU oracle fwd+bwd of one %dx%dx%d clip: 1 warm-up (%.2f s) + %d timed run(s), median %.2f s, "
+                     "%d threads of %d" % (frames, crop, crop, warm, len(times), best, cores, os.cpu_count() or 1)}
+    if dtype is not None:
+        try:
+            from models.model_builder_video import ModelBuilder
+            from vlfb.engine import Engine
+            model = ModelBuilder(train=True, split="train", name="bench_check")
+            model.build_model(suffix="_train")
+            eng = Engine(model, dtype, device=device, base_seed=cfg.RNG_SEED)
+            eng.plan(_c.OrderedDict((k + "_train", v.shape) for k, v in inputs.items() if (k + "_train") in model.input_blob_names))
+            eng.feed_params(params)
+            for k, v in inputs.items():
+                if (k + "_train") in model.input_blob_names:
+                    eng.feed(k + "_train", v)
+            eng.forward()
+            torch.cuda.synchronize()
+            rel = lambda a, r: float(np.linalg.norm((np.asarray(a, np.float64) - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-300))
+            chk = {}
+            for name in ("res5_2_branch2c_bn", "pool5", "prob"):
+                if name in blobs:
+                    got = eng.fetch(name)
+                    chk[name] = rel(got, blobs[name].detach().double().numpy().reshape(got.shape))
+            ref_loss = float(blobs["loss"].detach())
+            chk["loss"] = abs(float(eng.fetch("loss").reshape(-1)[0]) - ref_loss) / abs(ref_loss)
+            rec["gpu_outputs_vs_this_run"] = {"dtype": dtype, "relative_l2": {k: float("%.3e" % v) for k, v in chk.items()},
+                                              "within_1e-3": bool(max(chk.values()) < 1e-3)}
+        except Exception as e:     # a report, never a gate
+            rec["gpu_outputs_vs_this_run"] = {"error": repr(e)}
+    return rec
+
+
+DTYPE_NOTES = {
+    "mix": "fp32 storage, forward products as split-bf16 (3 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate); backward on "
+           "v_mfma_f32_16x16x32_f16 with fp16 gradient storage -- two-term fp16 weights in DGRAD, two-term gradients on the residual "
+           "stream / sums of DGRADs, fp32 gradients + split products around the non-local softmax and in the head",
+    "fp16": "fp16 storage and v_mfma_f32_16x16x32_f16 operands end to end, fp32 accumulate, static power-of-two loss scale",
+    "bf16": "bf16 storage and v_mfma_f32_16x16x32_bf16 operands end to end, fp32 accumulate",
+    "split": "fp32 storage, every contraction as split-bf16 products (3 x v_mfma_f32_16x16x32_bf16 per product) in both directions",
+    "fp32": "fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s peak)",
+}
+
+
+def profile_step(eng, lr, hip, torch):
+    """one train step with HIP events around every GEMM launch (hip.PROFILE) -> ({family: sums}, [(sec, flops, tag)])"""
+    hip.PROFILE = []
+    try:
+        eng.train_step(lr)
+        torch.cuda.synchronize()
+    finally:
+        prof, hip.PROFILE = hip.PROFILE, None
+    fam, rows = collections.OrderedDict(), []
+    for mode, flops, e0, e1, tag, nbytes, family, mpp in prof or []:
+        sec = e0.elapsed_time(e1) * 1e-3
+        f = fam.setdefault(family, {"flops": 0.0, "mfma_flops": 0.0, "sec": 0.0, "n": 0, "bytes": 0.0, "att": 0.0})
+        peak = MFMA32_PEAK if family.endswith("_f32") else MFMA16_PEAK
+        f["flops"] += flops
+        f["mfma_flops"] += flops * mpp
+        f["sec"] += sec
+        f["n"] += 1
+        f["bytes"] += nbytes
+        # per-launch attainable time: whichever of the MFMA and the HBM roof binds THIS launch
+        f["att"] += max(flops * mpp / (peak * 1e12), nbytes / (HBM_PEAK_GBPS * 1e9))
+        rows.append((sec, flops, tag))
+    return fam, rows
+
+
+def dominant(fam, side):
+    """the family of this side (nt / tn) that the step spends most launch time in"""
+    keys = [k for k in fam if k.startswith(side)]
+    return max(keys, key=lambda k: fam[k]["sec"]) if keys else None
+
+
+def roof_record(key, fam, traffic, traffic_source, brief=False):
+    if key is None:
+        return None
+    f = fam[key]
+    fl, sec, n = f["flops"], f["sec"], f["n"]
+    base = MFMA32_PEAK if key.endswith("_f32") else MFMA16_PEAK
+    mpp = f["mfma_flops"] / fl if fl > 0 else 1.0        # MFMA instructions per algorithmic product (FLOP-weighted)
+    ach = fl / sec / 1e12 if sec > 0 else 0.0
+    peak = base / mpp
+    rec = collections.OrderedDict([
+        ("kernel", FAMILY_KERNELS[key]), ("bound", "mfma"), ("achieved", round(ach, 2)), ("peak", round(peak, 1)),
+        ("unit", "TFLOP/s"), ("frac", round(ach / peak, 4)),
+        ("mfma_per_product", round(mpp, 3)), ("mfma_rate_tflops", round(ach * mpp, 1)), ("mfma_peak_tflops", base),
+        ("launches_per_step", n), ("avg_launch_us", round(sec / max(n, 1) * 1e6, 2)),
+        ("gflop_per_step", round(fl / 1e9, 1)), ("ms_per_step", round(sec * 1e3, 3)),
+        ("traffic", traffic.get(key))])
+    if brief:
+        return rec
+    rec.update([
+        ("traffic_source", traffic_source),
+        ("source", "HIP events on the launch stream around every launch of ONE step behind the timed region (two-stream steady "
+                   "state); achieved = sum of algorithmic FLOP / sum of launch durations; peak = %.1f TFLOP/s dense MFMA / "
+                   "%.3g MFMA instructions per algorithmic product" % (base, mpp)),
+        ("algorithmic_bytes_per_launch", round(f["bytes"] / max(n, 1))),
+        ("algorithmic_GBps", round(f["bytes"] / sec / 1e9, 1) if sec > 0 else 0.0),
+        # sum over launches of max(MFMA FLOP / MFMA peak, algorithmic bytes / HBM peak): what the same launch list
+        # would take with every launch on its own roof (thin-K layers are HBM-bound)
+        ("attainable_ms_per_step", round(f["att"] * 1e3, 3)),
+        ("frac_of_attainable", round(f["att"] / sec, 4) if sec > 0 else 0.0)])
+    return rec
+
+
+def traffic_record(args, clips):
+    """HBM bytes per launch and family: PMC counters cannot be read from inside this process, so they come from the committed
+    rocprofv3 --pmc passes of THIS command line (profiles/hbm_traffic.json, made by tools/pmc_traffic.py).  A traffic file
+    is only valid for the kernels it was measured on: it carries the hash of csrc/ at measurement time, and anything else --
+    another workload / dtype / batch, an edited kernel, an unstamped file -- reports null and says why."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not (args.workload == "ava_r50_lfb_nl" and clips == 8 and os.path.exists(tpath)):
+        return {}, "none: no committed PMC pass for this workload/dtype/batch"
+    t = json.load(open(tpath))
+    if t.get("dtype") != args.dtype:
+        return {}, "none: profiles/hbm_traffic.json was measured with --dtype %s" % t.get("dtype")
+    if t.get("csrc_sha256") != kernel_source_hash():
+        return {}, "none: profiles/hbm_traffic.json was measured on other kernel sources (csrc hash differs)"
+    return ({k: v["bytes_per_launch"] for k, v in t.get("families", {}).items()},
+            "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this kernel source, "
+            "read side x2 per MI355X_MICROARCH.md; not measured in this run)")
 
 
 def main():
@@ -272,18 +420,11 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            # HIP-event brackets around every GEMM launch of the last timed step, each on the stream the
-            # launch goes to, in the normal two-stream schedule: the durations are the ones the step pays
-            # (and the ones a rocprofv3 kernel trace of this command reports).  Events cannot sit inside a
-            # replayed graph, so this one step is enqueued launch by launch -- inside the timed region.
-            hip.PROFILE = []
+    for i in range(args.steps):                  # the timed region: K steps, nothing else
         eng.train_step(lr)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof, hip.PROFILE = hip.PROFILE, None
     if world > 1:
         import torch.distributed as td
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -296,37 +437,12 @@ def main():
     host_ms = (time.perf_counter() - th0) * 1e3
     torch.cuda.synchronize()
     loss = float(eng.fetch("loss").reshape(-1)[0])
-
-    # ---- live roofline of the GEMM kernel families (this rank) -----------------------------------
-    fam = {"nt": [0.0, 0.0, 0, 0.0, 0.0], "tn": [0.0, 0.0, 0, 0.0, 0.0]}
-    rows = []
-    for mode, flops, e0, e1, tag, nbytes in prof or []:
-        f = fam["tn" if mode == hip.WGRAD else "nt"]
-        sec = e0.elapsed_time(e1) * 1e-3
-        f[0] += flops
-        f[1] += sec
-        f[2] += 1
-        f[3] += nbytes
-        # per-launch attainable time: whichever of the MFMA and the HBM roof binds THIS launch
-        f[4] += max(flops / (PEAK_TFLOPS[args.dtype] * 1e12), nbytes / (HBM_PEAK_GBPS * 1e9))
-        rows.append((sec, flops, tag))
-    # HBM bytes per launch: PMC counters cannot be read from inside this process, so they come from the
-    # committed rocprofv3 --pmc passes of THIS command line (profiles/*_hbm_traffic.json, made by
-    # scratch/pmc_traffic.py); any other workload / dtype / batch reports null and says why
-    # A traffic file is only valid for the kernels it was measured on: it carries the hash of csrc/ at measurement time
-    # (scratch/pmc_traffic.py) and anything else -- another workload, an edited kernel, an unstamped file -- reports null.
-    traffic, traffic_source = {}, "none: no committed PMC pass for this workload/dtype/batch"
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if args.workload == "ava_r50_lfb_nl" and clips == 8 and os.path.exists(tpath):
-        t = json.load(open(tpath))
-        if t.get("dtype", "bf16") != args.dtype:
-            traffic_source = "none: profiles/hbm_traffic.json was measured with --dtype %s" % t.get("dtype", "bf16")
-        elif t.get("csrc_sha256") == kernel_source_hash():
-            traffic = {"nt": t["gemm_nt"]["bytes_per_launch"], "tn": t["gemm_tn"]["bytes_per_launch"]}
-            traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on " \
-                             "this kernel source, read side x2 per MI355X_MICROARCH.md; not measured in this run)"
-        else:
-            traffic_source = "none: profiles/hbm_traffic.json was measured on other kernel sources (csrc hash differs)"
+    host_path = "recorded call list (Engine.STEP_TRACE)" if eng._trace is not None else "step objects"
+    # ---- live roofline of the GEMM kernel families (this rank): ONE more step, behind the timed region, with HIP-event
+    # brackets around every GEMM launch on the stream it goes to, in the normal two-stream schedule (events cannot sit
+    # inside a recorded / replayed step, so this step is enqueued launch by launch)
+    fam, rows = profile_step(eng, lr, hip, torch)
+    traffic, traffic_source = traffic_record(args, clips)
     if args.detail and rank == 0:
         with open(args.detail, "w") as fh:
             agg = collections.OrderedDict()
@@ -336,23 +452,9 @@ def main():
             fh.write("%10s %8s %6s %9s  %s\n" % ("total_us", "TFLOP/s", "calls", "GFLOP", "launch"))
             for tag, (sec, flops, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
                 fh.write("%10.1f %8.1f %6d %9.2f  %s\n" % (sec * 1e6, flops / sec / 1e12, n, flops / 1e9, tag))
-    peak = PEAK_TFLOPS[args.dtype]
-
-    def roof(key, kernel):
-        fl, sec, n, nb, att = fam[key]
-        ach = fl / sec / 1e12 if sec > 0 else 0.0
-        return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic.get(key), "traffic_source": traffic_source,
-                "source": "HIP events on the launch stream around every launch of the last timed step "
-                          "(two-stream steady state); sum of algorithmic FLOP / sum of launch durations",
-                "algorithmic_bytes_per_launch": round(nb / max(n, 1)),
-                "algorithmic_GBps": round(nb / sec / 1e9, 1) if sec > 0 else 0.0, "launches_per_step": n,
-                "avg_launch_us": round(sec / max(n, 1) * 1e6, 2), "gflop_per_step": round(fl / 1e9, 1),
-                "ms_per_step": round(sec * 1e3, 3),
-                # sum over launches of max(flops/MFMA peak, algorithmic bytes/HBM peak): what the same
-                # launch list would take with every launch on its own roof (thin-K layers are HBM-bound)
-                "attainable_ms_per_step": round(att * 1e3, 3),
-                "frac_of_attainable": round(att / sec, 4) if sec > 0 else 0.0}
+    step_flops = sum(f["flops"] for f in fam.values())
+    step_mfma_flops = sum(f["mfma_flops"] for f in fam.values())
+    nt_key, tn_key = dominant(fam, "nt"), dominant(fam, "tn")
 
     clips_total = clips * world * args.steps
     value = clips_total / elapsed
@@ -369,26 +471,31 @@ def main():
                                    ("%d RoIs/clip" % args.rois_per_clip) if args.rois_per_clip > 0 else
                                    ("RoIs/clip ~ U{1..5} (%d on rank 0)" % n_rois), args.frames, args.crop, args.crop)
                                 + ((" [" + " ".join(args.set) + "]") if args.set else ""),
-                    "parallelism": "dp%d" % world, "final_loss": loss}),
-        ("roofline", roof("nt", "gemm_nt_kernel (implicit-GEMM conv fprop+dgrad, attention NT GEMMs)")),
-        ("roofline_wgrad", roof("tn", "gemm_tn_kernel (implicit-GEMM conv wgrad, attention TN GEMMs)")),
+                    "parallelism": "dp%d" % world, "final_loss": loss,
+                    "arithmetic": DTYPE_NOTES[args.dtype]}),
+        ("roofline", roof_record(nt_key, fam, traffic, traffic_source)),
+        ("roofline_wgrad", roof_record(tn_key, fam, traffic, traffic_source)),
+        ("roofline_families", collections.OrderedDict((k, roof_record(k, fam, traffic, traffic_source, brief=True))
+                                                      for k in FAMILY_KERNELS if k in fam)),
         # algorithmic FLOP of every contraction the step launched (this rank's plan: convs, attention products, head) per
-        # wall second against the MFMA peak of all GPUs
-        ("model_flops_utilisation", round((fam["nt"][0] + fam["tn"][0]) * args.steps / elapsed / 1e12 / peak, 4)),
-        ("gflop_per_step_per_gpu", round((fam["nt"][0] + fam["tn"][0]) / 1e9, 1)),
+        # wall second against the 16-bit MFMA peak of all GPUs; and the same with every product counted as the MFMA
+        # instructions it is executed with (3 per split-bf16 product, 2 per two-term DGRAD product)
+        ("model_flops_utilisation", round(step_flops * args.steps / elapsed / 1e12 / MFMA16_PEAK, 4)),
+        ("mfma_flops_utilisation", round(step_mfma_flops * args.steps / elapsed / 1e12 / MFMA16_PEAK, 4)),
+        ("gflop_per_step_per_gpu", round(step_flops / 1e9, 1)),
         ("host_enqueue_ms_per_step", round(host_ms, 2)),
-        ("host_enqueue_path", "recorded call list (Engine.STEP_TRACE)" if eng._trace is not None else "step objects"),
+        ("host_enqueue_path", host_path),
     ])
     if eng.comm is not None:       # the gradient exchange of this job (None on a one-process run without a process group)
         out["allreduce"] = data_parallel_report(eng, args, lr, elapsed / args.steps, device)
-    # The parity-grade paths on the same workload, so that the numbers next to the parity claims exist:
-    #   split_path: fp32 storage, every contraction as split-bf16 products on the bf16 matrix cores (three MFMAs per product,
-    #               Engine.SPLIT_MATH; csrc/vlfb_gemm_split.hip) -- outputs AND every parameter gradient within 1e-3 of
-    #               the fp64 oracle at the benchmarked size (profiles/r03_parity_fullsize_*.txt)
-    #   fp32_path:  the same with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 matrix rate)
-    step_flops = fam["nt"][0] + fam["tn"][0]
+    out["parity"] = parity_record(args.workload, args.dtype)
 
-    def extra_path(dtype, steps, what, peak_tf):
+    # The other paths on the same workload, so that every number quoted next to a parity claim exists in THIS line:
+    #   mix_path   (when --dtype is not mix): the default path, see the module docstring
+    #   fp16_path:  16-bit storage and MFMA operands end to end -- the throughput path; gradients 15x outside the gate
+    #   split_path: fp32 storage, every contraction as split-bf16 products (three MFMAs per product) -- 25x inside it
+    #   fp32_path:  the same with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit matrix rate)
+    def extra_path(dtype, steps):
         eng2 = Engine(model, dtype, device=device, base_seed=cfg.RNG_SEED)
         eng2.plan(collections.OrderedDict((k, v.shape) for k, v in batch.items() if k in model.input_blob_names))
         eng2.feed_params(synth.params(model, seed=cfg.RNG_SEED))
@@ -396,40 +503,42 @@ def main():
             if k in model.input_blob_names:
                 eng2.feed(k, v)
         eng2.train_step(lr)
+        eng2.train_step(lr)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for _ in range(steps):
             eng2.train_step(lr)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t2) / max(steps, 1)
-        return {"value": round(clips / dt, 3), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": what,
-                "model_flops_utilisation": round(step_flops / dt / 1e12 / peak_tf, 4), "peak_tflops": peak_tf,
-                "parity": parity_record(args.workload, dtype)}
+        fam2, _ = profile_step(eng2, lr, hip, torch)
+        fl2 = sum(f["flops"] for f in fam2.values())
+        rec = {"value": round(clips / dt, 3), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+               "dtype": dtype, "arithmetic": DTYPE_NOTES[dtype],
+               "model_flops_utilisation": round(fl2 / dt / 1e12 / MFMA16_PEAK, 4),
+               "roofline": roof_record(dominant(fam2, "nt"), fam2, {}, "none: PMC passes are made for the default dtype", brief=True),
+               "roofline_wgrad": roof_record(dominant(fam2, "tn"), fam2, {}, "none: PMC passes are made for the default dtype", brief=True),
+               "parity": parity_record(args.workload, dtype)}
+        del eng2
+        return rec
 
-    out["parity"] = parity_record(args.workload, args.dtype)
-    if world == 1 and args.dtype not in ("fp32", "split", "mix"):
+    if world == 1:
         del eng
         torch.cuda.empty_cache()
-        for key, dtype, steps, skip, what, peak_tf in (
-                ("mix_path", "mix", args.mix_steps, args.no_mix_line,
-                 "fp32 storage + split-bf16 forward products (3 MFMAs per product), fp16 backward (fp16 gradient storage, two-term "
-                 "fp16 weights in DGRAD, fp32 / split products around the non-local softmax)", 2500.0 * 3.0 / (3 + 2 + 1)),
-                ("split_path", "split", args.split_steps, args.no_split_line,
-                 "fp32 storage + split-bf16 products on v_mfma_f32_16x16x32_bf16 (%d per product forward, %d backward)" % Engine.SPLIT_MATH,
-                 2500.0 * 3.0 / (Engine.SPLIT_MATH[0] + 2 * Engine.SPLIT_MATH[1])),   # 1/3 of a step's FLOP are forward
-                ("fp32_path", "fp32", args.fp32_steps, args.no_fp32_line,
-                 "fp32 storage + v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak)", PEAK_TFLOPS["fp32"])):
-            if skip:
+        for key, dtype, steps, skip in (("mix_path", "mix", args.mix_steps, args.no_mix_line),
+                                        ("fp16_path", "fp16", args.fp16_steps, args.no_fp16_line),
+                                        ("split_path", "split", args.split_steps, args.no_split_line),
+                                        ("fp32_path", "fp32", args.fp32_steps, args.no_fp32_line)):
+            if skip or dtype == args.dtype:
                 continue
             try:
-                out[key] = extra_path(dtype, steps, what, peak_tf)
+                out[key] = extra_path(dtype, steps)
                 torch.cuda.empty_cache()
             except Exception as e:   # a report, never a gate
                 out[key] = {"value": None, "error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, args.frames, args.crop, max(args.rois_per_clip, 3))
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.frames, args.crop, max(args.rois_per_clip, 3), args.dtype, device)
             except Exception as e:  # the baseline is a report, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

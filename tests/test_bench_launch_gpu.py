@@ -19,7 +19,7 @@ def _run(extra, env_extra):
         env.pop(k, None)
     env.update(env_extra)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--clips-per-gpu", "1", "--frames", "16",
-           "--crop", "64", "--no-cpu-baseline", "--no-fp32-line", "--no-split-line"] + extra
+           "--crop", "64", "--no-cpu-baseline", "--no-fp32-line", "--no-split-line", "--no-fp16-line"] + extra
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     return r
 
@@ -31,6 +31,12 @@ def test_self_launched_one_rank_rccl_job_prints_one_json_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    # the line is the gate-meeting path's: dtype mix, its dominant family (the split-bf16 NT kernels of the forward pass) priced
+    # against the MFMA peak / 3 instructions per product, every family of the step listed
+    assert out["dtype"] == "mix" and out["roofline"]["kernel"].startswith("gemm_nt_sp_kernel"), out["roofline"]
+    assert abs(out["roofline"]["peak"] - 2500.0 / 3) < 0.1 and abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-3
+    assert {"nt_split", "nt_16", "tn_16", "tn_split"} <= set(out["roofline_families"]), sorted(out["roofline_families"])
+    assert 1.0 < out["roofline_families"]["nt_16"]["mfma_per_product"] <= 2.0       # two-term DGRADs among the fp16 NT launches
     ar = out["allreduce"]
     assert ar["backend"] == "nccl" and ar["buckets"] >= 1 and ar["ranks"] == 1, ar
     # what makes an N > 1 line checkable: identical weights on every rank, the step without the exchange, the exchange alone

@@ -346,6 +346,36 @@ def test_avgpool_global_and_temporal(dtype):
         assert rel_err(to_ncthw(DX.float()), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_avgpool_bwd_from_an_fp32_gradient_into_two_terms(dtype):
+    """vlfb_avgpool_bwd_two_term (where the "mix" path's fp32 head gradient re-enters the 16-bit backward): hi + lo reproduce the
+    fp64 pool backward of the fp32 pooled gradient to ~2^-20 (the one-term kernel on the rounded gradient: ~2^-9 .. 2^-12, and
+    the SAME error at every position of a channel); hi is the rounding of the exact value, masked by the forward values"""
+    import ctypes as C
+    gen = torch.Generator().manual_seed(14)
+    code = hip.dtype_code(dtype)
+    N, Cc, T, H, W = 2, 64, 4, 5, 5
+    x = q(torch.randn(N, Cc, T, H, W, generator=gen), dtype)
+    X = gpu(to_nthwc(x), dtype)
+    for k in [(T, H, W), (T, 1, 1)]:  # head_helper.py:37-40 and :92-98
+        To, Ho, Wo = T - k[0] + 1, H - k[1] + 1, W - k[2] + 1
+        xd = x.double().requires_grad_(True)
+        y_ref = F.avg_pool3d(xd, k, (1, 1, 1))
+        dy = torch.randn(N, Cc, To, Ho, Wo, generator=gen) * 1e-3
+        (gx,) = torch.autograd.grad(y_ref, (xd,), dy.double())
+        ref = torch.where(x.double() > 0, gx, torch.zeros_like(gx))
+        d = hip.pool_desc(code, N, T, H, W, Cc, To, Ho, Wo, k, (1, 1, 1), (0, 0, 0))
+        HI, LO = (torch.empty(N, T, H, W, Cc, device=dev(), dtype=dtype) for _ in range(2))
+        DY = gpu(to_nthwc(dy))
+        hip.call("vlfb_avgpool_bwd_two_term", C.byref(d), hip.ptr(DY), hip.ptr(HI), hip.ptr(LO), hip.ptr(X))
+        two = to_ncthw(HI.double() + LO.double())
+        assert rel_err(two, ref) < (2e-6 if dtype == torch.float16 else 4e-5), rel_err(two, ref)
+        assert rel_err(to_ncthw(HI.float()), ref) < TOL[dtype]
+        ONE = torch.empty_like(HI)                      # the one-term path: rounded gradient in, one rounding out
+        hip.call("vlfb_avgpool_bwd", C.byref(d), gp(to_nthwc(q(dy, dtype)), dtype), hip.ptr(ONE), None, hip.ptr(X))
+        assert rel_err(two, ref) < 0.05 * rel_err(to_ncthw(ONE.float()), ref)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_softmax_fwd_bwd(dtype):
     gen = torch.Generator().manual_seed(17)

@@ -330,7 +330,19 @@ def conv_tag(d):
         d.st, d.sh, d.sw, d.dh, max(d.batch, 1), d.Ts, d.Hs, d.Ws)
 
 
-_KEEP_ARGS = []       # vlfb_conv_args structs handed to the library by reference (kept alive for recorded steps)
+def conv_family(d):
+    """(family, MFMA instructions per algorithmic product) of a launch, for the roofline records of bench.py: the kernels
+    that run a split-bf16 product issue 3 (6) MFMAs per product, an fp16 DGRAD with two-term weights (the "mix" path: doubled
+    outermost tap dimension of dilation 0) 2, everything else 1.  Families: nt_split / tn_split (csrc/vlfb_gemm_split.hip),
+    nt_16 / tn_16 (the 16-bit families), nt_f32 / tn_f32 (exact-fp32 MFMA)."""
+    side = "tn" if d.mode == WGRAD else "nt"
+    if d.math in (MATH_BF16X3, MATH_BF16X6):
+        return side + "_split", (6 if (d.math == MATH_BF16X6 and d.mode == FPROP) else 3)
+    if d.dtype == F32:
+        return side + "_f32", 1
+    return side + "_16", (2 if (d.mode == DGRAD and d.dt == 0 and d.kt == 2) else 1)
+
+
 
 # When a list, every conv_run is bracketed by HIP events on the launch stream and appended as
 # (mode, flops, start_event, end_event); bench.py uses it for the live roofline measurement.
@@ -351,9 +363,7 @@ def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspa
         fn = lib().vlfb_conv_run_args
         a = ConvArgs(ptr(A), ptr(B), ptr(P), ptr(O), ptr(bias), ptr(rowscale), ptr(R), ptr(mask), ptr(workspace), ws_bytes,
                      ptr(O_planes), ptr(dbias), ptr(R_lo), ptr(O_lo))
-        if tracing() is not None:
-            _KEEP_ARGS.append(a)            # (a recorded step replays the call with this struct; bounded: one per recorded call)
-        args = (C.byref(d), C.byref(a), stream())
+        args = (C.byref(d), C.byref(a), stream())   # (a recorded step keeps `a` alive through the byref object in its call list)
     elif dbias is not None:
         fn = lib().vlfb_conv_run_wgrad_bias
         args = (C.byref(d), ptr(A), ptr(P), ptr(O), ptr(dbias), ptr(rowscale), ptr(workspace), ws_bytes, stream())
@@ -367,7 +377,7 @@ def conv_run(d, A, B, P, O, bias=None, rowscale=None, R=None, mask=None, workspa
     rc = fn(*args)
     if prof is not None:
         e1.record()
-        prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d), conv_bytes(d, R is not None, mask is not None)))
+        prof.append((d.mode, conv_flops(d), e0, e1, conv_tag(d), conv_bytes(d, R is not None, mask is not None)) + conv_family(d))
     _check(rc, "vlfb_conv_run")
 
 
