@@ -507,6 +507,12 @@ int vlfb_lfb_append(const vlfb_lfb_desc* d, void* bank, int32_t* count, const vo
 int vlfb_lfb_sample_window(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
                            const int32_t* query, int64_t rows, int window, int max_per_step,
                            uint64_t seed, void* out, int out_dtype, vlfb_stream_t stream);
+/* The AVA window from a HOST-DRAWN table (stream-equal with the reference: the host makes the np.random.choice calls of
+ * ava.py:316-318, the device gathers): query [rows][2] = {video, centre step}; table [rows][window][max_per_step] = slot of
+ * step (centre - window/2 + j) that becomes output row j*max_per_step + k, or -1 for zeros. */
+int vlfb_lfb_gather_slots(const vlfb_lfb_desc* d, const void* bank, const int32_t* count, const int32_t* query,
+                          const int32_t* table, int64_t rows, int window, int max_per_step, void* out, int out_dtype,
+                          vlfb_stream_t stream);
 /* Frame-level sampling (charades.py:251-276): query [rows][3] = {video, first step, last step};
  * out [rows][window][dim] = the first `window` occupied steps of [first, last] packed to the
  * front, zeros behind. */

@@ -4,8 +4,9 @@ tests/golden/ref_aux.npz holds what tools/lfb_loader.py (construct_ava_lfb, cons
 lib/datasets/{ava,charades,epic}.py returned on synthetic banks when oracle/make_ref_aux_golden.py ran them from
 /root/reference.  Here the same feature batches go through vlfb.lfb_bank.DeviceBank (vlfb_lfb_append,
 vlfb_lfb_sample_compact / _packed / _window in csrc/vlfb_lfb.hip; fp32 bank, fp32 output) and must give the same banks and
-the same samples, exactly -- except the AVA draw, which is a counter-based key on the device and np.random.choice in the
-reference: there the occupied rows, their second and their distinctness are compared."""
+the same samples, exactly.  The AVA draw exists twice: a counter-based key on the device (sample_window: the reference's
+distribution, another stream -- occupied rows, their second and their distinctness are compared) and the reference's own
+np.random.choice stream drawn on the host with the device only gathering (sample_window_reference_draw: exact)."""
 import json
 import os
 
@@ -81,6 +82,37 @@ def test_ava_bank_built_on_the_device_and_the_draw_has_the_reference_structure()
             have = [tuple(r) for r in out[j * K:(j + 1) * K] if np.any(r != 0)]
             pool = [tuple(np.float32(f)) for f in ref.get(d["video"], {}).get(lower + j, [])]
             assert len(set(have)) == len(have) and all(h in pool for h in have), (i, j)
+
+
+def test_ava_window_with_the_references_own_random_stream_is_the_references_sample():
+    """DeviceBank.sample_window_reference_draw (vlfb_lfb_gather_slots): the host makes the np.random.choice calls of
+    ava.py:316-318 in the reference's order, the device gathers -- seeded as the fixture generator seeded the reference
+    (np.random.seed(np_seed) in front of ava.sample_lfb), the sampled bank IS the reference's, element for element; two boxes
+    of one clip share the draw (ava_data_input.py:191-192)"""
+    from vlfb import lfb_bank as lb
+    case = _case("ava")
+    D, K, W = case["dim"], case["max_per_step"], case["window"]
+    meta = Z["lfb_ava_meta"]
+    secs = np.round(meta[:, 1]).astype(np.int64)
+    vids = np.round(meta[:, 0]).astype(np.int64)
+    cap = int(max(np.unique(np.stack([vids, secs], 1), axis=0, return_counts=True)[1]))
+    bank = lb.DeviceBank(int(vids.max()) + 1, int(secs.max() - secs.min() + 1), cap, D, "fp32", "cuda:0", int(secs.min()))
+    at = 0
+    for n in Z["lfb_ava_batch_rows"].reshape(-1):
+        n = int(n)
+        bank.append_ava(torch.as_tensor(Z["lfb_ava_feats"][at:at + n].reshape(n, D, 1, 1, 1)), meta[at:at + n])
+        at += n
+    for i, d in enumerate(case["draws"]):
+        np.random.seed(d["np_seed"])
+        out = bank.sample_window_reference_draw([d["video"], d["video"]], [d["sec"], d["sec"]], [i, i], W, K,
+                                                out_dtype=torch.float32).cpu().numpy()
+        want = Z["lfb_ava_sample_%d" % i]
+        assert np.array_equal(out[0].astype(np.float64), want), i
+        assert np.array_equal(out[1], out[0])              # the second box of the clip: the same bank, no second draw
+    # a table entry outside the occupied slots reads as zeros, not as stale memory
+    rng = np.random.RandomState(0)
+    out = bank.sample_window_reference_draw([0], [int(secs.min()) - 50], [0], W, K, rng=rng, out_dtype=torch.float32)
+    assert float(out.abs().sum()) == 0.0
 
 
 def test_epic_banks_sampled_on_the_device():

@@ -142,6 +142,26 @@ __global__ void lfb_sample_window_kernel(BankP b, const char* __restrict__ bank,
   }
 }
 
+// The same output from a HOST-DRAWN table: table[r][j][k] = slot of step (centre - window/2 + j) that goes to output row
+// j*K + k, or -1 (zeros).  For a run that has to reproduce the reference's sample STREAM (np.random.choice in
+// ava.py:316-318), not just its distribution: the host draws exactly as the reference does, the device only gathers.
+__global__ void lfb_gather_slots_kernel(BankP b, const char* __restrict__ bank, const int32_t* __restrict__ count,
+                                        const int32_t* __restrict__ query, const int32_t* __restrict__ table, int window,
+                                        int K, void* out, int odt) {
+  const int j = blockIdx.x, r = blockIdx.y;
+  const int video = query[2 * r], centre = query[2 * r + 1];
+  const int step = centre - window / 2 + j;
+  const bool ok = key_ok(b, video, step);
+  const long long cell = ok ? (long long)video * b.n_steps + step : 0;
+  const int n = ok ? count[cell] : 0;
+  const long long obase = ((long long)r * window + j) * K;
+  for (int k = 0; k < K; ++k) {
+    const int slot = table[obase + k];
+    if (slot >= 0 && slot < n) row_copy(out, odt, (obase + k) * b.dim, bank, b.dtype, (cell * b.capacity + slot) * (long long)b.dim, b.dim);
+    else row_copy(out, odt, (obase + k) * b.dim, nullptr, 0, 0, b.dim);
+  }
+}
+
 // frame-level banks (Charades, EPIC verb: one feature per step; EPIC noun: up to `max_per_step` detector
 // features per step): walk the steps of [first, last] in order, take the first min(count, max_per_step)
 // features of every occupied step, pack them to the front of the `window` output rows, zeros behind
@@ -225,6 +245,22 @@ extern "C" int vlfb_lfb_sample_window(const vlfb_lfb_desc* d, const void* bank, 
   hipLaunchKernelGGL(lfb_sample_window_kernel, dim3((unsigned)window, (unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, b, (const char*)bank, count, query, window, max_per_step, seed, out, out_dtype);
   return check_launch("lfb_sample_window");
+}
+
+extern "C" int vlfb_lfb_gather_slots(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,
+                                     const int32_t* query, const int32_t* table, int64_t rows, int window, int max_per_step,
+                                     void* out, int out_dtype, vlfb_stream_t stream) {
+  BankP b;
+  int rc = check_desc(d, &b);
+  if (rc != VLFB_OK) return rc;
+  VLFB_REQUIRE(bank && count && query && table && out, "lfb_gather_slots: NULL buffer");
+  VLFB_REQUIRE(dtype_ok(out_dtype), "lfb_gather_slots: out dtype must be f32, bf16 or f16");
+  VLFB_REQUIRE(window > 0 && max_per_step > 0, "lfb_gather_slots: need window > 0, max_per_step > 0");
+  VLFB_REQUIRE(rows >= 0 && rows < 65536, "lfb_gather_slots: rows out of range");
+  if (rows == 0) return VLFB_OK;
+  hipLaunchKernelGGL(lfb_gather_slots_kernel, dim3((unsigned)window, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, b,
+                     (const char*)bank, count, query, table, window, max_per_step, out, out_dtype);
+  return check_launch("lfb_gather_slots");
 }
 
 extern "C" int vlfb_lfb_sample_packed(const vlfb_lfb_desc* d, const void* bank, const int32_t* count,

@@ -29,7 +29,11 @@ def check_nan_losses(model=None):
 
     Here the loss step keeps its last 64 values in a device ring, so the loop may call this every
     N <= 64 iterations and still see every step's loss with a single sync.  The reference logs and
-    `os._exit(0)`s; a library raises instead.  Returns the losses it inspected."""
+    `os._exit(0)`s; a library raises instead (FloatingPointError).  Returns the losses it inspected.
+
+    CONTRACT in a data-parallel job (a process group exists): the verdict is COLLECTIVE -- one all-reduce + one host sync --
+    so every rank must call this, and at the same iterations; a call on rank 0 only, or at rank-dependent iterations,
+    deadlocks where the reference's per-process check was harmless."""
     import math
     if model is not None:
         engines = [model.engine]

@@ -164,6 +164,7 @@ _SIGS = {
     "vlfb_lfb_append": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, C.c_int, _P, _I64, _P, _P]),
     "vlfb_lfb_sample_window": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, C.c_int, C.c_uint64,
                                          _P, C.c_int, _P]),
+    "vlfb_lfb_gather_slots": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P, C.c_int, _P]),
     "vlfb_lfb_sample_compact": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),
     "vlfb_lfb_sample_packed": (C.c_int, [C.POINTER(LfbDesc), _P, _P, _P, _I64, C.c_int, C.c_int, _P, C.c_int, _P]),
 }

@@ -172,6 +172,45 @@ class DeviceBank(object):
         torch.cuda.current_stream().synchronize()
         return out
 
+    def sample_window_reference_draw(self, videos, secs, sample_ids, window, max_per_step, rng=None, out=None, out_dtype=None):
+        """AVA (ava.py:300-323) with the reference's OWN random stream: the host makes exactly the calls `sample_lfb` makes --
+        per clip (rows with one sample id share a draw, clips in order of first appearance, as ava_data_input.py:191-192
+        builds the bank once per clip and repeats it per box), per occupied second of the window in ascending order, one
+        `rng.choice(range(num_feat), min(num_feat, K), replace=False)` -- and the device gathers (vlfb_lfb_gather_slots).
+        With `rng = np.random` seeded as the reference seeds it (np.random.seed(cfg.RNG_SEED)) and the same call order the
+        sampled banks are the reference's, element for element.  `sample_window` (a counter-based key per draw, no host
+        work, no sync) has the same DISTRIBUTION but another stream.  Needs the step counts on the host: one small D2H
+        copy per call."""
+        rng = np.random if rng is None else rng
+        rows = len(videos)
+        vid = self._rows_of(videos)
+        centre = np.asarray(secs).astype(np.int64).reshape(-1) - self.step_base
+        ids = np.asarray(sample_ids).astype(np.int64).reshape(-1)
+        cnt = self.counts()
+        K = int(max_per_step)
+        table = np.full((rows, int(window), K), -1, dtype=np.int32)
+        drawn = {}
+        for r in range(rows):
+            key = int(ids[r])
+            if key not in drawn:
+                t = np.full((int(window), K), -1, dtype=np.int32)
+                lower = int(centre[r]) - int(window) // 2
+                for j in range(int(window)):
+                    si = lower + j
+                    n = int(cnt[vid[r], si]) if (0 <= vid[r] < cnt.shape[0] and 0 <= si < cnt.shape[1]) else 0
+                    if n > 0:                       # `if si in in_video_lfb`
+                        used = min(n, K)
+                        t[j, :used] = rng.choice(range(n), used, replace=False)
+                drawn[key] = t
+            table[r] = drawn[key]
+        qd = self._dev_i32(np.stack([vid, centre], axis=1))
+        td = self._dev_i32(table.reshape(-1))
+        out = self._out(out, (rows, int(window) * K, self.dim), out_dtype)
+        hip.call("vlfb_lfb_gather_slots", C.byref(self.desc), hip.ptr(self.bank), hip.ptr(self.count), hip.ptr(qd), hip.ptr(td),
+                 rows, int(window), K, hip.ptr(out), hip.dtype_code(out.dtype))
+        torch.cuda.current_stream().synchronize()
+        return out
+
     def sample_frames(self, videos, center_frames, window, clips_per_second, out=None, out_dtype=None):
         """Charades (charades.py:251-276): -> (N, window, dim), the first `window` bank frames inside
         [begin, end] around each clip centre, packed to the front"""
