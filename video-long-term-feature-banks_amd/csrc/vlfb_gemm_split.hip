@@ -102,7 +102,7 @@ __device__ __forceinline__ long long s2_row_pos(const GP& p, int m, int ph, int 
 template <int BN, int FN, int FM, bool S2 = false>
 __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN][FM], char* smem, int m0, int n0, int z, int tid,
                                             int wm, int wn, int l15, int g, int s2_ph = 0, int s2_pw = 0) {
-  constexpr int BM = 128, NTHR = 256, WM = 64, WN = BN / 2;
+  constexpr int BM = 128, NTHR = 256, WM = FM * 16, WN = FN * 16;      // (the wave tile: 64 x BN/2 as 2 x 2 waves, 32 x BN as 4 x 1)
   const int mrows = S2 ? p.s2_mq : p.M;
   char* Ob = p.O + (long long)z * p.o_bs * 4;
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 4 : nullptr;
@@ -174,16 +174,20 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
 // =============================================================================================
 // NT: O[m][n] = sum_k X[m][k] * W[n][k];  X fp32 (gathered), W = NPL bf16 planes, O / R / Mask fp32
 // =============================================================================================
-template <int NPL, int BN, bool IDENT, bool DGRAD, bool PACKW, bool UT, bool S2 = false>
+// NWN: waves along n.  2 = 2 (m) x 2 (n) waves of 64 x BN/2; 1 = 4 x 1 waves of 32 x BN: every activation fragment is then
+// split by ONE wave instead of two (the split is the VALU work of the loop: 2.0 -> 1.0 VALU per MFMA at BN = 128, 4.0 -> 2.0
+// at BN = 64), for 1.25x the LDS fragment reads (the bf16 weight planes are read by all four waves).
+template <int NPL, int BN, bool IDENT, bool DGRAD, bool PACKW, bool UT, bool S2 = false, int NWN = 2>
 __global__ __launch_bounds__(256) void gemm_nt_sp_kernel(const GP p) {
   static_assert(!UT || (!IDENT && !PACKW), "UT is for gathered, unpacked operands");
   static_assert(!S2 || (UT && DGRAD), "S2 is the scalar-cursor DGRAD over the parity classes of a (1, 2, 2)-strided conv");
+  static_assert(NWN == 1 || NWN == 2, "wave layouts: 2 x 2 or 4 x 1");
   typedef float T;
-  constexpr int BM = 128, NTHR = 256, NWN = 2;
+  constexpr int BM = 128, NTHR = 256;
   constexpr int EPC = 4;                          // fp32 elements per 16-byte chunk of the activation operand
   constexpr int RPPS_A = NTHR / 8, A_IT = BM / RPPS_A;       // 32 rows per pass, 4 passes
   constexpr int RPPS_B = NTHR / 4, B_ITP = BN / RPPS_B;      // 64 rows per pass; 2 | 1 passes per plane
-  constexpr int WM = BM / 2, WN = BN / NWN;
+  constexpr int WM = BM / (4 / NWN), WN = BN / NWN;
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
   constexpr int BUF = A_BYTES + NPL * BP_BYTES;
@@ -833,21 +837,30 @@ int launch_sp(K kernel, dim3 grid, size_t lds, const GP& gp, hipStream_t s, int 
   return check_launch("split-bf16 conv kernel");
 }
 
-template <int NPL, int BN>
-int launch_nt_sp_shape(const GP& gp, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s) {
+template <int NPL, int BN, int NWN>
+int launch_nt_sp_waves(const GP& gp, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s) {
   switch (kind) {
-    case 0: return launch_sp(gemm_nt_sp_kernel<NPL, BN, true, false, false, false>, grid, lds, gp, s);
-    case 1: return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, true>, grid, lds, gp, s)
-                      : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, false>, grid, lds, gp, s);
+    case 0: return launch_sp(gemm_nt_sp_kernel<NPL, BN, true, false, false, false, false, NWN>, grid, lds, gp, s);
+    case 1: return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, true, false, NWN>, grid, lds, gp, s)
+                      : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, false, false, false, NWN>, grid, lds, gp, s);
     case 2:
       if constexpr (NPL == 2) {
-        if (gp.s2) return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true, true>, grid, lds, gp, s);
+        if (gp.s2) return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true, true, NWN>, grid, lds, gp, s);
       }
       if (gp.s2) return set_error(VLFB_ERR_UNSUPPORTED, "conv: class-major strided DGRAD exists for three-term products only");
-      return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true>, grid, lds, gp, s)
-                : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, false>, grid, lds, gp, s);
-    default: return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, true, false>, grid, lds, gp, s);
+      return ut ? launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, true, false, NWN>, grid, lds, gp, s)
+                : launch_sp(gemm_nt_sp_kernel<NPL, BN, false, true, false, false, false, NWN>, grid, lds, gp, s);
+    default: return launch_sp(gemm_nt_sp_kernel<NPL, BN, false, false, true, false, false, NWN>, grid, lds, gp, s);
   }
+}
+template <int NPL, int BN>
+int launch_nt_sp_shape(const GP& gp, int kind, bool ut, dim3 grid, size_t lds, hipStream_t s) {
+  // Three-term products (NPL = 2): 4 x 1 waves of 32 x BN -- measured against 2 x 2 waves of 64 x BN/2 on the benchmarked
+  // `mix` step (same box, alternating runs): every launch family faster or equal (64-column res2 convs -16 %, gathered 3x3 /
+  // 3x1x1 -6..7 %, plain 1x1x1 rows 0..-4 %), forward NT time 19.26 -> 18.48 ms, 233.0 -> 236.0 clips/s; bit-identical (the
+  // accumulation order of an output element does not depend on which wave owns it).  Six-term products keep 2 x 2: a
+  // 32 x 128 wave tile would hold three weight planes x eight fragments in registers.
+  return launch_nt_sp_waves<NPL, BN, NPL == 2 ? 1 : 2>(gp, kind, ut, grid, lds, s);
 }
 
 // ---- fp32 -> bf16 term planes (attention operands; optionally transposed per batch element) -----------------
