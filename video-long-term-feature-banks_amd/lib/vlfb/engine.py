@@ -2021,7 +2021,7 @@ class Engine(object):
         blobs whose gradient stays in fp32 (Blob.grad_f32): walk back from the classifier's input through dropout / concat /
         RoIAlign + max; the output of the average pool that reads res5 is the last one (its PoolStep casts down).  A blob
         is only marked when every step that contributes to its gradient can write fp32."""
-        self.head_f32 = []
+        self.head_f32, self.head_f32_fbo = [], []
         if not (self.train and self.mix):
             return
         fcs = [st for st in self.steps if isinstance(st, FCStep)]
