@@ -1102,10 +1102,23 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const GP p) {
 // row); its G lane groups stride over the splits (4 loads in flight each) and fold through LDS; group
 // 0 applies the epilogue.  Many splits (skinny weights: few columns, hundreds of slabs) use narrow
 // 16-column workgroups so the grid still covers the chip.
+// ws_b / dbias / nb (optional): the bias-gradient partial rows of the same split launch (GP::dbias: ws_b[split][nb] behind the
+// weight slabs) are folded by the workgroups past the weight part of the grid, splits in order -- one launch per split WGRAD
+// instead of two (the stand-alone wgrad_bias_reduce_kernel stays for the families whose column sums are a separate pass).
 template <typename OutT, int G, int CL>
 __global__ __launch_bounds__(CL * G) void wgrad_reduce_kernel(const float* ws, char* O, const float* rowscale,
                                                               long long n, int ldo, int splits, float alpha,
-                                                              int accumulate) {
+                                                              int accumulate, const float* __restrict__ ws_b = nullptr,
+                                                              float* __restrict__ dbias = nullptr, int nb = 0, int wblocks = 0) {
+  if (ws_b != nullptr && (int)blockIdx.x >= wblocks) {
+    const int i = ((int)blockIdx.x - wblocks) * (CL * G) + (int)threadIdx.x;
+    if (i < nb) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += ws_b[(long long)k * nb + i];
+      dbias[i] = s * alpha * (rowscale ? rowscale[i] : 1.f);
+    }
+    return;
+  }
   __shared__ float4 part[G > 1 ? (G - 1) * CL : 1];
   const int lane = threadIdx.x % CL, g = threadIdx.x / CL;
   const long long i = ((long long)blockIdx.x * CL + lane) * 4;
@@ -1888,17 +1901,21 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
     if (rc != VLFB_OK) return rc;
     hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->Cn + 63) / 64)), dim3(64), 0, s, part, dbias, rowscale,
                        d->Cn, slabs, d->alpha);
-  } else if (dbias && pl.splits > 1) {
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->Cn + 63) / 64)), dim3(64), 0, s,
-                       g.ws + (long long)pl.splits * ((long long)d->Cn * g.ldo), dbias, rowscale, d->Cn, pl.splits, d->alpha);
   }
+  // (a launch with fused column sums and splits: its bias partial rows are folded by the weight reduce below)
+  const float* bias_rows = (dbias && pl.bias_fused && pl.splits > 1) ? g.ws + (long long)pl.splits * ((long long)d->Cn * g.ldo) : nullptr;
   if (pl.splits > 1) {
     const long long n = (long long)d->Cn * g.K;
     VLFB_REQUIRE(n % 4 == 0, "conv: split WGRAD output size must be a multiple of 4");
     const int G = pl.splits >= 32 ? 16 : pl.splits >= 8 ? 4 : 1;
-#define VLFB_REDUCE(OT, GG, CC)                                                                       \
-  hipLaunchKernelGGL((wgrad_reduce_kernel<OT, GG, CC>), dim3((unsigned)((n / 4 + CC - 1) / CC)),     \
-                     dim3(CC * GG), 0, s, g.ws, g.O, rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate)
+#define VLFB_REDUCE(OT, GG, CC)                                                                                         \
+  do {                                                                                                                  \
+    const unsigned wblocks = (unsigned)((n / 4 + CC - 1) / CC);                                                         \
+    const unsigned bblocks = bias_rows ? (unsigned)((d->Cn + CC * GG - 1) / (CC * GG)) : 0u;                            \
+    hipLaunchKernelGGL((wgrad_reduce_kernel<OT, GG, CC>), dim3(wblocks + bblocks), dim3(CC * GG), 0, s, g.ws, g.O,     \
+                       rowscale, n, g.ldo, pl.splits, d->alpha, d->accumulate, bias_rows, bias_rows ? dbias : nullptr,  \
+                       (int)d->Cn, (int)wblocks);                                                                       \
+  } while (0)
     if (d->out_dtype == VLFB_F32) {
       if (G == 16) VLFB_REDUCE(float, 16, 16); else if (G == 4) VLFB_REDUCE(float, 4, 64); else VLFB_REDUCE(float, 1, 64);
     } else if (d->out_dtype == VLFB_F16) {
