@@ -110,7 +110,12 @@ int vlfb_affine_nd_bwd(const float* dy, const float* scale, float* dx,
 enum { VLFB_CONV_FPROP = 0, VLFB_CONV_DGRAD = 1, VLFB_CONV_WGRAD = 2 };
 enum { VLFB_BIAS_NONE = 0, VLFB_BIAS_COL = 1, VLFB_BIAS_ROW = 2 };
 enum { VLFB_ALGO_AUTO = 0, VLFB_ALGO_TILE128 = 1, VLFB_ALGO_PIPE256 = 2, VLFB_ALGO_STREAM = 3,
-       VLFB_ALGO_CLASSES = 4 /* split-math DGRAD of a (1,2,2)-strided conv: force the parity-class walk (AUTO takes it for kh*kw > 1) */ };
+       VLFB_ALGO_CLASSES = 4 /* split-math DGRAD of a (1,2,2)-strided conv: force the parity-class walk (AUTO takes it for kh*kw > 1) */,
+       /* 16-bit DGRAD of a (1,2,2)-strided 1x1x1 conv (the projection shortcut of res3_0 / res4_0, resnet_helper.py:86-103) as
+        * an ACCUMULATE over the rows it touches: only the input positions the conv reads (even h, even w: a quarter of the
+        * rows) are computed and written, every other row of O is LEFT AS IT IS.  For a caller that passes R = O holding an
+        * earlier contribution to the same gradient (in-place accumulate; R_lo = O_lo likewise), or has zero-filled O. */
+       VLFB_ALGO_CLASS0 = 5 };
 
 typedef struct vlfb_conv_desc {
   int32_t mode;

@@ -115,3 +115,74 @@ def test_class_major_strided_dgrad_split_bf16(case):
     want = torch.where(mask_src.double() > 0, gx + add_src.double(), torch.zeros_like(gx))
     assert rel_err(to_ncthw(got[hip.ALGO_CLASSES][0][0]), want) < 2e-5
     assert rel_err(to_ncthw(got[hip.ALGO_CLASSES][3][0]), 0.5 * gx) < 2e-5
+
+
+SHORTCUTS = {
+    # name: (N, Cin, Cout, T, H, W)   1x1x1, stride (1, 2, 2), no padding: the projection shortcuts of res3_0 / res4_0
+    "res3_like": (2, 256, 512, 2, 12, 20),
+    "res4_like_ragged_tiles": (1, 192, 128, 3, 10, 14),      # the class's rows do not fill whole 128-row tiles
+}
+
+
+@pytest.mark.parametrize("two_term", [False, True], ids=["one_term", "two_term_weights"])
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", sorted(SHORTCUTS))
+def test_strided_shortcut_dgrad_as_an_in_place_accumulate(case, tdt, two_term):
+    """algo = CLASS0: the DGRAD of a strided 1x1x1 conv computes and writes ONLY the rows the conv reads (even h, even w) and
+    leaves every other row of O as it was.  Run in place on a buffer that holds an earlier contribution (R = O, and R_lo =
+    O_lo for a two-term gradient) it must give, bit for bit, what the ordinary launch gives with that contribution as its
+    residual operand -- on every row: a row the conv does not read is `0 + R`, i.e. untouched.  Also with the doubled term
+    dimension of two-term fp16 weights (kt = 2, dt = 0: the `mix` path's DGRAD form)."""
+    from vlfb import hip
+    hip.lib()
+    hdt = hip.dtype_code(tdt)
+    N, Cin, Cout, T, H, W = SHORTCUTS[case]
+    Ho, Wo = H // 2, W // 2
+    gen = torch.Generator().manual_seed(sum(map(ord, case)) + 3)
+    w = torch.randn(Cout, Cin, generator=gen) / math.sqrt(Cin)
+    dy = q(torch.randn(N, Cout, T, Ho, Wo, generator=gen), tdt)
+    first = q(torch.randn(N, Cin, T, H, W, generator=gen), tdt)
+    first_lo = q(torch.randn(N, Cin, T, H, W, generator=gen) * 2.0 ** -12, tdt)
+    G = to_nthwc(dy).to(dev(), tdt)
+    terms = 2 if two_term else 1
+    if two_term:                                     # [Cin][term][Cout]: hi + lo of the weight
+        wh = q(w, tdt)
+        wl = q(w - wh.float(), tdt)
+        Wd = torch.stack([wh.t(), wl.t()], 1).contiguous().to(dev(), tdt)
+    else:
+        Wd = q(w, tdt).t().contiguous().to(dev(), tdt)
+    geom = dict(kt=terms, kh=1, kw=1, st=1, sh=2, sw=2, pt=0, ph=0, pw=0, dt=0 if two_term else 1, dh=1, dw=1)
+    rows = dict(N=N, Tr=T, Hr=H, Wr=W, Ts=T, Hs=Ho, Ws=Wo)
+    view = torch.int16
+    full = hip.conv_desc(mode=hip.DGRAD, dtype=hdt, out_dtype=hdt, Cs=Cout, Cn=Cin, algo=hip.ALGO_TILE128, **rows, **geom)
+    sparse = hip.conv_desc(mode=hip.DGRAD, dtype=hdt, out_dtype=hdt, Cs=Cout, Cn=Cin, algo=hip.ALGO_CLASS0, **rows, **geom)
+    assert "class0" in hip.conv_plan(sparse)
+    R = to_nthwc(first).to(dev(), tdt)
+    R_lo = to_nthwc(first_lo).to(dev(), tdt)
+    # (a) one-term gradient
+    want = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt)
+    hip.conv_run(full, G, Wd, None, want, R=R)
+    got = R.clone()
+    hip.conv_run(sparse, G, Wd, None, got, R=got)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(view), want.view(view))
+    # rows the conv does not read: exactly the first contribution
+    odd = torch.ones(H, W, dtype=torch.bool)
+    odd[0::2, 0::2] = False
+    assert torch.equal(got[:, :, odd].view(view), R[:, :, odd].view(view))
+    # (b) two-term gradient: hi and lo in place
+    want, want_lo = (torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt) for _ in range(2))
+    hip.conv_run(full, G, Wd, None, want, R=R, R_lo=R_lo, O_lo=want_lo)
+    got, got_lo = R.clone(), R_lo.clone()
+    hip.conv_run(sparse, G, Wd, None, got, R=got, R_lo=got_lo, O_lo=got_lo)
+    torch.cuda.synchronize()
+    ev = ~odd
+    assert torch.equal(got[:, :, ev].view(view), want[:, :, ev].view(view))
+    assert torch.equal(got_lo[:, :, ev].view(view), want_lo[:, :, ev].view(view))
+    assert torch.equal(got[:, :, odd].view(view), R[:, :, odd].view(view)) and torch.equal(got_lo[:, :, odd].view(view), R_lo[:, :, odd].view(view))
+    # and against fp64: the sum of both contributions
+    wd = (w if not two_term else (wh.double() + wl.double())).double()
+    xd = torch.zeros(N, Cin, T, H, W, dtype=torch.float64, requires_grad=True)
+    gx, = torch.autograd.grad(F.conv3d(xd, wd.reshape(Cout, Cin, 1, 1, 1), None, (1, 2, 2)), xd, dy.double())
+    tol = 1e-2 if tdt == torch.bfloat16 else 2e-3
+    assert rel_err(to_ncthw(got.double() + got_lo.double()), gx + first.double() + first_lo.double()) < tol

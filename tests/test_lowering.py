@@ -240,6 +240,29 @@ def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_n
     assert sorted({s.wcode for s in convs}) == sorted([hip.MIX, hip.MIX_W2])    # (one weight-prep batch per format: Engine._wprep_table)
 
 
+def test_strided_projection_shortcuts_run_their_dgrad_as_an_in_place_accumulate():
+    """Engine._plan_sparse_shortcut_dgrads (16-bit backward: fp16, bf16, mix): the DGRADs of res3_0 / res4_0 branch1 -- 1x1x1,
+    stride (1, 2, 2) -- are planned as hip.ALGO_CLASS0 (only the rows the conv reads) and their backward step comes BEHIND
+    branch2a's, the other contributor to the block-input gradient, so that they accumulate in place; the stride-1 shortcuts of
+    res2_0 / res5_0 and the fp32-storage backward of `split` are untouched"""
+    from vlfb import hip
+    from vlfb.engine import ConvStep
+    for dtype in ("mix", "fp16"):
+        cfg, m, eng = plan("ava_r50_lfb_nl", dtype=dtype)
+        convs = {s.wname: s for s in eng.steps if isinstance(s, ConvStep)}
+        order = [s.wname for s in eng.bwd_steps if isinstance(s, ConvStep)]
+        for blk in ("res3_0", "res4_0"):
+            sc = convs[blk + "_branch1_w"]
+            assert sc.sparse_dgrad and sc.d_d.algo == hip.ALGO_CLASS0 and sc.d_d_full.algo == hip.ALGO_AUTO, blk
+            assert "class0" in hip.conv_plan(sc.d_d) and hip.conv_flops(sc.d_d) == hip.conv_flops(sc.d_d_full)
+            assert order.index(blk + "_branch1_w") == order.index(blk + "_branch2a_w") + 1, order
+            assert order.index(blk + "_branch2c_w") < order.index(blk + "_branch2a_w")
+        for blk in ("res2_0", "res5_0"):
+            assert not getattr(convs[blk + "_branch1_w"], "sparse_dgrad", False) and convs[blk + "_branch1_w"].d_d_full is None
+    cfg, m, eng = plan("ava_r50_lfb_nl", dtype="split")
+    assert not any(getattr(s, "sparse_dgrad", False) for s in eng.steps)
+
+
 def test_product_code_never_imports_the_oracle():
     import os
     import re

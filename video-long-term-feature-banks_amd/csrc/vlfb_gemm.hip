@@ -1315,6 +1315,22 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       g.tiles_m = 4 * g.s2_tpc;
       pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), 1, 1);
     }
+    // The strided 1x1x1 shortcut (VLFB_ALGO_CLASS0): only class (0, 0) meets its one tap, so ONLY that class's tiles are
+    // launched -- a quarter of the rows, the whole k-loop, no epilogue-only tiles -- and the other rows of O stay as the
+    // caller left them (the engine runs this DGRAD as the SECOND contribution to the block-input gradient, in place on the
+    // first).  The "classes" form above lost on these convs because three of four tiles were epilogue-only passes.
+    if (d->algo == VLFB_ALGO_CLASS0) {
+      const bool ok = d->mode == VLFB_CONV_DGRAD && !pl->sp && !pl->ident && !pl->packw && batch == 1 && d->kh * d->kw == 1 &&
+                      is16(d->dtype) && d->out_dtype == d->dtype && d->st == 1 && d->sh == 2 && d->sw == 2 && d->ph == 0 &&
+                      d->pw == 0 && (d->dt == 1 || d->dt == 0) && d->Hr % 2 == 0 && d->Wr % 2 == 0 &&
+                      ((long long)d->Cs * es) % 128 == 0 && d->bias_mode == VLFB_BIAS_NONE && !d->relu && g.vec_epi;
+      VLFB_REQUIRE(ok, "conv: algo = CLASS0 is the 16-bit DGRAD of an unpadded (1, 2, 2)-strided 1x1x1 conv (even H, W; whole 128-byte taps)");
+      g.s2 = 1;
+      g.s2_mq = (int)(M / 4);
+      g.s2_tpc = (g.s2_mq + pl->bm - 1) / pl->bm;
+      g.tiles_m = g.s2_tpc;                       // class (0, 0) only
+      pl->grid = dim3((unsigned)(g.tiles_m * g.tiles_n), 1, 1);
+    }
     // The split-bf16 form of the same walk (gemm_nt_sp_kernel<.., S2>): a scalar tap cursor over the class's taps instead
     // of the per-lane decode.  Measured in the step (8 clips): res3_0 2b 502 -> 321 us, res4_0 2b 486 -> 240 us.  The 1x1x1
     // shortcuts stay on the plain walk here too (VLFB_SPLIT_S2_1X1=1 to try: 466 -> 513 us, 386 -> 380 us).
@@ -1771,7 +1787,7 @@ extern "C" int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64
     else if (h16 && pl.nts) fam = "nt_stream";
     else if (h16 && pl.nt8) { fam = "nt8"; bm = pl.nt8_bm; bn = pl.nt8; }
     else fam = "nt";
-    snprintf(buf, (size_t)buf_bytes, "%s %s %dx%d%s%s%s", fam, dt, bm, bn, pl.ut ? " ut" : "", pl.gp.s2 ? " classes" : "",
+    snprintf(buf, (size_t)buf_bytes, "%s %s %dx%d%s%s%s", fam, dt, bm, bn, pl.ut ? " ut" : "", pl.gp.s2 ? (d->algo == VLFB_ALGO_CLASS0 ? " class0" : " classes") : "",
              pl.pre ? " pre" : "");
   }
   return VLFB_OK;

@@ -308,6 +308,7 @@ class ConvStep(Step):
                                  bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, math=mf,
                                  **planes, **geom, **ld_f)
         self.d_d = None
+        self.d_d_full = None
         self.w2 = False
         self.bwd_split = False
         self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
@@ -336,6 +337,17 @@ class ConvStep(Step):
             if self.bwd_split:
                 self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, Cs=self.Cog, Cn=Cin // G, alpha=alpha,
                                          math=hip.MATH_BF16X3, **rows, **planes, **dg, **ld_d)
+            # (Engine._plan_sparse_shortcut_dgrads) the strided 1x1x1 shortcut as an in-place accumulate over the rows it
+            # touches; d_d_full is the ordinary launch, for a pass in which this DGRAD is not an in-place second contribution
+            self.d_d_full = None
+            if getattr(self, "sparse_dgrad", False) and not self.bwd_split and not self.dx_f32:
+                sp = hip.ConvDesc.from_buffer_copy(bytes(self.d_d))
+                sp.algo = hip.ALGO_CLASS0
+                try:
+                    hip.conv_workspace_bytes(sp)
+                    self.d_d_full, self.d_d = self.d_d, sp
+                except hip.VlfbError:
+                    self.sparse_dgrad = False
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
@@ -551,7 +563,10 @@ class ConvStep(Step):
                     kw.update(a_planes=2, a_pstride=gp.numel() // 2)
                 if planes is not None:
                     kw.update(o_planes=2, o_pstride=planes.numel() // 2)
-                d = self._pl_desc(self.d_d, **kw) if kw else self.d_d
+                base = self.d_d
+                if self.d_d_full is not None and not (add is not None and add.data_ptr() == out.data_ptr() and mask is None):
+                    base = self.d_d_full          # (not an in-place second contribution: the launch that writes every row)
+                d = self._pl_desc(base, **kw) if kw else base
                 xs = self.x.root.slot
                 if self.group == 1:
                     hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes,
@@ -2203,6 +2218,7 @@ class Engine(object):
         for b in self.all_blobs:
             if b.root is b and b.grad_scale != 1.0:
                 assert b.slot.expected <= 1, "a scaled gradient (%s) must have a single contributor" % b.name
+        self._plan_sparse_shortcut_dgrads()
         if self.mix and self.MIX_TRUNK2:
             # the residual stream: a blob that is the identity operand of a conv's residual Sum receives that conv's output
             # gradient as an alias and adds its own branch to it (GradSlot.two_term)
@@ -2231,6 +2247,32 @@ class Engine(object):
                     if r.kind == "act" and not r.grad_f32 and r.slot.expected == 1 and r.C % 8 == 0:
                         r.slot.two_term = True
                         st.two_term_dx = True
+
+    SPARSE_SHORTCUT_DGRAD = True
+
+    def _plan_sparse_shortcut_dgrads(self):
+        """16-bit backward: the DGRAD of a (1, 2, 2)-strided 1x1x1 projection shortcut (res3_0 / res4_0 branch1) reaches only
+        the even (h, w) positions of the block input -- three quarters of its output rows are structural zeros that the
+        gathered kernel still walks the whole k-loop for (172 / 140 us per step on fp16, 292 / 232 us with two-term weights).
+        When the OTHER contribution to that gradient (branch2a's DGRAD) comes first, the shortcut can run as an in-place
+        accumulate over the rows it touches (hip.ALGO_CLASS0: a quarter of the tiles, nothing else is read or written).
+        So: mark those convs and move their backward step behind the other contributor's (they are independent: the
+        shortcut's output gradient is the block-output gradient, finished before either runs)."""
+        if not self.SPARSE_SHORTCUT_DGRAD or self.btdtype not in (torch.float16, torch.bfloat16) or (self.split and not self.mix):
+            return
+        for st in list(self.bwd_steps):
+            if not (isinstance(st, ConvStep) and tuple(st.k) == (1, 1, 1) and tuple(st.s) == (1, 2, 2) and tuple(st.p) == (0, 0, 0)
+                    and st.group == 1 and st.residual is None and not st.relu and st.x.needs_grad and not st.x.detached):
+                continue
+            r = st.x.root
+            others = [o for o in self.bwd_steps if o is not st and any(b.root is r for b in o.grad_inputs())]
+            if r.kind != "act" or r.grad_f32 or r.relu or r.slot.expected != 2 or len(others) != 1 or \
+                    not isinstance(others[0], ConvStep) or others[0].x.root is not r or r.shape[3] % 2 or r.shape[4] % 2:
+                continue
+            i, j = self.bwd_steps.index(st), self.bwd_steps.index(others[0])
+            if i < j:                                   # the shortcut ran first: move it right behind the other contributor
+                self.bwd_steps.insert(j, self.bwd_steps.pop(i))
+            st.sparse_dgrad = True
 
     def _allocate(self):
         dev = self.device

@@ -17,7 +17,7 @@ MIX_W2_SCALE = 1024.0                               # vlfb.h VLFB_MIX_W2_SCALE
 MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6     # vlfb_conv_desc.math
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
-ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256, ALGO_STREAM, ALGO_CLASSES = 0, 1, 2, 3, 4
+ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256, ALGO_STREAM, ALGO_CLASSES, ALGO_CLASS0 = 0, 1, 2, 3, 4, 5
 ATTN_CAN_RUN, ATTN_FWD_FASTER, ATTN_BWD_FASTER = 1, 2, 4     # vlfb_attn_scores_supported flags
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
