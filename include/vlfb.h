@@ -45,6 +45,15 @@ enum { VLFB_SPLIT = 3 };
  *                gradient with 22 significant bits of W: dX = dY . Wh + dY . Wl */
 enum { VLFB_MIX = 4, VLFB_MIX_W2 = 5 };
 #define VLFB_MIX_W2_SCALE 1024.0f
+/* ... of the two-plane fp16 forward (vlfb_conv_desc.math = VLFB_MATH_F16X3): the FPROP copy as the two fp16 terms of
+ * (w * s) * VLFB_MIX_W2_SCALE, planes [term][Cout][taps][Cin] (alpha of the launch carries 1 / VLFB_MIX_W2_SCALE); the
+ * DGRAD copy as VLFB_MIX (VLFB_MIXH) or VLFB_MIX_W2 (VLFB_MIXH_W2) */
+enum { VLFB_MIXH = 6, VLFB_MIXH_W2 = 7 };
+/* A TWO-PLANE fp16 tensor: [2][numel] fp16, value = plane 0 (hi = fp16(v)) + plane 1 (lo = fp16(v - hi)), ~22 significant
+ * bits.  The storage format of the forward activations of the "mix" path: plane 0 alone is the fp16 tensor the fp16 backward
+ * reads (WGRAD operand, ReLU mask).  vlfb_pool_desc.dtype of vlfb_maxpool_fwd (x, y two-plane) and vlfb_avgpool_fwd (x
+ * two-plane, y fp32); produced by convolutions through O / O_lo of vlfb_conv_args, by vlfb_pair_split from fp32. */
+enum { VLFB_F16PAIR = 8 };
 /* vlfb_conv_desc.math: how the contraction is evaluated when dtype == VLFB_F32.
  *   VLFB_MATH_NATIVE  v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 vector rate)
  *   VLFB_MATH_BF16X6  operands expanded into three bf16 terms each, six bf16 MFMAs per product (hh hm mh mm hl lh):
@@ -53,7 +62,13 @@ enum { VLFB_MIX = 4, VLFB_MIX_W2 = 5 };
  * With math != 0 the B operand of FPROP / DGRAD launches is pre-split: bf16 planes (3 for BF16X6, 2 for BF16X3)
  * `b_pstride` elements apart, each laid out as the fp32 B operand would be (vlfb_weight_prep* with VLFB_SPLIT,
  * vlfb_split_planes); A, P, R, Mask and O stay fp32. */
-enum { VLFB_MATH_NATIVE = 0, VLFB_MATH_BF16X3 = 3, VLFB_MATH_BF16X6 = 6 };
+enum { VLFB_MATH_NATIVE = 0, VLFB_MATH_BF16X3 = 3, VLFB_MATH_BF16X6 = 6,
+       /* dtype VLFB_F16, FPROP / plain NT products: BOTH operands are two fp16 planes (A: a_pstride elements apart, B:
+        * b_pstride, 0 = Cn * ldb), a product is hi.hi + hi.lo + lo.hi on the fp16 MFMA (~2^-21 per product, nothing is
+        * converted in the k-loop; fp16 MFMA operands keep subnormals).  out_dtype VLFB_F16: the output is written as two
+        * planes O / O_lo, the residual read as R / R_lo (vlfb_conv_args); out_dtype VLFB_F32: a plain fp32 output.
+        * The split-bf16 maths accept out_dtype VLFB_F16 in the same sense (fp32 A operand, two-plane output / residual). */
+       VLFB_MATH_F16X3 = 13 };
 
 enum {
   VLFB_OK = 0,
@@ -240,6 +255,9 @@ int vlfb_ncthw_to_nthwc_wpad(const float* src, void* dst, int dtype, int64_t n, 
 /* NTHWC `dtype` -> fp32 NCTHW (for FetchBlob of activations / gradients) */
 int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64_t n, int64_t c, int64_t thw,
                         vlfb_stream_t stream);
+/* fp32 -> two-plane fp16 (VLFB_F16PAIR: dst[0..n) = hi, dst[n..2n) = lo) and back; n % 8 == 0 */
+int vlfb_pair_split(const float* src, void* dst_pair, int64_t n, vlfb_stream_t stream);
+int vlfb_pair_join(const void* src_pair, float* dst, int64_t n, vlfb_stream_t stream);
 /* generic cast fp32 <-> dtype, n elements */
 int vlfb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
               vlfb_stream_t stream);

@@ -224,7 +224,8 @@ def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_n
     small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64)
     cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
     convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.d_d is not None]
-    assert convs and all(s.w2 and s.wcode == hip.MIX_W2 for s in convs)
+    # (hip.MIXH*: the same DGRAD copies next to a two-plane fp16 FPROP copy -- the convs whose input is stored as two planes)
+    assert convs and all(s.w2 and s.wcode == (hip.MIXH_W2 if s.x_pair else hip.MIX_W2) for s in convs)
     real = hip.conv_workspace_bytes
 
     def refuse_some(d):
@@ -235,9 +236,9 @@ def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_n
     cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
     convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.d_d is not None]
     plain = [s for s in convs if not s.w2]
-    assert plain and all(s.d_d.Cn == 64 and s.wcode == hip.MIX and s.d_d.kt == s.k[0] and s.wd_npl == 1 for s in plain)
-    assert all(s.wcode == hip.MIX_W2 and s.wd_npl == 2 for s in convs if s.w2) and any(s.w2 for s in convs)
-    assert sorted({s.wcode for s in convs}) == sorted([hip.MIX, hip.MIX_W2])    # (one weight-prep batch per format: Engine._wprep_table)
+    assert plain and all(s.d_d.Cn == 64 and s.wcode == (hip.MIXH if s.x_pair else hip.MIX) and s.d_d.kt == s.k[0] and s.wd_npl == 1 for s in plain)
+    assert all(s.wcode == (hip.MIXH_W2 if s.x_pair else hip.MIX_W2) and s.wd_npl == 2 for s in convs if s.w2) and any(s.w2 for s in convs)
+    assert {s.wcode for s in convs} <= {hip.MIX, hip.MIX_W2, hip.MIXH, hip.MIXH_W2} and len({s.wcode for s in convs}) >= 2    # (one weight-prep batch per format: Engine._wprep_table)
 
 
 def test_strided_projection_shortcuts_run_their_dgrad_as_an_in_place_accumulate():
@@ -275,10 +276,11 @@ def test_product_code_never_imports_the_oracle():
 
 
 def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
-    """Engine dtype "mix" (DESIGN.md 3.1g): every forward value the backward reads has an fp16 copy with exactly one writer
-    (the producing conv's epilogue, a copy pass behind a non-conv step, or the start of forward() for fed blobs); the
-    backward descriptors are fp16 with two-term weights; theta / phi / g of the non-local blocks keep fp32 gradients; the
-    residual-stream slots are two-term"""
+    """Engine dtype "mix" (DESIGN.md 3.5): the trunk's activations are two fp16 planes read by two-plane forward convs (three
+    fp16 MFMAs per product), the rest of the forward is split-bf16 on fp32 storage; every forward value the backward reads
+    has an fp16 copy with exactly one writer (the hi plane of a two-plane blob, the producing conv's epilogue, a copy pass
+    behind a non-conv step, or the start of forward() for fed blobs); the backward descriptors are fp16 with two-term weights;
+    theta / phi / g of the non-local blocks keep fp32 gradients; the residual-stream slots are two-term"""
     import torch
     from vlfb import hip
     from vlfb.engine import ConvStep, AttentionStep, Engine
@@ -291,14 +293,24 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     fed = [id(b) for b in eng._half_inputs]
     assert len(posted) == len(set(posted)) and not (set(posted) & by_conv) and not (set(fed) & by_conv)
     for b in halves:
-        assert (id(b) in by_conv) + (id(b) in posted) + (id(b) in fed) == 1, b.name
-        assert b.half.dtype == torch.float16 and b.half.numel() == b.tensor.numel()
+        # (a two-plane blob: the hi plane IS the copy -- written by its producer, a conv epilogue or the max pool over planes)
+        assert (id(b) in by_conv or b.pair) + (id(b) in posted) + (id(b) in fed) == 1, b.name
+        assert b.half.dtype == torch.float16 and b.half.numel() * (2 if b.pair else 1) == b.tensor.numel()
+        assert not b.pair or (b.tensor.dtype == torch.float16 and b.half.data_ptr() == b.tensor.data_ptr())
+    # the two-plane blobs: every bottleneck / stem / pool output of the trunk; theta / phi / g, the attention internals and the
+    # head stay fp32
+    pairs = {b.name for b in eng.all_blobs if b.root is b and b.pair}
+    assert len(pairs) == 65 and {"res_conv1_bn", "pool1", "res2_0_branch2a_bn", "res3_1_branch2c_bn", "nonlocal_conv4_1_pool",
+                                 "nonlocal_conv4_1_sum", "res5_2_branch2c_bn"} <= pairs
+    assert not any(n.endswith(("_theta", "_phi", "_g", "_y")) or n.startswith(("lfb", "box_pooled", "blob_pooled", "pool5")) for n in pairs)
     assert sorted(b.name for b in eng._half_inputs) == ["data_train"]     # (the bank is read by fp32 steps only: the FBO head)
     convs = {s.out.name: s for s in eng.steps if isinstance(s, ConvStep)}
     c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
-    assert (c.d_f.dtype, c.d_f.math, c.d_f.kt) == (hip.F32, hip.MATH_BF16X3, 1)
+    assert (c.d_f.dtype, c.d_f.out_dtype, c.d_f.math, c.d_f.kt) == (hip.F16, hip.F16, hip.MATH_F16X3, 1) and c.x_pair and c.o_pair
+    assert c.d_f.a_pstride == c.x.numel and abs(c.d_f.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.wcode == hip.MIXH_W2
+    assert c.w_f.dtype == torch.float16 and c.w_f.shape[0] == 2 and hip.conv_plan(c.d_f).startswith("nt_pair f16x3")
     assert (c.d_d.dtype, c.d_d.math, c.d_d.kt, c.d_d.dt, c.d_d.kh, c.d_d.kw) == (hip.F16, hip.MATH_NATIVE, 2, 0, 3, 3)
-    assert abs(c.d_d.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.w_d.numel() == 2 * c.w_f.numel() // 3
+    assert abs(c.d_d.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.w_d.numel() == c.w_f.numel()
     assert hip.conv_flops(c.d_d) == hip.conv_flops(c.d_f)          # the doubled taps are not algorithmic work
     assert (c.d_w.dtype, c.d_w.out_dtype, c.d_w.math) == (hip.F16, hip.F32, hip.MATH_NATIVE)
     a = convs["res4_2_branch2a_bn"]                       # 3x1x1: T plays H, H x W one pointwise axis, T' = 1 carries the terms
@@ -310,7 +322,10 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert len(f32) == 20 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g", "y") for n in f32), f32
     oc = [c for c in convs.values() if c.wname == "nonlocal_conv4_1_out_w"][0]       # (fused with its AffineNd + Sum: named by the sum)
     assert oc.dx_f32 and oc.d_d.out_dtype == hip.F32 and oc.x.root.slot.buf.dtype == torch.float32
+    # (its forward: fp32 attention output in, split-bf16 products, the two-plane block input added, a two-plane output)
+    assert (oc.d_f.dtype, oc.d_f.out_dtype, oc.d_f.math) == (hip.F32, hip.F16, hip.MATH_BF16X3) and oc.o_pair and not oc.x_pair
     th = convs["nonlocal_conv4_1_theta"]
+    assert th.x_pair and not th.o_pair and (th.d_f.dtype, th.d_f.out_dtype, th.d_f.math) == (hip.F16, hip.F32, hip.MATH_F16X3)
     assert th.bwd_f32 and (th.d_w.dtype, th.d_w.math, th.d_w.wgrad_bias) == (hip.F32, hip.MATH_BF16X3, 1)
     assert th.out.root.slot.buf.dtype == torch.float32
     att = [s for s in eng.steps if isinstance(s, AttentionStep) and not s.single][0]

@@ -55,6 +55,11 @@ struct GP {
   // per bottleneck block): v = alpha * acc + bias + R + R2; relu; mask; O = T(v), O2 = T(v - T(v)).  Either may be null.
   const char* R2;
   char* O2;
+  // split-bf16 NT launches (vlfb_gemm_split.hip) with a TWO-PLANE fp16 output: O / O2 and R / R2 are fp16 planes (hi, lo)
+  // instead of fp32 tensors -- where an fp32 operand (the attention output of a non-local block) enters the two-plane forward
+  int pair_io;
+  // VLFB_MATH_F16X3: the two planes INTERLEAVED in groups of 32 k ([row][k / 32][hi 32 | lo 32]; a_ps = b_ps = 32 elements)
+  int pair_il;
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered
@@ -95,6 +100,8 @@ int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 g
 // NT with the activation operand pre-split into npl bf16 term planes (kind 0 plain rows, 1 / 2 gathered FPROP / DGRAD with
 // the scalar tap cursor)
 int launch_nt_planes(const GP& gp, int npl, int bn, int kind, dim3 grid, size_t lds, hipStream_t s);
+// vlfb_gemm_pair.hip: VLFB_MATH_F16X3 -- both operands as two fp16 planes (GP::a_ps / b_ps apart), plain rows or scalar tap cursor
+int launch_nt_pair(const GP& gp, int bn, bool ident, bool pre, bool out_f32, dim3 grid, size_t lds, hipStream_t s);
 
 namespace {
 

@@ -104,8 +104,11 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
                                             int wm, int wn, int l15, int g, int s2_ph = 0, int s2_pw = 0) {
   constexpr int BM = 128, NTHR = 256, WM = FM * 16, WN = FN * 16;      // (the wave tile: 64 x BN/2 as 2 x 2 waves, 32 x BN as 4 x 1)
   const int mrows = S2 ? p.s2_mq : p.M;
-  char* Ob = p.O + (long long)z * p.o_bs * 4;
-  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 4 : nullptr;
+  // p.pair_io: O / O2 and R / R2 are fp16 planes (hi, lo) of the values instead of fp32 tensors (GP::pair_io)
+  const bool pair = p.pair_io != 0;
+  const int oes = pair ? 2 : 4;
+  char* Ob = p.O + (long long)z * p.o_bs * oes;
+  const char* Rb = p.R ? p.R + (long long)z * p.r_bs * oes : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 4 : nullptr;
   constexpr int TPR = BN / 4, RPP = NTHR / TPR, NPASS = BM / RPP, CPR = BN / 4;
   const int tc = tid % TPR, tr = tid / TPR;
@@ -120,6 +123,15 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
     const bool ok = m < mrows && ncol < p.Ncols;
     const long long mo = S2 ? s2_row_pos(p, ok ? m : 0, s2_ph, s2_pw) : (long long)(ok ? m : 0);
     const long long ridx = mo * p.ldr + (ok ? ncol : 0);
+    if (pair) {
+      rv[gp] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (Rb && ok) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(Rb) + ridx);
+        const uint2 l = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.R2 + (long long)z * p.r_bs * 2) + ridx);
+        rv[gp] = make_float4(h2f((unsigned short)(h.x & 0xffffu)) + h2f((unsigned short)(l.x & 0xffffu)), h2f((unsigned short)(h.x >> 16)) + h2f((unsigned short)(l.x >> 16)),
+                             h2f((unsigned short)(h.y & 0xffffu)) + h2f((unsigned short)(l.y & 0xffffu)), h2f((unsigned short)(h.y >> 16)) + h2f((unsigned short)(l.y >> 16)));
+      }
+    } else
     rv[gp] = (Rb && ok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Rb) + ridx) : make_float4(0.f, 0.f, 0.f, 0.f);
     mv[gp] = (Mb && ok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Mb) + ridx) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
@@ -157,6 +169,13 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
       v[0] = mv[gp].x > 0.f ? v[0] : 0.f; v[1] = mv[gp].y > 0.f ? v[1] : 0.f;
       v[2] = mv[gp].z > 0.f ? v[2] : 0.f; v[3] = mv[gp].w > 0.f ? v[3] : 0.f;
       const long long oidx = mo * p.ldo + ncol;
+      if (pair) {
+        const unsigned short h0 = f2h(v[0]), h1 = f2h(v[1]), h2 = f2h(v[2]), h3 = f2h(v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Ob) + oidx) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.O2 + (long long)z * p.o_bs * 2) + oidx) =
+            make_uint2((uint32_t)f2h(v[0] - h2f(h0)) | ((uint32_t)f2h(v[1] - h2f(h1)) << 16), (uint32_t)f2h(v[2] - h2f(h2)) | ((uint32_t)f2h(v[3] - h2f(h3)) << 16));
+        continue;
+      }
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ob) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
       if (planes) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.OP) + oidx;

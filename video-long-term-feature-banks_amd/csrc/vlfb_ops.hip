@@ -162,9 +162,27 @@ template <> struct WStore<MixW> {
 struct MixW2 {};
 template <> struct WStore<MixW2> : WStore<MixW> {};
 
+// VLFB_MIXH / VLFB_MIXH_W2: the two-plane fp16 forward (VLFB_MATH_F16X3) -- the FPROP copy as the two fp16 terms of
+// (w * s) * VLFB_MIX_W2_SCALE, planes [term][Cout][taps][Cin] (the scale keeps the low term of a small weight in the fp16
+// normal range; the launch's alpha carries its inverse); the DGRAD copy as VLFB_MIX / VLFB_MIX_W2
+struct MixHW {};
+struct MixHW2 {};
+__device__ __forceinline__ void store_h2(void* base, long long idx, long long plane, float v) {
+  unsigned short* o = reinterpret_cast<unsigned short*>(base);
+  const float sv = v * VLFB_MIX_W2_SCALE;
+  const unsigned short h = f2h(sv);
+  o[idx] = h;
+  o[plane + idx] = f2h(sv - h2f(h));
+}
+template <> struct WStore<MixHW> {
+  __device__ static __forceinline__ void fprop(void* base, long long idx, long long plane, float v) { store_h2(base, idx, plane, v); }
+  __device__ static __forceinline__ void dgrad(void* base, long long idx, long long, float v) { reinterpret_cast<unsigned short*>(base)[idx] = f2h(v); }
+};
+template <> struct WStore<MixHW2> : WStore<MixHW> {};
+
 template <typename T>
 __device__ __forceinline__ void wstore_dgrad(void* base, int ci, int tap, int co, int taps, int cout, long long plane, float v) {
-  if constexpr (std::is_same<T, MixW2>::value) {
+  if constexpr (std::is_same<T, MixW2>::value || std::is_same<T, MixHW2>::value) {
     unsigned short* o = reinterpret_cast<unsigned short*>(base) + ((long long)ci * 2 * taps + tap) * cout + co;
     const float sv = v * VLFB_MIX_W2_SCALE;
     const unsigned short h = f2h(sv);
@@ -306,6 +324,146 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
         *reinterpret_cast<uint32_t*>(am) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
       }
     }
+  }
+}
+
+// Two-plane fp16 tensors (VLFB_F16PAIR: [2][numel] fp16, value = hi + lo; the forward activations of the "mix" path):
+// the window maximum of hi + lo, stored as the selected element's two planes (a copy: the pooled value IS an input value)
+struct PairVec {
+  __device__ static __forceinline__ void load(const f16_t* hi, long long plane, float (&h)[8], float (&l)[8]) {
+    Vec16<f16_t>::load(hi, h);
+    Vec16<f16_t>::load(hi + plane, l);
+  }
+};
+template <typename IdxT>
+__global__ void maxpool_fwd_pair_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ y, IdxT* __restrict__ argmax, PoolP p) {
+  constexpr int V = 8;
+  const int cchunks = p.C / V;
+  const long long total = (long long)p.N * p.To * p.Ho * p.Wo * cchunks;
+  const long long xplane = (long long)p.N * p.Ti * p.Hi * p.Wi * p.C, yplane = (long long)p.N * p.To * p.Ho * p.Wo * p.C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long o = i / cchunks;
+    const int wo = (int)(o % p.Wo); long long r = o / p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int to = (int)(r % p.To);
+    const int n = (int)(r / p.To);
+    float best[V], bh[V], bl[V];
+    int arg[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; bh[k] = bl[k] = 0.f; arg[k] = 0; }
+    for (int a = 0; a < p.kt; ++a) {
+      const int ti = to * p.st - p.pt + a;
+      if ((unsigned)ti >= (unsigned)p.Ti) continue;
+      for (int b = 0; b < p.kh; ++b) {
+        const int hi = ho * p.sh - p.ph + b;
+        if ((unsigned)hi >= (unsigned)p.Hi) continue;
+        for (int c = 0; c < p.kw; ++c) {
+          const int wi = wo * p.sw - p.pw + c;
+          if ((unsigned)wi >= (unsigned)p.Wi) continue;
+          float h[V], l[V];
+          PairVec::load(x + ((((long long)n * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * p.C + cc * V, xplane, h, l);
+          const int tap = (a * p.kh + b) * p.kw + c;
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            const float v = h[k] + l[k];
+            if (v > best[k]) { best[k] = v; bh[k] = h[k]; bl[k] = l[k]; arg[k] = tap; }
+          }
+        }
+      }
+    }
+    Vec16<f16_t>::store(y + o * p.C + cc * V, bh);
+    Vec16<f16_t>::store(y + yplane + o * p.C + cc * V, bl);
+    if (argmax && sizeof(IdxT) == 2) {
+      IdxT* am = argmax + o * p.C + cc * V;
+#pragma unroll
+      for (int k = 0; k < V; ++k) am[k] = (IdxT)arg[k];
+    } else if (argmax) {
+      uint2 pk;
+      pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+      pk.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(argmax) + o * p.C + cc * V) = pk;
+    }
+  }
+}
+// average pools over a two-plane fp16 tensor, fp32 output (the head reads res5 through them: head_helper.py:37-40, 92-98)
+__global__ void avgpool_fwd_pair_kernel(const f16_t* __restrict__ x, float* __restrict__ y, PoolP p) {
+  constexpr int V = 8;
+  const int cchunks = p.C / V;
+  const long long total = (long long)p.N * p.To * p.Ho * p.Wo * cchunks;
+  const long long xplane = (long long)p.N * p.Ti * p.Hi * p.Wi * p.C;
+  const float inv = 1.0f / (float)(p.kt * p.kh * p.kw);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long o = i / cchunks;
+    const int wo = (int)(o % p.Wo); long long r = o / p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int to = (int)(r % p.To);
+    const int n = (int)(r / p.To);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int a = 0; a < p.kt; ++a)
+      for (int b = 0; b < p.kh; ++b)
+        for (int c = 0; c < p.kw; ++c) {
+          const int ti = to * p.st + a, hi = ho * p.sh + b, wi = wo * p.sw + c;
+          float h[V], l[V];
+          PairVec::load(x + ((((long long)n * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * p.C + cc * V, xplane, h, l);
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[k] += h[k] + l[k];
+        }
+    float* yo = y + o * p.C + cc * V;
+    *reinterpret_cast<float4*>(yo) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<float4*>(yo + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
+  }
+}
+__global__ void global_avgpool_pair_kernel(const f16_t* __restrict__ x, float* __restrict__ y, long long rows, int C, long long xplane) {
+  constexpr int V = 8;
+  __shared__ float red[32][8 * 8 + 1];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int n = blockIdx.y;
+  const int c0 = (blockIdx.x * 8 + cl) * V;
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  if (c0 < C) {
+    const f16_t* base = x + (long long)n * rows * C + c0;
+    for (long long r = rl; r < rows; r += 32) {
+      float h[V], l[V];
+      PairVec::load(base + r * C, xplane, h, l);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += h[k] + l[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[rl][cl * 8 + k] = acc[k];
+  __syncthreads();
+  if (rl == 0 && c0 < C) {
+    const float inv = 1.0f / (float)rows;
+    float* yo = y + (long long)n * C + c0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float sum = 0.f;
+      for (int j = 0; j < 32; ++j) sum += red[j][cl * 8 + k];
+      yo[k] = sum * inv;
+    }
+  }
+}
+// fp32 -> the two fp16 planes, and back
+__global__ void pair_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    const unsigned short h0 = f2h(v.x), h1 = f2h(v.y), h2 = f2h(v.z), h3 = f2h(v.w);
+    *reinterpret_cast<uint2*>(dst + i) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+    *reinterpret_cast<uint2*>(dst + n + i) = make_uint2((uint32_t)f2h(v.x - h2f(h0)) | ((uint32_t)f2h(v.y - h2f(h1)) << 16),
+                                                        (uint32_t)f2h(v.z - h2f(h2)) | ((uint32_t)f2h(v.w - h2f(h3)) << 16));
+  }
+}
+__global__ void pair_join_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const uint2 h = *reinterpret_cast<const uint2*>(src + i), l = *reinterpret_cast<const uint2*>(src + n + i);
+    *reinterpret_cast<float4*>(dst + i) = make_float4(h2f((unsigned short)(h.x & 0xffffu)) + h2f((unsigned short)(l.x & 0xffffu)), h2f((unsigned short)(h.x >> 16)) + h2f((unsigned short)(l.x >> 16)),
+                                                      h2f((unsigned short)(h.y & 0xffffu)) + h2f((unsigned short)(l.y & 0xffffu)), h2f((unsigned short)(h.y >> 16)) + h2f((unsigned short)(l.y >> 16)));
   }
 }
 
@@ -1000,7 +1158,7 @@ PoolP to_poolp(const vlfb_pool_desc* d) {
   return p;
 }
 int check_pool(const vlfb_pool_desc* d) {
-  VLFB_REQUIRE(d->dtype == VLFB_F32 || is16(d->dtype), "pool: bad dtype");
+  VLFB_REQUIRE(d->dtype == VLFB_F32 || is16(d->dtype) || d->dtype == VLFB_F16PAIR, "pool: bad dtype");
   const int v = d->dtype == VLFB_F32 ? 4 : 8;
   VLFB_REQUIRE(d->C % v == 0, "pool: C=%d must be a multiple of %d", d->C, v);
   VLFB_REQUIRE(d->kt * d->kh * d->kw <= 65535, "pool: window too large for a 16-bit argmax");
@@ -1082,6 +1240,18 @@ extern "C" int vlfb_half_copy(const float* src, void* dst, int64_t n, vlfb_strea
                      (unsigned short*)dst, (long long)(n / 4), (long long)n);
   return check_launch("half_copy");
 }
+extern "C" int vlfb_pair_split(const float* src, void* dst_pair, int64_t n, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src && dst_pair && n >= 0 && n % 8 == 0, "pair_split: bad args (n must be a multiple of 8)");
+  if (n == 0) return VLFB_OK;
+  hipLaunchKernelGGL(pair_split_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst_pair, (long long)n);
+  return check_launch("pair_split");
+}
+extern "C" int vlfb_pair_join(const void* src_pair, float* dst, int64_t n, vlfb_stream_t stream) {
+  VLFB_REQUIRE(src_pair && dst && n >= 0 && n % 8 == 0, "pair_join: bad args (n must be a multiple of 8)");
+  if (n == 0) return VLFB_OK;
+  hipLaunchKernelGGL(pair_join_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src_pair, dst, (long long)n);
+  return check_launch("pair_join");
+}
 extern "C" int vlfb_cast(const void* src, int sd, void* dst, int dd, int64_t n, vlfb_stream_t stream) {
   VLFB_REQUIRE(src && dst && n >= 0, "cast: bad args");
   if (n == 0) return VLFB_OK;
@@ -1115,7 +1285,8 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
                                 int dtype, int64_t cout, int64_t taps, int64_t cin,
                                 vlfb_stream_t stream) {
   VLFB_REQUIRE(w && (w_fprop || w_dgrad) && cout > 0 && taps > 0 && cin > 0, "weight_prep: bad args");
-  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype) || dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2, "weight_prep: bad dtype");
+  VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype) || dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2 || dtype == VLFB_MIXH ||
+                   dtype == VLFB_MIXH_W2, "weight_prep: bad dtype");
   VLFB_REQUIRE(taps < 65536, "weight_prep: too many taps");
   hipStream_t s = (hipStream_t)stream;
   const long long total = cout * taps * cin;
@@ -1125,6 +1296,8 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
       hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
     else if (dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<SplitW>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
+    else if (dtype == VLFB_MIXH || dtype == VLFB_MIXH_W2)
+      hipLaunchKernelGGL(weight_prep_fprop_kernel<MixHW>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
     else
       VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_fprop_kernel<T16>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total));
   }
@@ -1134,9 +1307,9 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<float>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else if (dtype == VLFB_SPLIT)
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<SplitW>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
-    else if (dtype == VLFB_MIX)
+    else if (dtype == VLFB_MIX || dtype == VLFB_MIXH)
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
-    else if (dtype == VLFB_MIX_W2)
+    else if (dtype == VLFB_MIX_W2 || dtype == VLFB_MIXH_W2)
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW2>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else
       VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_dgrad_kernel<T16>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin));
@@ -1157,6 +1330,11 @@ extern "C" int vlfb_maxpool_fwd(const vlfb_pool_desc* d, const void* x, void* y,
   const bool wide = vlfb_pool_argmax_bytes(d) == 2;
   int grid = grid_for((long long)p.N * p.To * p.Ho * p.Wo * (p.C / v), 256);
   hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == VLFB_F16PAIR) {
+    if (!wide) hipLaunchKernelGGL((maxpool_fwd_pair_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, (uint8_t*)argmax, p);
+    else hipLaunchKernelGGL((maxpool_fwd_pair_kernel<uint16_t>), dim3(grid), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, (uint16_t*)argmax, p);
+    return check_launch("maxpool_fwd (fp16 planes)");
+  }
   if (d->dtype == VLFB_F32 && !wide)
     hipLaunchKernelGGL((maxpool_fwd_kernel<float, uint8_t>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, (uint8_t*)argmax, p);
   else if (d->dtype == VLFB_F32)
@@ -1228,6 +1406,16 @@ extern "C" int vlfb_avgpool_fwd(const vlfb_pool_desc* d, const void* x, void* y,
   const int v = d->dtype == VLFB_F32 ? 4 : 8;
   hipStream_t s = (hipStream_t)stream;
   const bool global = p.To == 1 && p.Ho == 1 && p.Wo == 1 && p.kt == p.Ti && p.kh == p.Hi && p.kw == p.Wi;
+  if (d->dtype == VLFB_F16PAIR) {
+    // x: two fp16 planes, y: fp32
+    const long long xplane = (long long)p.N * p.Ti * p.Hi * p.Wi * p.C;
+    if (global && p.N < 65536)
+      hipLaunchKernelGGL(global_avgpool_pair_kernel, dim3((unsigned)((p.C / 8 + 7) / 8), (unsigned)p.N), dim3(256), 0, s, (const f16_t*)x, (float*)y,
+                         (long long)p.Ti * p.Hi * p.Wi, p.C, xplane);
+    else
+      hipLaunchKernelGGL(avgpool_fwd_pair_kernel, dim3(grid_for((long long)p.N * p.To * p.Ho * p.Wo * (p.C / 8), 256)), dim3(256), 0, s, (const f16_t*)x, (float*)y, p);
+    return check_launch("avgpool_fwd (fp16 planes)");
+  }
   if (global && p.N < 65536) {
     dim3 grid((unsigned)((p.C / v + 7) / 8), (unsigned)p.N);
     const long long rows = (long long)p.Ti * p.Hi * p.Wi;
@@ -1488,6 +1676,10 @@ extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_
     hipLaunchKernelGGL(weight_prep_batched_kernel<MixW>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else if (dtype == VLFB_MIX_W2)
     hipLaunchKernelGGL(weight_prep_batched_kernel<MixW2>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_MIXH)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<MixHW>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_MIXH_W2)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<MixHW2>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
   return check_launch("weight_prep_batched");
 }

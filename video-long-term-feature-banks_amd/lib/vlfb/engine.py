@@ -75,6 +75,10 @@ class Blob(object):
         self.half = None              # "mix" dtype: fp16 copy of the values for the fp16 backward (root only; Engine.want_half)
         self.need_half = False
         self.grad_f32 = False         # "mix" dtype: the gradient of this blob is kept in fp32 (theta / phi / g of a non-local block)
+        # "mix" dtype: the values are stored as TWO fp16 planes [2][numel] (hi = fp16(v), lo = fp16(v - hi): ~22 bits; vlfb.h
+        # VLFB_F16PAIR) instead of fp32 -- what the two-plane forward convs (hip.MATH_F16X3) read without converting anything,
+        # and whose hi plane IS the fp16 copy the backward reads (Blob.half aliases it).  Root only; Engine._plan_pairs.
+        self.pair = False
 
     @property
     def numel(self):
@@ -101,6 +105,11 @@ class Blob(object):
 
     def ptr(self):
         return self.root.tensor.data_ptr()
+
+    def lo(self):
+        """the low plane of a two-plane blob (a view of the second half of its storage)"""
+        t = self.root.tensor
+        return t[t.numel() // 2:]
 
     def view(self, name, shape, caxis):
         v = Blob(name, shape, caxis, self.kind, self.root)
@@ -303,10 +312,24 @@ class ConvStep(Step):
         self.wblk = _prod(wshape) // G                # elements of one group's weight block
         planes = dict(b_pstride=self.wblk) if eng.split else {}
         bplanes = planes if mb != hip.MATH_NATIVE else {}          # ("mix": split forward, native fp16 backward)
-        self.d_f = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=code, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H,
-                                 Ws=W, Cs=self.Cin_k, Cn=self.Cog, pack_w=self.pack, relu=int(self.relu),
-                                 bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE, math=mf,
-                                 **planes, **geom, **ld_f)
+        # "mix", two-plane forward (Engine._plan_pairs): x_pair -- the input is two fp16 planes (the stem makes the clip's per
+        # pass): both operands pre-split, three fp16 MFMAs per product (hip.MATH_F16X3), fp32 or two-plane output; o_pair
+        # without x_pair -- an fp32 input (the attention output of a non-local block) through the split-bf16 kernel that
+        # writes two planes.  The residual, if any, has the format of the output.
+        self.o_pair = bool(self.out.root.pair)
+        self.x_pair = bool(self.x.root.pair or (self.stem and eng.pair_fwd and self.o_pair))
+        assert not (self.o_pair or self.x_pair) or (G == 1 and eng.mix)
+        assert self.residual is None or bool(self.residual.root.pair) == self.o_pair, "residual / output formats differ: %s" % self.out.name
+        fkw = dict(N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W, Cs=self.Cin_k, Cn=self.Cog, pack_w=self.pack, relu=int(self.relu),
+                   bias_mode=hip.BIAS_COL if self.has_bias() else hip.BIAS_NONE)
+        if self.x_pair:
+            n_in = (self.x.root.numel // self.x.root.C // self.x.root.shape[-1] * W * self.Cin_k) if self.stem else self.x.root.numel
+            self.d_f = hip.conv_desc(mode=hip.FPROP, dtype=hip.F16, out_dtype=hip.F16 if self.o_pair else hip.F32, math=hip.MATH_F16X3,
+                                     a_pstride=n_in, b_pstride=_prod(eng.kernel_shape(self.wname)), alpha=1.0 / hip.MIX_W2_SCALE,
+                                     **fkw, **geom)
+        else:
+            self.d_f = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=hip.F16 if self.o_pair else code, math=mf,
+                                     **fkw, **planes, **geom, **ld_f)
         self.d_d = None
         self.d_d_full = None
         self.w2 = False
@@ -366,6 +389,10 @@ class ConvStep(Step):
             eng.need_workspace(hip.conv_workspace_bytes(self.d_w))
             if not self.bwd_f32:
                 eng.want_half(self.x)
+            elif self.x.root.pair:
+                # the split-bf16 WGRAD reads fp32 operands: the two planes of the input are joined into a scratch tensor
+                # right before it, on the parameter-gradient stream (whose launches run one after the other)
+                eng.need_join_scratch(self.x.numel)
         # Pre-split operands ("split" dtype, Engine.PLANES): a conv epilogue can write the bf16 term planes of its output
         # next to the fp32 values (o_planes), and DGRAD / WGRAD launches that find their activation / gradient operands in
         # that form spend no VALU on the expansion (a_planes / p_planes).  Variants are built lazily (_pl_desc).
@@ -374,7 +401,9 @@ class ConvStep(Step):
         # the stem reads the clip: its term planes are made once per forward pass by a split pass (3 planes for the
         # six-product FPROP, of which the WGRAD reads the first two next to a split pass over its output gradient)
         self.x_planes = self.g_planes = None
-        if self.stem and eng.split and (eng.PLANES or eng.mix) and eng.STEM_PLANES:
+        if self.stem and self.x_pair:
+            self.x_planes = torch.empty(2 * self.d_f.a_pstride, device=eng.device, dtype=torch.float16)
+        elif self.stem and eng.split and (eng.PLANES or eng.mix) and eng.STEM_PLANES:
             n_in = self.x.root.numel // self.x.root.C // self.x.root.shape[-1] * W * self.Cin_k     # W is the padded width here
             self.x_npl = 3 if mf == hip.MATH_BF16X6 else 2
             self.x_planes = torch.empty(self.x_npl * n_in, device=eng.device, dtype=torch.bfloat16)
@@ -388,7 +417,9 @@ class ConvStep(Step):
         self.fprop_takes_planes = bool(eng.split and eng.PLANES and eng.FPROP_PLANES and mf == hip.MATH_BF16X3 and G == 1 and
                                        not self.stem and (plain or self.Cin_k % 32 == 0))
         # operand copies (split math: 3 bf16 term planes for FPROP, 2 for DGRAD -- include/vlfb.h VLFB_SPLIT)
-        if eng.split:
+        if self.x_pair:
+            self.w_f = torch.empty((2,) + tuple(wshape), device=eng.device, dtype=torch.float16)     # hi, lo of (w * s) * 2^10
+        elif eng.split:
             self.w_f = torch.empty((3,) + tuple(wshape), device=eng.device, dtype=torch.bfloat16)
         else:
             self.w_f = torch.empty(wshape, device=eng.device, dtype=eng.tdtype)
@@ -403,12 +434,16 @@ class ConvStep(Step):
                             torch.empty(_prod(wshape), device=eng.device, dtype=eng.tdtype))
         # one group's weight-operand block: [planes][wblk] elements, group g at g * planes * wblk (vlfb_weight_prep* is run
         # per group, so the term planes of a group lie next to each other)
-        self.wf_npl = 3 if eng.split else 1
+        self.wf_npl = 2 if self.x_pair else 3 if eng.split else 1
         self.wd_npl = (2 if (self.w2 or self.bwd_split) else 1) if eng.mix else (2 if eng.split else 1)
         # the format vlfb_weight_prep writes this conv's operand copies in ("mix": two-term or plain fp16 DGRAD copy, per conv --
         # ConvStep._w2_geometry; a conv without a DGRAD copy goes with the engine's default)
         self.wcode = eng.wcode if not eng.mix else (hip.SPLIT if self.bwd_split else
                                                     hip.MIX if (self.w_d is not None and not self.w2) else eng.wcode)
+        if self.x_pair:
+            assert not self.bwd_split, "a conv of the fp32 head with a two-plane input: %s" % self.out.name
+            self.wcode = {hip.MIX: hip.MIXH, hip.MIX_W2: hip.MIXH_W2}[self.wcode]
+        self.half_by_copy = False       # (True: the fp16 copy of the output comes from a copy pass, Engine._plan_half_copies)
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
         self.params = [n for n in (self.wname, self.cbname) if n and eng.is_trainable(n)]
@@ -498,6 +533,19 @@ class ConvStep(Step):
     def fwd(self):
         R = self.residual.storage() if self.residual is not None else None
         op = self.out.root.planes
+        if self.x_pair or self.o_pair:
+            A = self.x.storage()
+            if self.x_planes is not None:         # the stem: the clip's two fp16 planes, made per pass
+                hip.call("vlfb_pair_split", self.x.ptr(), hip.ptr(self.x_planes), self.x_planes.numel() // 2)
+                A = self.x_planes
+            if self.o_pair:
+                hip.conv_run(self.d_f, A, self.w_f, None, self.out.storage(), bias=self.bias_tensor(), R=R,
+                             R_lo=self.residual.lo() if R is not None else None, O_lo=self.out.lo())
+            else:
+                # fp32 output (theta / phi / g of a non-local block); O_lo = the fp16 copy the backward reads, if it wants one
+                assert R is None
+                hip.conv_run(self.d_f, A, self.w_f, None, self.out.storage(), bias=self.bias_tensor(), O_lo=self.out.root.half)
+            return
         if self.x_planes is not None:
             n = self.x_planes.numel() // self.x_npl
             hip.call("vlfb_split_planes", self.x.ptr(), hip.ptr(self.x_planes), self.x_npl, 1, n // 8, 8, 0)
@@ -578,6 +626,14 @@ class ConvStep(Step):
                                  O_planes=_at(planes, c), R_lo=_at(xs.add_lo, c), O_lo=_at(xs.out_lo, c))
             self.x.root.slot.contribute(dgrad, writes_planes=True)
 
+    def _x_f32(self):
+        """the input VALUES as an fp32 tensor (the operand of a split-bf16 WGRAD)"""
+        if not self.x.root.pair:
+            return self.x.storage()
+        t = self.eng.join_scratch(self.x.numel)
+        hip.call("vlfb_pair_join", self.x.ptr(), hip.ptr(t), self.x.numel)
+        return t
+
     def _param_grads(self, g, gp=None):
         eng = self.eng
         if self.d_w is not None:
@@ -593,7 +649,7 @@ class ConvStep(Step):
                 d = self._pl_desc(self.d_w, a_planes=2, a_pstride=xp.numel() // 2, p_planes=2, p_pstride=gp.numel() // 2, wgrad_bias=0)
                 hip.conv_run(d, xp, None, gp, eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
             elif self.group > 1:
-                xsrc, gw = (self.x.storage() if self.bwd_f32 else self.x.bstorage()), eng.grad_tensor(self.wname)
+                xsrc, gw = (self._x_f32() if self.bwd_f32 else self.x.bstorage()), eng.grad_tensor(self.wname)
                 gb = eng.grad_tensor(self.cbname) if self.d_w.wgrad_bias else None
                 for gi in range(self.group):
                     hip.conv_run(self.d_w, _at(xsrc, gi * self.Cin_k), None, _at(g, gi * self.Cog), _at(gw, gi * self.wblk),
@@ -601,11 +657,11 @@ class ConvStep(Step):
                 if gb is not None:
                     return
             elif self.d_w.wgrad_bias:
-                hip.conv_run(self.d_w, self.x.storage() if self.bwd_f32 else self.x.bstorage(), None, g,
+                hip.conv_run(self.d_w, self._x_f32() if self.bwd_f32 else self.x.bstorage(), None, g,
                              eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace, dbias=eng.grad_tensor(self.cbname))
                 return
             else:
-                hip.conv_run(self.d_w, self.x.storage() if self.bwd_f32 else self.x.bstorage(), None, g,
+                hip.conv_run(self.d_w, self._x_f32() if self.bwd_f32 else self.x.bstorage(), None, g,
                              eng.grad_tensor(self.wname), rowscale=s, workspace=eng.workspace)
             if self.stem:   # keep the zero padding of the packed stem weight exactly zero
                 gw = eng.grad_tensor(self.wname)
@@ -638,7 +694,9 @@ class PoolStep(Step):
         eng = self.eng
         N, Cc, T, H, W = self.x.shape
         _, _, To, Ho, Wo = self.out.shape
-        self.desc = hip.pool_desc(eng.code, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
+        # (a two-plane input: the max pool copies the selected element's planes, the average pool writes fp32)
+        assert bool(self.x.root.pair) == bool(self.out.root.pair) or (self.x.root.pair and not self.is_max), self.out.name
+        self.desc = hip.pool_desc(hip.F16PAIR if self.x.root.pair else eng.code, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
         self.desc_b = self.desc if eng.bcode == eng.code else hip.pool_desc(eng.bcode, N, T, H, W, Cc, To, Ho, Wo, self.k, self.s, self.p)
         if self.is_max and eng.train and self.x.relu:
             eng.want_half(self.out)               # vlfb_maxpool_relu_bwd reads the pooled values as the ReLU mask
@@ -1964,6 +2022,14 @@ class Engine(object):
     def need_scratch_planes(self, n):
         self._spl = max(self._spl, int(n))
 
+    def need_join_scratch(self, n):
+        self._sjoin = max(getattr(self, "_sjoin", 0), int(n))
+
+    def join_scratch(self, n):
+        """fp32 scratch of the parameter-gradient stream (ConvStep._x_f32)"""
+        assert n <= self._scratch_join.numel()
+        return self._scratch_join[:n]
+
     def scratch_planes(self, n):
         assert n <= self._scratch_pl.numel()
         return self._scratch_pl[:n]
@@ -2007,6 +2073,7 @@ class Engine(object):
         self._plan_head_f32()
         self.env = low.env
         self.all_blobs = list(low.blobs.values())
+        self._plan_pairs()
         self._plan_params()
         self._analyse_grads()
         for st in self.steps:
@@ -2106,6 +2173,71 @@ class Engine(object):
                     for b in cand.values():
                         b.grad_f32 = True
                         self.head_f32_fbo.append(b.name)
+
+    # "mix" dtype: forward activations of the trunk as two fp16 planes, forward convs on them with three fp16 MFMAs per product
+    # (hip.MATH_F16X3) -- VLFB_MIX_PAIR=0: the round-5 form (fp32 storage, split-bf16 products, separate fp16 copies)
+    MIX_PAIR = os.environ.get("VLFB_MIX_PAIR", "1") != "0"
+
+    def _plan_pairs(self):
+        """Which activations are stored as two fp16 planes (Blob.pair).  A blob qualifies when a conv or a max pool over a
+        two-plane blob produces it and EVERY consumer can read the format: a conv (as its input: plain rows or whole 32-channel
+        k-tiles; or as the residual of its epilogue), a max pool (whose output then qualifies in turn), an average pool (fp32
+        out: the head).  The formats of a conv's residual and output, and of a max pool's input and output, are tied; a conv
+        with a two-plane input and an fp32 output takes no residual.  Everything else -- theta / phi / g and the internals of a
+        non-local block, the head, the FBO branch -- stays fp32 and is read by the kernels it was read by before."""
+        self.pair_fwd = bool(self.mix and self.MIX_PAIR)
+        self.pair_blobs = []
+        if not self.pair_fwd:
+            return
+        consumers = {}
+        for st in self.steps:
+            for b in st.inputs:
+                consumers.setdefault(id(b.root), []).append((st, b))
+        cand = {}
+        for b in self.all_blobs:
+            if b.root is not b or b.kind != "act" or getattr(b, "dead", False) or b.grad_f32 or b.C % 8 or getattr(b, "is_input", False):
+                continue
+            st = b.producer
+            if (isinstance(st, ConvStep) and st.group == 1 and st.out is b) or (isinstance(st, PoolStep) and st.is_max):
+                cand[id(b)] = b
+
+        def conv_reads(st, b):
+            if st.group != 1:
+                return False
+            if st.residual is not None and st.residual.root is b and st.x.root is not b:
+                return True
+            plain = tuple(st.k) == (1, 1, 1) and tuple(st.s) == (1, 1, 1) and tuple(st.p) == (0, 0, 0)
+            return st.x.root is b and not st.stem and (b.C % 32 == 0 or (plain and b.C % 8 == 0))
+
+        changed = True
+        while changed:
+            changed = False
+            for b in list(cand.values()):
+                ok = True
+                p = b.producer
+                if isinstance(p, PoolStep):
+                    ok = id(p.x.root) in cand
+                elif p.stem:
+                    ok = True
+                for st, v in consumers.get(id(b), []):
+                    if isinstance(st, ConvStep):
+                        ok = ok and conv_reads(st, b)
+                        if st.residual is not None and st.residual.root is b:        # residual and output: one format
+                            ok = ok and id(st.out.root) in cand
+                        if st.x.root is b and st.residual is not None and st.residual.root is not b:
+                            ok = ok and id(st.residual.root) in cand       # (two-plane input + fp32 residual: no kernel)
+                    elif isinstance(st, PoolStep):
+                        ok = ok and (not st.is_max or id(st.out.root) in cand) and v.caxis == 1 and len(v.shape) == 5
+                    else:
+                        ok = False
+                if isinstance(p, ConvStep) and p.residual is not None:
+                    ok = ok and id(p.residual.root) in cand
+                if not ok:
+                    del cand[id(b)]
+                    changed = True
+        for b in cand.values():
+            b.pair = True
+            self.pair_blobs.append(b.name)
 
     def _plan_params(self):
         """flat fp32 buckets: trainables ordered by backward completion; frozen ones separately"""
@@ -2284,19 +2416,22 @@ class Engine(object):
                 if getattr(b, "pad_c", None):
                     wpad = getattr(b, "pad_w", 0)
                     n = b.numel // b.C // b.shape[-1] * (b.shape[-1] + 2 * wpad) * b.pad_c
-                b.tensor = torch.zeros(n, device=dev, dtype=self.tdtype)
+                b.tensor = torch.zeros(2 * n if b.pair else n, device=dev, dtype=torch.float16 if b.pair else self.tdtype)
             elif b.kind == "f32":
                 b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.float32)
             else:
                 b.tensor = torch.zeros(max(b.numel, 1), device=dev, dtype=torch.int32)
+            nval = b.tensor.numel() // 2 if b.pair else b.tensor.numel()
             if self.train and b.slot.expected > 0:
-                gdt = self.btdtype if (b.kind == "act" and not b.grad_f32) else b.tensor.dtype
-                b.slot.buf = torch.zeros(b.tensor.numel(), device=dev, dtype=gdt)
+                gdt = self.btdtype if (b.kind == "act" and not b.grad_f32) else torch.float32 if b.pair else b.tensor.dtype
+                b.slot.buf = torch.zeros(nval, device=dev, dtype=gdt)
                 if b.slot.two_term:
-                    b.slot.buf_lo = torch.zeros(b.tensor.numel(), device=dev, dtype=gdt)
+                    b.slot.buf_lo = torch.zeros(nval, device=dev, dtype=gdt)
                 if b.relu:
                     self.want_half(b)             # the finished gradient is masked by the sign of the values
-            if b.need_half:
+            if b.pair:
+                b.half = b.tensor[:nval]          # the hi plane IS the fp16 copy the backward reads
+            elif b.need_half:
                 b.half = torch.zeros(b.tensor.numel(), device=dev, dtype=torch.float16)
             # "split" dtype: bf16 term planes next to the fp32 values of conv-produced tensors whose consumers are
             # MFMA-bound convs (the large res2 / stem tensors are HBM-bound: a second copy would only cost traffic)
@@ -2317,6 +2452,7 @@ class Engine(object):
                        if b.root is b and b.kind == "act" and b.tensor is not None] + [4])
         self._scratch_act = torch.empty(max(self._sact, biggest), device=dev, dtype=self.btdtype)
         self._scratch_pl = torch.empty(max(self._spl, 8), device=dev, dtype=torch.bfloat16)
+        self._scratch_join = torch.empty(max(getattr(self, "_sjoin", 0), 4), device=dev, dtype=torch.float32)
 
     # ---- parameters ---------------------------------------------------------------------------
     def _to_kernel_layout(self, name, arr):
@@ -2511,6 +2647,8 @@ class Engine(object):
             raise KeyError("blob %r was fused away (its value only exists inside a kernel epilogue)" % name)
         src = b.root.slot.cur if grad else b.root.tensor
         t = src.detach().float().cpu()
+        if b.root.pair and not grad:              # two fp16 planes: value = hi + lo
+            t = t[:t.numel() // 2] + t[t.numel() // 2:]
         if grad and self.loss_scale != 1.0:
             t = t / self.loss_scale
         if grad and b.root.grad_scale != 1.0:     # fp16: theta / phi gradients are stored times a power of two
@@ -2603,11 +2741,13 @@ class Engine(object):
         seen = set()
         for st in self.steps:
             st._half_post = []
-            if isinstance(st, ConvStep):
+            if isinstance(st, ConvStep) and not st.half_by_copy:
                 seen.update(id(o.root) for o in st.outputs)
                 continue
             for o in list(st.outputs) + list(getattr(st, "aux_outputs", ())):
                 r = o.root
+                if r.pair:
+                    seen.add(id(r))               # (two planes: the hi plane is the copy)
                 if r.half is not None and id(r) not in seen:
                     seen.add(id(r))
                     st._half_post.append(r)

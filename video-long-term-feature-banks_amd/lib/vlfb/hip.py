@@ -13,8 +13,10 @@ import torch
 F32, BF16, F16 = 0, 1, 2
 SPLIT = 3                                           # weight-operand format of the split-bf16 path (vlfb.h VLFB_SPLIT)
 MIX, MIX_W2 = 4, 5                                  # ... of the "mix" path (split FPROP copy, fp16 DGRAD copy: plain / two terms)
+MIXH, MIXH_W2 = 6, 7                                # ... of the two-plane fp16 forward (two-term fp16 FPROP copy; DGRAD as MIX / MIX_W2)
+F16PAIR = 8                                         # two-plane fp16 tensors (vlfb.h VLFB_F16PAIR; pool descriptors)
 MIX_W2_SCALE = 1024.0                               # vlfb.h VLFB_MIX_W2_SCALE
-MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6     # vlfb_conv_desc.math
+MATH_NATIVE, MATH_BF16X3, MATH_BF16X6, MATH_F16X3 = 0, 3, 6, 13     # vlfb_conv_desc.math
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256, ALGO_STREAM, ALGO_CLASSES, ALGO_CLASS0 = 0, 1, 2, 3, 4, 5
@@ -112,6 +114,8 @@ _SIGS = {
     "vlfb_nthwc_to_ncthw": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_cast": (C.c_int, [_P, C.c_int, _P, C.c_int, _I64, _P]),
     "vlfb_half_copy": (C.c_int, [_P, _P, _I64, _P]),
+    "vlfb_pair_split": (C.c_int, [_P, _P, _I64, _P]),
+    "vlfb_pair_join": (C.c_int, [_P, _P, _I64, _P]),
     "vlfb_transpose2d": (C.c_int, [_P, _P, C.c_int, _I64, _I64, _I64, _P]),
     "vlfb_copy2d": (C.c_int, [_P, _I64, _P, _I64, C.c_int, _I64, _I64, _P]),
     "vlfb_zero_f32": (C.c_int, [_P, _I64, _P]),
@@ -312,8 +316,8 @@ def conv_flops(d):
 
 def conv_bytes(d, has_r=False, has_mask=False):
     """ALGORITHMIC HBM bytes of a launch: every operand read once, the output written once"""
-    es = 4 if d.dtype == F32 else 2
-    os_ = 4 if d.out_dtype == F32 else 2
+    es = 4 if (d.dtype == F32 or d.math == MATH_F16X3) else 2          # (two fp16 planes = 4 bytes per value)
+    os_ = 4 if (d.out_dtype == F32 or d.math != MATH_NATIVE) else 2
     batch = max(d.batch, 1)
     taps = d.kt * d.kh * d.kw
     k = d.kt * d.kh * d.pack_w * 4 if d.pack_w else taps * d.Cs
@@ -339,6 +343,8 @@ def conv_family(d):
     side = "tn" if d.mode == WGRAD else "nt"
     if d.math in (MATH_BF16X3, MATH_BF16X6):
         return side + "_split", (6 if (d.math == MATH_BF16X6 and d.mode == FPROP) else 3)
+    if d.math == MATH_F16X3:
+        return side + "_pair", 3
     if d.dtype == F32:
         return side + "_f32", 1
     return side + "_16", (2 if (d.mode == DGRAD and d.dt == 0 and d.kt == 2) else 1)
