@@ -51,14 +51,25 @@ def run(name, N, Cin, Cout, T, H, W, k, s, p, dl, res=True, algo=0):
         hip.call("vlfb_pair_split", r.data_ptr(), rp.data_ptr(), n_out)
     yp = torch.empty(2 * n_out, device=dev, dtype=torch.float16)
     d_h2 = hip.conv_desc(dtype=hip.F16, out_dtype=hip.F16, math=hip.MATH_F16X3, a_pstride=x.numel(), b_pstride=wf.numel(), alpha=1.0 / 1024, algo=algo, **base)
+    d_h2 = hip.conv_desc(dtype=hip.F16, out_dtype=hip.F16, math=hip.MATH_F16X3, a_pstride=x.numel(), b_pstride=wf.numel(), alpha=1.0 / 1024, algo=hip.ALGO_TILE128, **base)
     t_h2 = timeit(lambda: hip.conv_run(d_h2, xp, wh, None, yp, bias=bias, R=rp, R_lo=rp[n_out:] if res else None, O_lo=yp[n_out:]))
+    t_h8, same = float('nan'), None
+    try:
+        d_h8 = hip.conv_desc(dtype=hip.F16, out_dtype=hip.F16, math=hip.MATH_F16X3, a_pstride=x.numel(), b_pstride=wf.numel(), alpha=1.0 / 1024, algo=hip.ALGO_PIPE256, **base)
+        yq = torch.empty(2 * n_out, device=dev, dtype=torch.float16)
+        t_h8 = timeit(lambda: hip.conv_run(d_h8, xp, wh, None, yq, bias=bias, R=rp, R_lo=rp[n_out:] if res else None, O_lo=yq[n_out:]))
+        torch.cuda.synchronize()
+        same = torch.equal(yp, yq)
+        plan8 = hip.conv_plan(d_h8)
+    except hip.VlfbError:
+        plan8 = '-'
     xh, w16 = x.half(), wf.half()
     rh = r.half() if res else None
     d_16 = hip.conv_desc(dtype=hip.F16, out_dtype=hip.F16, **base)
     t_16 = timeit(lambda: hip.conv_run(d_16, xh, w16, None, yh, bias=bias, R=rh))
-    print('%-24s split %8.1f us %6.1f TF | pair %8.1f us %6.1f TF (%s) | fp16 %7.1f us (%s)' % (
-        name, t_sp, fl / t_sp / 1e6, t_h2, fl / t_h2 / 1e6, hip.conv_plan(d_h2), t_16, hip.conv_plan(d_16)))
-    return t_sp, t_h2, t_16
+    print('%-24s split %8.1f us %6.1f TF | pair %8.1f us %6.1f TF | pair 8-phase %8.1f us %6.1f TF (%s, ==%s) | fp16 %7.1f us (%s)' % (
+        name, t_sp, fl / t_sp / 1e6, t_h2, fl / t_h2 / 1e6, t_h8, fl / t_h8 / 1e6, plan8, same, t_16, hip.conv_plan(d_16)))
+    return t_sp, t_h2, min(t_h2, t_h8) if t_h8 == t_h8 else t_h2
 
 
 C = 8
@@ -94,4 +105,4 @@ for calls, a in shapes:
     t = run(*a)
     for i in range(3):
         tot[i] += calls * t[i]
-print('forward conv time per step over these launches: split %.2f ms | pair %.2f ms | fp16 %.2f ms' % tuple(v / 1e3 for v in tot))
+print('forward conv time per step over these launches: split %.2f ms | pair (128-row) %.2f ms | pair (best of both) %.2f ms' % tuple(v / 1e3 for v in tot))

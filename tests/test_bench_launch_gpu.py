@@ -31,11 +31,11 @@ def test_self_launched_one_rank_rccl_job_prints_one_json_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
-    # the line is the gate-meeting path's: dtype mix, its dominant family (the split-bf16 NT kernels of the forward pass) priced
-    # against the MFMA peak / 3 instructions per product, every family of the step listed
-    assert out["dtype"] == "mix" and out["roofline"]["kernel"].startswith("gemm_nt_sp_kernel"), out["roofline"]
+    # the line is the gate-meeting path's: dtype mix, its dominant family (the two-plane fp16 NT kernels of the forward pass)
+    # priced against the MFMA peak / 3 instructions per product, every family of the step listed
+    assert out["dtype"] == "mix" and out["roofline"]["kernel"].startswith("gemm_nt_kernel<f16, PAIR>"), out["roofline"]
     assert abs(out["roofline"]["peak"] - 2500.0 / 3) < 0.1 and abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-3
-    assert {"nt_split", "nt_16", "tn_16", "tn_split"} <= set(out["roofline_families"]), sorted(out["roofline_families"])
+    assert {"nt_pair", "nt_split", "nt_16", "tn_16", "tn_split"} <= set(out["roofline_families"]), sorted(out["roofline_families"])
     assert 1.0 < out["roofline_families"]["nt_16"]["mfma_per_product"] <= 2.0       # two-term DGRADs among the fp16 NT launches
     ar = out["allreduce"]
     assert ar["backend"] == "nccl" and ar["buckets"] >= 1 and ar["ranks"] == 1, ar

@@ -115,7 +115,7 @@ def test_pair_conv_fprop(case):
     # two-plane output with a two-plane residual
     O = torch.full((2 * n_out,), float("nan"), device=dev(), dtype=torch.float16)
     desc = hip.conv_desc(out_dtype=hip.F16, **base)
-    assert hip.conv_plan(desc).startswith("nt_pair f16x3"), hip.conv_plan(desc)
+    assert hip.conv_plan(desc).startswith(("nt_pair f16x3", "nt8_pair f16x3")), hip.conv_plan(desc)
     hip.conv_run(desc, A, Wf, None, O, bias=gpu(bias), R=R, R_lo=R[n_out:], O_lo=O[n_out:])
     got = to_ncthw(pair_value(O, (N, To, Ho, Wo, Cout)))
     assert rel_err(got, y_ref) < TOL, ("pair out", rel_err(got, y_ref))
@@ -185,6 +185,54 @@ def test_split_launch_with_two_plane_output():
     assert rel_err(got, y_ref) < 4e-5, rel_err(got, y_ref)
     hi, lo = O.cpu().view(2, -1).float()
     assert (lo.abs() <= torch.clamp(hi.abs() * 2.0 ** -11, min=2.0 ** -25)).all()
+
+
+@pytest.mark.parametrize("case", ["pw", "k133", "k311_s2", "ragged"])
+def test_pair_256_row_pipelined_kernel_is_bit_identical_to_the_128_row_kernel(case):
+    """vlfb_gemm_nt8.h PAIR (algo = PIPE256; the planner takes it for K >= 512): same products, same accumulation order"""
+    N, Cin, Cout, T, H, W, k, s, p, d = {
+        "pw": (2, 512, 256, 4, 14, 14, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+        "k133": (2, 128, 256, 3, 14, 14, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+        "k311_s2": (1, 64, 128, 6, 30, 30, (3, 1, 1), (1, 2, 2), (1, 0, 0), (1, 1, 1)),
+        "ragged": (1, 160, 136, 2, 25, 25, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1))}[case]
+    gen = torch.Generator().manual_seed(sum(map(ord, case)))
+    x = torch.randn(N, Cin, T, H, W, generator=gen)
+    taps = k[0] * k[1] * k[2]
+    w = torch.randn(Cout, Cin, *k, generator=gen) * (1.0 / math.sqrt(Cin * taps))
+    To, Ho, Wo = conv_out_dims(T, H, W, k, s, p, d)
+    bias = torch.randn(Cout, generator=gen)
+    res = torch.randn(N, Cout, To, Ho, Wo, generator=gen)
+    y_ref = torch.relu(F.conv3d(x.double(), w.double(), None, s, p, d) + bias.double().view(1, -1, 1, 1, 1) + res.double())
+    A = pair_of(to_nthwc(x))
+    Wf = torch.empty(2, Cout, taps, Cin, device=dev(), dtype=torch.float16)
+    hip.call("vlfb_weight_prep", hip.ptr(gpu(w_to_kernel(w).contiguous())), None, hip.ptr(Wf), None, hip.MIXH, Cout, taps, Cin)
+    R = pair_of(to_nthwc(res))
+    n_out = N * To * Ho * Wo * Cout
+    base = dict(mode=hip.FPROP, dtype=hip.F16, out_dtype=hip.F16, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W, Cs=Cin, Cn=Cout, relu=1,
+                bias_mode=hip.BIAS_COL, math=hip.MATH_F16X3, a_pstride=x.numel(), b_pstride=Cout * taps * Cin,
+                alpha=1.0 / hip.MIX_W2_SCALE, **geom_kwargs(k, s, p, d))
+    outs = {}
+    for algo in (hip.ALGO_TILE128, hip.ALGO_PIPE256):
+        O = torch.full((2 * n_out,), float("nan"), device=dev(), dtype=torch.float16)
+        desc = hip.conv_desc(algo=algo, **base)
+        assert hip.conv_plan(desc).startswith("nt8_pair" if algo == hip.ALGO_PIPE256 else "nt_pair"), hip.conv_plan(desc)
+        hip.conv_run(desc, A, Wf, None, O, bias=gpu(bias), R=R, R_lo=R[n_out:], O_lo=O[n_out:])
+        outs[algo] = O
+    assert torch.equal(outs[hip.ALGO_TILE128], outs[hip.ALGO_PIPE256])
+    got = to_ncthw(pair_value(outs[hip.ALGO_PIPE256], (N, To, Ho, Wo, Cout)))
+    assert rel_err(got, y_ref) < TOL
+    # fp32 output + fp16 copy
+    O32 = torch.full((n_out,), float("nan"), device=dev(), dtype=torch.float32)
+    Oh = torch.full((n_out,), float("nan"), device=dev(), dtype=torch.float16)
+    d32 = dict(base)
+    d32["out_dtype"] = hip.F32
+    hip.conv_run(hip.conv_desc(algo=hip.ALGO_PIPE256, **d32), A, Wf, None, O32, bias=gpu(bias), O_lo=Oh)
+    O32b = torch.full((n_out,), float("nan"), device=dev(), dtype=torch.float32)
+    hip.conv_run(hip.conv_desc(algo=hip.ALGO_TILE128, **d32), A, Wf, None, O32b, bias=gpu(bias))
+    assert torch.equal(O32, O32b)
+    ref_h = torch.empty_like(Oh)
+    hip.call("vlfb_half_copy", hip.ptr(O32), hip.ptr(ref_h), n_out)
+    assert torch.equal(Oh, ref_h)
 
 
 @pytest.mark.parametrize("geom", [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((2, 1, 1), (2, 1, 1), (0, 0, 0)), ((1, 2, 2), (1, 2, 2), (0, 0, 0))])

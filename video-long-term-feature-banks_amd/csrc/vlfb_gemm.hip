@@ -1078,9 +1078,11 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // 256-row phase-pipelined kernel (vlfb_gemm8.hip): bf16, 16-byte epilogue legal, at least 128 output
     // channels and 128 k; gathered operands need taps that span whole 64-element k-tiles (and unit stride
     // for DGRAD) and at most 32 taps (one validity bit per tap and row)
-    const bool gather_ok = pl->ident || (!d->pack_w && ((long long)d->Cs * es) % 128 == 0 && taps <= 32 &&
+    // (two fp16 planes, pl->h2: a k-tile is 32 k of both planes -- taps of whole 32-channel runs; FPROP / plain rows only)
+    const bool gather_ok = pl->ident || (!d->pack_w && ((long long)d->Cs * es) % (pl->h2 ? 64 : 128) == 0 && taps <= 32 &&
                                          (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
-    const bool ok = is16(d->dtype) && !pl->h2 && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024;
+    const bool ok = is16(d->dtype) && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024 &&
+                    (!pl->h2 || (K % 32 == 0 && batch == 1));
     if (d->algo == VLFB_ALGO_PIPE256)
       VLFB_REQUIRE(ok, "conv: algo = PIPE256 needs bf16 / f16, Cn >= 128, K >= 128, M >= 1024, 16-byte aligned rows and "
                        "taps spanning whole k-tiles");
@@ -1091,8 +1093,14 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // non-local theta conv: 1.07-1.20x) and the batched P.g products of the non-local blocks (1.15-1.20x).
     // Elsewhere (Cn = 2048 with residual + mask epilogues, K <= 512, the res3 / res4 shapes whose tiles
     // fill half the chip) the 128x128 kernel with 2-3 co-resident workgroups is 1.1-1.6x faster.
-    const bool want = d->algo == VLFB_ALGO_PIPE256 ||
-                      (ok && ((d->Cn == 512 && K >= 1024) ||
+    static const int pair8 = getenv("VLFB_PAIR_PIPE256") ? atoi(getenv("VLFB_PAIR_PIPE256")) : -1;     // (A/B switch: 0 never, 1 every eligible launch)
+    // Two fp16 planes (pl->h2): 24 MFMAs per phase on the fragment reads and DMA pieces of the plain form's 16, so the
+    // pipelined kernel pays on more shapes (measured per launch at 8 clips, scratch/r6/pair_probe.py: K >= 512 0.74-0.95x the
+    // time of the 128-row kernel -- res5 3x3 361 -> 270 us = 1.31 PFLOP/s of MFMA issue, res5 3x1x1 494 -> 364 us -- except
+    // the 2048-column layers with K = 512, whose residual epilogue dominates: 231 -> 250 us; K <= 256 0.94-1.36x)
+    const bool want_h2 = pl->h2 && ok && (pair8 == 1 || (pair8 != 0 && K >= 512 && (d->Cn <= 1024 || K >= 1024)));
+    const bool want = d->algo == VLFB_ALGO_PIPE256 || want_h2 ||
+                      (ok && !pl->h2 && ((d->Cn == 512 && K >= 1024) ||
                               (batch > 1 && K >= 768 && d->Cn >= 256 && d->Cn <= 512 && d->out_dtype == d->dtype)));
     if (ok && want) {
       // tile shape: 256 / 196 rows (196 = two wave rows of 98: 7 of 8 fragment rows useful) x 256 / 128 columns,
@@ -1390,6 +1398,7 @@ extern "C" int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64
     const char* fam;
     int bm = pl.bm, bn = pl.bn;
     if (pl.sp) fam = pl.sp_pl ? "nt_planes" : "nt_split";
+    else if (pl.h2 && pl.nt8) { fam = "nt8_pair"; bm = pl.nt8_bm; bn = pl.nt8; }
     else if (pl.h2) fam = "nt_pair";
     else if (h16 && pl.skinny) fam = "nt_skinny";
     else if (h16 && d->mode == VLFB_CONV_FPROP && pl.stemf) fam = "stem_fprop";
@@ -1519,7 +1528,8 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
     } else if (d->mode == VLFB_CONV_WGRAD) rc = launch_tn_split(g, pl.bm, pl.bn, pl.ident, pl.packw, pl.grid, pl.lds, s);
     else if (pl.sp_pl) rc = launch_nt_planes(g, pl.sp, pl.bn, pl.sp_kind, pl.grid, pl.lds, s);
     else rc = launch_nt_split(g, pl.sp, pl.bn, pl.sp_kind, pl.ut != 0, pl.grid, pl.lds, s);
-  } else if (pl.h2) rc = launch_nt_pair(g, pl.bn, pl.ident, pl.pre != 0, d->out_dtype == VLFB_F32, pl.grid, pl.lds, s);
+  } else if (pl.h2 && pl.nt8) rc = launch_nt8_pair(g, pl.nt8_bm, pl.nt8, pl.nt8_mode, d->out_dtype == VLFB_F32, s);
+  else if (pl.h2) rc = launch_nt_pair(g, pl.bn, pl.ident, pl.pre != 0, d->out_dtype == VLFB_F32, pl.grid, pl.lds, s);
   else if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
   else if (d->dtype == VLFB_F16) rc = d->out_dtype == VLFB_F32 ? dispatch<f16_t, float>(d, pl, s) : dispatch<f16_t, f16_t>(d, pl, s);
   else rc = d->out_dtype == VLFB_F32 ? dispatch<bf16_t, float>(d, pl, s) : dispatch<bf16_t, bf16_t>(d, pl, s);

@@ -102,6 +102,7 @@ int launch_tn_split(const GP& gp, int bp, int bq, bool ident, bool packw, dim3 g
 int launch_nt_planes(const GP& gp, int npl, int bn, int kind, dim3 grid, size_t lds, hipStream_t s);
 // vlfb_gemm_pair.hip: VLFB_MATH_F16X3 -- both operands as two fp16 planes (GP::a_ps / b_ps apart), plain rows or scalar tap cursor
 int launch_nt_pair(const GP& gp, int bn, bool ident, bool pre, bool out_f32, dim3 grid, size_t lds, hipStream_t s);
+int launch_nt8_pair(const GP& gp, int bm, int bn, int mode, bool out_f32, hipStream_t s);
 
 namespace {
 

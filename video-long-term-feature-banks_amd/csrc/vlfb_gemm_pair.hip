@@ -10,6 +10,7 @@
 // of the 16-bit paths (vlfb_gemm_nt.h, PAIR): LDS-DMA of 128-byte rows = 32 k of hi | the same 32 k of lo, one bare
 // barrier per k-tile, XOR-swizzled rows, the LDS-staged 16-byte epilogue with two-term residual / output.
 #include "vlfb_gemm_nt.h"
+#include "vlfb_gemm_nt8.h"
 
 namespace vlfb {
 namespace {
@@ -31,7 +32,39 @@ void launch_pair_shape(const GP& gp, bool ident, dim3 grid, size_t lds, hipStrea
   else launch_pair_k(gemm_nt_kernel<f16_t, OutT, 128, BN, false, false, false, 128, PRE, NW, 2, true, true>, grid, 64 * NW, lds, gp, s);
 }
 
+// (a non-type template parameter: one `configured` flag per KERNEL -- every kernel here has the same function type)
+template <auto Kernel>
+void launch_pair8_k(const GP& gp, dim3 grid, size_t lds, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    configured = true;
+  }
+  hipLaunchKernelGGL(Kernel, grid, dim3(512), lds, s, gp);
+}
+template <typename OutT, int BN, int RV>
+void launch_pair8_bn(const GP& gp, int mode, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = (BN == 256 ? 2 : 3) * (size_t)(2 + BN / 128) * 16384;
+  if (mode == 0) launch_pair8_k<gemm_nt8_kernel<f16_t, OutT, BN, 0, false, RV, true>>(gp, grid, lds, s);
+  else launch_pair8_k<gemm_nt8_kernel<f16_t, OutT, BN, 1, false, RV, true>>(gp, grid, lds, s);
+}
+template <typename OutT>
+void launch_pair8_t(const GP& gp, int mode, int bm, int bn, dim3 grid, hipStream_t s) {
+  if (bn == 256) {
+    if (bm == 196) launch_pair8_bn<OutT, 256, 98>(gp, mode, grid, s); else launch_pair8_bn<OutT, 256, 128>(gp, mode, grid, s);
+  } else {
+    if (bm == 196) launch_pair8_bn<OutT, 128, 98>(gp, mode, grid, s); else launch_pair8_bn<OutT, 128, 128>(gp, mode, grid, s);
+  }
+}
+
 }  // namespace
+
+// the 256-row phase-pipelined form (vlfb_gemm_nt8.h): mode 0 plain rows, 1 gathered FPROP; bm 256 | 196, bn 256 | 128
+int launch_nt8_pair(const GP& gp, int bm, int bn, int mode, bool out_f32, hipStream_t s) {
+  const dim3 grid((unsigned)(gp.tiles_m * gp.tiles_n), 1, 1);
+  if (out_f32) launch_pair8_t<float>(gp, mode, bm, bn, grid, s); else launch_pair8_t<f16_t>(gp, mode, bm, bn, grid, s);
+  return check_launch("conv kernel (fp16 planes, 256-row pipelined)");
+}
 
 int launch_nt_pair(const GP& gp, int bn, bool ident, bool pre, bool out_f32, dim3 grid, size_t lds, hipStream_t s) {
   if (out_f32) {
