@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--rois-per-clip", type=int, default=0,
                     help="0 = SURVEY 8d C4 draw U{1..5} per clip (seeded per rank); N > 0 = exactly N per clip")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the extra fp32 parity-path measurement")
-    ap.add_argument("--fp32-steps", type=int, default=3)
+    ap.add_argument("--fp32-steps", type=int, default=10)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--crop", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,6 +99,8 @@ def parse():
     ap.add_argument("--no-mix-line", action="store_true", help="skip the extra 'mix' path measurement")
     ap.add_argument("--fp16-steps", type=int, default=20, help="timed steps of the extra fp16 throughput-path measurement")
     ap.add_argument("--no-fp16-line", action="store_true", help="skip the extra fp16 path measurement")
+    ap.add_argument("--bf16-steps", type=int, default=20, help="timed steps of the extra bf16 throughput-path measurement (BASELINE.json configs[1])")
+    ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16 path measurement")
     return ap.parse_args()
 
 
@@ -134,6 +136,17 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
+def parity_source_hash():
+    """sha256 over everything that decides the arithmetic of a step: the HIP sources AND the engine (which dtype every blob /
+    gradient slot has, which launches run: lib/vlfb/engine.py, hip.py) -- what a committed parity summary is valid for"""
+    import hashlib
+    h = hashlib.sha256(kernel_source_hash().encode())
+    for f in ("engine.py", "hip.py"):
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib", "vlfb", f), "rb").read())
+    return h.hexdigest()
+
+
 def parity_record(workload, dtype):
     """measured gradient / output error of a path at the benchmarked clip size: the committed summary of
     tests/test_model_gpu.py::test_full_size_clip_matches_oracle (profiles/parity_fullsize_<workload>.json), quoted only while
@@ -142,8 +155,9 @@ def parity_record(workload, dtype):
     if not os.path.exists(path):
         return {"source": "none: no committed full-size parity summary for this workload"}
     rec = json.load(open(path))
-    if rec.get("csrc_sha256") != kernel_source_hash():
-        return {"source": "none: %s was measured on other kernel sources (csrc hash differs)" % os.path.relpath(path, ROOT)}
+    if rec.get("source_sha256") != parity_source_hash():
+        return {"source": "none: %s was measured on other kernel / engine sources (hash of csrc + lib/vlfb/engine.py + hip.py differs)"
+                          % os.path.relpath(path, ROOT)}
     out = dict(rec["paths"].get(dtype, {}))
     out["source"] = "%s (%s, %s; tests/test_model_gpu.py::test_full_size_clip_matches_oracle on these kernel sources)" % (
         os.path.relpath(path, ROOT), rec["size"], rec["metric"])
@@ -190,8 +204,8 @@ def data_parallel_report(eng, args, lr, step_s, device):
     rep["allreduce_alone_ms"] = round(alone * 1e3, 3)
     rep["allreduce_alone_busbw_GBps"] = round(2.0 * (world - 1) / world * buf.numel() * 4 / alone / 1e9, 1) if world > 1 else None
     # (c) the same step without the exchange (LAST: the ranks' weights diverge from here on)
-    comm, eng.comm = eng.comm, None
-    trace, eng.STEP_TRACE = eng.STEP_TRACE, False          # same host path as the timed data-parallel step (stream objects)
+    comm, eng.comm = eng.comm, None                         # (same host path as the timed step: the recorded call list, re-recorded without the collectives)
+    trace = eng.STEP_TRACE
     try:
         for _ in range(2):
             eng.train_step(lr)
@@ -275,9 +289,11 @@ def cpu_baseline(workload, frames, crop, rois_per_clip, dtype=None, device=None)
 
 
 DTYPE_NOTES = {
-    "mix": "fp32 storage, forward products as split-bf16 (3 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate); backward on "
-           "v_mfma_f32_16x16x32_f16 with fp16 gradient storage -- two-term fp16 weights in DGRAD, two-term gradients on the residual "
-           "stream / sums of DGRADs, fp32 gradients + split products around the non-local softmax and in the head",
+    "mix": "forward: trunk activations and weights as TWO fp16 planes (hi + lo, ~22 bits), a product = hi.hi + hi.lo + lo.hi on "
+           "v_mfma_f32_16x16x32_f16 (3 MFMAs per product, fp32 accumulate, nothing converted in the k-loop); non-local / FBO internals "
+           "fp32 with split-bf16 products; backward on v_mfma_f32_16x16x32_f16 with fp16 gradient storage (the hi plane is the fp16 "
+           "operand) -- two-term fp16 weights in DGRAD, two-term gradients on the residual stream / sums of DGRADs, fp32 gradients + "
+           "split products around the non-local softmax and in the head",
     "fp16": "fp16 storage and v_mfma_f32_16x16x32_f16 operands end to end, fp32 accumulate, static power-of-two loss scale",
     "bf16": "bf16 storage and v_mfma_f32_16x16x32_bf16 operands end to end, fp32 accumulate",
     "split": "fp32 storage, every contraction as split-bf16 products (3 x v_mfma_f32_16x16x32_bf16 per product) in both directions",
@@ -330,7 +346,9 @@ def roof_record(key, fam, traffic, traffic_source, brief=False):
         ("mfma_per_product", round(mpp, 3)), ("mfma_rate_tflops", round(ach * mpp, 1)), ("mfma_peak_tflops", base),
         ("launches_per_step", n), ("avg_launch_us", round(sec / max(n, 1) * 1e6, 2)),
         ("gflop_per_step", round(fl / 1e9, 1)), ("ms_per_step", round(sec * 1e3, 3)),
-        ("traffic", traffic.get(key))])
+        ("traffic", traffic.get(key)),
+        # measured HBM bytes (PMC) / algorithmic bytes per launch: > 1 = re-reads (operand panels per column tile, slabs)
+        ("traffic_ratio", round(traffic[key] / (f["bytes"] / max(n, 1)), 3) if traffic.get(key) and f["bytes"] > 0 else None)])
     if brief:
         return rec
     rec.update([
@@ -527,6 +545,7 @@ def main():
         torch.cuda.empty_cache()
         for key, dtype, steps, skip in (("mix_path", "mix", args.mix_steps, args.no_mix_line),
                                         ("fp16_path", "fp16", args.fp16_steps, args.no_fp16_line),
+                                        ("bf16_path", "bf16", args.bf16_steps, args.no_bf16_line),
                                         ("split_path", "split", args.split_steps, args.no_split_line),
                                         ("fp32_path", "fp32", args.fp32_steps, args.no_fp32_line)):
             if skip or dtype == args.dtype:

@@ -477,6 +477,14 @@ int vlfb_roi_align_max_bwd(const void* dout, int dtype, const float* rois, const
 int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,
                       int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
                       vlfb_stream_t stream);
+/* The same with SHARED banks (inference: tools/lfb_loader.py, tools/test_net.py): the data layer hands every RoI a COPY of its
+ * clip's bank (lib/datasets/ava_data_input.py:191-192) and the graph projects each copy (lib/models/lfb_helper.py:320-338);
+ * without dropout the projected banks of a clip's RoIs are identical, so phi / g are computed ONCE per clip -- [n_banks][K][D]
+ * -- and row r attends to bank (int)owner[r * owner_stride] (the batch-index column of the `proposals` blob: owner = rois,
+ * owner_stride = 5).  Same arithmetic per row as vlfb_fbo_attn_fwd on the duplicated banks: bit-identical outputs. */
+int vlfb_fbo_attn_fwd_shared(const void* theta, const void* phi, const void* g, float* p, void* t,
+                             int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                             const float* owner, int64_t owner_stride, vlfb_stream_t stream);
 /* ds_ws: fp32 scratch of r*k elements (the softmax-input gradient handed from the per-row
  * kernel to the chip-wide dphi/dg writer) */
 int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const void* g,

@@ -242,6 +242,15 @@ class _Ctx(object):
         # instead of taking its own -- a parity check of the arithmetic that a tie at zero cannot disturb.
         self.dec = decisions
         self.dec_used, self.dec_missing = set(), set()
+        # ... and the other direction: when the caller passes decisions["_record"] = True, the decisions THIS evaluation
+        # takes are written into decisions["relu"] / ["pool"] / ["roi_bin"] in the same format (oracle/fp32_control.py feeds
+        # the fp32 oracle's decisions to the fp64 oracle: the reference-width witness of the parity protocol)
+        self.record = bool(decisions and decisions.get("_record"))
+        if self.record:
+            self.dec = None
+            decisions.setdefault("relu", {})
+            decisions.setdefault("pool", {})
+            self.rec = decisions
 
 
 def _relu(cx, x, name):
@@ -250,7 +259,10 @@ def _relu(cx, x, name):
     if m is None:
         if cx.dec:
             cx.dec_missing.add(name)
-        return torch.relu(x)
+        y = torch.relu(x)
+        if cx.record:
+            cx.rec["relu"][name] = (y.detach() > 0).numpy()
+        return y
     cx.dec_used.add(name)
     return x * torch.from_numpy(np.ascontiguousarray(m)).reshape(x.shape).to(x.dtype)
 
@@ -262,6 +274,16 @@ def _max_pool(cx, x, name, k, s, p=(0, 0, 0)):
     if tap is None:
         if cx.dec:
             cx.dec_missing.add(name)
+        if cx.record:
+            y, idx = F.max_pool3d(x, k, s, p, return_indices=True)      # idx: flat (t, h, w) position of the selected element
+            H, W = x.shape[3], x.shape[4]
+            To, Ho, Wo = y.shape[2:]
+            ti, hi, wi = idx // (H * W), (idx // W) % H, idx % W
+            a = ti - (torch.arange(To).view(1, 1, To, 1, 1) * s[0] - p[0])
+            b = hi - (torch.arange(Ho).view(1, 1, 1, Ho, 1) * s[1] - p[1])
+            c = wi - (torch.arange(Wo).view(1, 1, 1, 1, Wo) * s[2] - p[2])
+            cx.rec["pool"][name] = ((a * k[1] + b) * k[2] + c).numpy()
+            return y
         return F.max_pool3d(x, k, s, p)
     cx.dec_used.add(name)
     tap = torch.from_numpy(np.ascontiguousarray(tap)).to(torch.int64)
@@ -553,6 +575,8 @@ def forward(cfg, params, inputs, split="train", lfb_infer_only=False, dtype=torc
                 rf = rf.flatten(2).gather(2, binidx.view(rf.shape[0], rf.shape[1], 1)).view(rf.shape[0], rf.shape[1], 1, 1)
                 cx.dec_used.add("roi_bin")
             else:
+                if cx.record:
+                    decisions["roi_bin"] = rf.detach().flatten(2).argmax(2).numpy()
                 rf = F.max_pool2d(rf, (res, res), (1, 1))
         feat = rf.reshape(-1, 2048, 1, 1, 1)
         B["box_pooled"] = feat

@@ -24,6 +24,9 @@ def test_launch_families_and_mfma_instructions_per_product():
     # split-bf16 products on fp32 storage: three MFMAs per product (six in a six-term forward)
     assert hip.conv_family(d(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X3)) == ("nt_split", 3)
     assert hip.conv_family(d(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X6)) == ("nt_split", 6)
+    # two fp16 planes per operand (the `mix` forward): three fp16 MFMAs per product, 4 bytes per stored value
+    h2 = d(mode=hip.FPROP, dtype=hip.F16, out_dtype=hip.F16, math=hip.MATH_F16X3, a_pstride=4 * 8 * 8 * 64)
+    assert hip.conv_family(h2) == ("nt_pair", 3) and hip.conv_bytes(h2) == hip.conv_bytes(d(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32))
     assert hip.conv_family(d(mode=hip.WGRAD, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X3)) == ("tn_split", 3)
     assert hip.conv_family(d(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32)) == ("nt_f32", 1)
 
@@ -40,8 +43,9 @@ def test_roofline_record_prices_a_family_against_the_mfma_peak_per_product():
     assert abs(r["achieved"] - 3.0e12 / 0.018 / 1e12) < 0.01 and abs(r["peak"] - 2500.0 / 3) < 0.1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["mfma_per_product"] == 3.0
     assert r["traffic"] == 4.1e8 and r["launches_per_step"] == 100 and abs(r["frac_of_attainable"] - 0.006 / 0.018) < 1e-3
+    assert abs(r["traffic_ratio"] - 4.1e8 / (2.0e10 / 100)) < 1e-3          # PMC bytes / algorithmic bytes per launch
     r = bench.roof_record("nt_16", fam, {}, "none", brief=True)
-    assert r["traffic"] is None and abs(r["mfma_per_product"] - 1.75) < 1e-9 and abs(r["peak"] - 2500.0 / 1.75) < 0.1
+    assert r["traffic"] is None and r["traffic_ratio"] is None and abs(r["mfma_per_product"] - 1.75) < 1e-9 and abs(r["peak"] - 2500.0 / 1.75) < 0.1
     assert "source" not in r and bench.roof_record(None, fam, {}, "none") is None
 
 
@@ -54,9 +58,12 @@ def test_pmc_traffic_maps_kernel_names_onto_the_bench_families():
         "void vlfb::(anonymous namespace)::gemm_tn_sp_kernel<128, 128, true, false, 8>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::bf16_t, float, 128, 128, false, false, 8, true>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::f16_t, float, 128, 128, false, false, 8, false>(vlfb::GP)": "tn_16",
-        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, true, false, 128, false, 8, 2, true>(vlfb::GP)": "nt_16",
-        "void vlfb::(anonymous namespace)::gemm_nt_kernel<float, float, 128, 128, true, false, false, 128, false, 4, 2, false>(vlfb::GP)": "nt_f32",
-        "void vlfb::(anonymous namespace)::gemm_nt8_kernel<vlfb::f16_t, vlfb::f16_t, 256, 2, false, 98>(vlfb::GP)": "nt_16",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, true, false, 128, false, 8, 2, true, false>(vlfb::GP)": "nt_16",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, false, false, 128, false, 8, 2, true, true>(vlfb::GP)": "nt_pair",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, float, 128, 128, true, false, false, 128, false, 8, 2, false, true>(vlfb::GP)": "nt_pair",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<float, float, 128, 128, true, false, false, 128, false, 4, 2, false, false>(vlfb::GP)": "nt_f32",
+        "void vlfb::(anonymous namespace)::gemm_nt8_kernel<vlfb::f16_t, vlfb::f16_t, 256, 2, false, 98, false>(vlfb::GP)": "nt_16",
+        "void vlfb::(anonymous namespace)::gemm_nt8_kernel<vlfb::f16_t, vlfb::f16_t, 256, 1, false, 98, true>(vlfb::GP)": "nt_pair",
         "void vlfb::(anonymous namespace)::stem_wgrad_kernel<vlfb::f16_t>(vlfb::GP)": "tn_16",
         "void vlfb::(anonymous namespace)::wgrad_rows_fat_kernel<vlfb::f16_t, 4, 3>(vlfb::GP)": "tn_16",
         "void vlfb::(anonymous namespace)::conv_rows64_kernel<vlfb::f16_t, 1>(vlfb::GP)": "nt_16",

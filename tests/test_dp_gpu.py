@@ -182,6 +182,71 @@ def test_rccl_bucketed_allreduce_one_rank(handoff):
         assert np.array_equal(g, eng.fetch_grad(n)), n
 
 
+def _replay_worker(port, q, handoff):
+    try:
+        _setup_paths()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                          VLFB_DIST_FORCE="1", VLFB_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import time
+        from vlfb import dist
+        from vlfb.presets import load_preset
+        from core.config import config as cfg
+        from oracle import model as om
+        from vlfb.engine import Engine
+        Engine.BUCKET_HANDOFF = handoff
+        dist.init_from_env()
+        load_preset("charades_r50_baseline", ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 1] + OV)
+        inputs = om.synth_inputs(cfg, 1, "train", seed=2, crop=64, frames=16)
+        params = om.synth_params(cfg, seed=2)
+        out = {}
+        for trace in (True, False):
+            eng = _run_replica(1, 0, 1, inputs, params)       # (plans, feeds, enables data parallel; one forward / backward)
+            assert eng.comm is not None and len(eng.comm.buckets) > 5
+            eng.STEP_TRACE = trace
+            host = []
+            for it in range(5):
+                t0 = time.perf_counter()
+                eng.train_step(0.01)
+                host.append(time.perf_counter() - t0)
+                torch.cuda.synchronize()
+            names = [n for _, _, n in (eng._trace or [])]
+            out[trace] = {"w": {n: eng.fetch_param(n) for n in ("pred_w", "res3_1_branch2b_w", "conv1_w")}, "loss": float(eng.fetch("loss").reshape(-1)[0]),
+                          "recorded": len(names), "reductions": names.count("all-reduce buckets"), "waits": names.count("comm wait"),
+                          "host_ms": [round(h * 1e3, 2) for h in host]}
+            del eng
+        q.put(out)
+        dist.barrier()
+        torch.distributed.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put((-1, {"_error": traceback.format_exc()}))
+        raise
+
+
+@pytest.mark.parametrize("handoff", ["streams", "join"])
+def test_data_parallel_step_replays_from_the_recorded_call_list(handoff):
+    """Engine.STEP_TRACE on a data-parallel step (model_builder_video.py:126-157): the bucket all-reduces and the communicator's
+    bookkeeping are recorded host actions (Engine.traced), a replayed step re-issues them between the same launches -- five
+    steps over RCCL (one rank) end with the weights of five steps walked through the step objects, bit for bit, and the
+    replayed steps cost the host less than the recorded one."""
+    import torch.multiprocessing as mp
+    _setup_paths()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_replay_worker, args=(port, q, handoff))
+    p.start()
+    got = _collect(q, [p], 1)[0]
+    a, b = got[True], got[False]
+    assert a["recorded"] > 100 and b["recorded"] == 0
+    assert a["reductions"] >= 1 and a["waits"] == 1, a
+    assert a["loss"] == b["loss"]
+    for n in a["w"]:
+        assert np.array_equal(a["w"][n], b["w"][n]), n
+    print("\n[dp step, %s] host ms per step: recorded list %s | step objects %s" % (handoff, a["host_ms"], b["host_ms"]))
+    assert min(a["host_ms"][2:]) < min(b["host_ms"][2:])
+
+
 # ---- AVA: a different number of RoIs on every rank ---------------------------------------------------------
 AVA_OV = ["TRAIN.VIDEO_LENGTH", 16, "TRAIN.CROP_SIZE", 64]
 ROIS = {0: [1], 1: [4]}

@@ -205,3 +205,64 @@ def test_epic_verb_and_noun_banks_match_the_reference_samplers():
         for i, (v, c) in enumerate(zip(vids, centres)):
             want = ol.sample_noun_lfb_epic(c, noun[v], W, D, 10, 1)
             assert np.array_equal(got[i], want.astype(np.float32)), (W, v, c)
+
+
+def test_one_bank_per_clip_in_inference_is_bit_identical_to_one_copy_per_roi():
+    """SURVEY.md 8f-1, "project the bank once per clip": the reference's data layer hands every RoI a copy of its clip's bank
+    (lib/datasets/ava_data_input.py:191-192) and the graph projects each copy (lfb_helper.py:320-338).  An inference plan
+    whose `lfb` blob has one row per CLIP runs lfb_1x1 and the phi / g convs of every FBO layer on n_clips x K rows and lets a
+    RoI read its clip's bank through the batch-index column of `proposals` (vlfb_fbo_attn_fwd_shared): same outputs, bit for
+    bit, with R / n_clips times fewer projected rows.  A training plan (dropout on the bank) refuses the shape."""
+    import collections
+    import pytest
+    from vlfb.presets import load_preset
+    from core.config import config as cfg
+    from models.model_builder_video import ModelBuilder
+    from vlfb.engine import Engine, ConvStep
+    from oracle import model as om
+    ov = ["NUM_GPUS", 1, "TEST.BATCH_SIZE", 2, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 16, "TEST.VIDEO_LENGTH", 16, "TEST.CROP_SIZE", 64,
+          "TRAIN.CROP_SIZE", 64]
+    load_preset("ava_r50_lfb_nl", ov)
+    rois = [2, 3]
+    inputs = om.synth_inputs(cfg, 2, "test", seed=5, rois_per_clip=rois, crop=64, frames=16)
+    params = om.synth_params(cfg, seed=5)
+    first = np.cumsum([0] + rois[:-1])
+    per_clip = inputs["lfb"][first]                                    # the bank of each clip, once
+    owner = inputs["proposals"][:, 0].astype(np.int64)
+    assert np.array_equal(inputs["lfb"], per_clip[owner])              # (what the data layer duplicated)
+    R, K = inputs["lfb"].shape[:2]
+    for dtype in ("mix", "fp32"):
+        out = {}
+        for mode in ("per_roi", "per_clip"):
+            model = ModelBuilder(train=False, split="test", name="test")
+            model.build_model(suffix="_test")
+            eng = Engine(model, dtype)
+            feed = dict(inputs)
+            if mode == "per_clip":
+                feed["lfb"] = per_clip
+            names = list(model.input_blob_names)
+            eng.plan(collections.OrderedDict((n, feed[n[:-5]].shape) for n in names))
+            eng.feed_params({k: v for k, v in params.items() if k in eng.param_views})
+            for n in names:
+                eng.feed(n, feed[n[:-5]])
+            eng.forward()
+            torch.cuda.synchronize()
+            bank_convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.out.name.startswith("lfb") and s.x.shape[2] == K]
+            assert len(bank_convs) == 1 + 2 * cfg.FBO_NL.NUM_LAYERS          # lfb_1x1 + phi, g per layer
+            out[mode] = (eng.fetch("pool5"), eng.fetch("prob"), sum(s.x.shape[0] * K for s in bank_convs))
+            del eng
+        assert np.array_equal(out["per_roi"][0], out["per_clip"][0]) and np.array_equal(out["per_roi"][1], out["per_clip"][1])
+        assert out["per_roi"][2] == R * K * 5 and out["per_clip"][2] == 2 * K * 5
+    # the oracle on the duplicated banks (the reference's formulation) agrees with the per-clip plan
+    blobs, _ = om.run(cfg, {k: v for k, v in params.items() if k in om.param_spec(cfg)}, inputs, "test", torch.float64, False, None)
+    got = out["per_clip"][1]
+    assert np.linalg.norm(got - blobs["prob"].numpy().reshape(got.shape)) < 1e-4 * np.linalg.norm(got)
+    # training: the bank of every RoI gets its own dropout mask (lfb_helper.py:333-336) -- one row per clip is refused
+    load_preset("ava_r50_lfb_nl", ov)
+    model = ModelBuilder(train=True, split="train", name="train")
+    model.build_model(suffix="_train")
+    tin = om.synth_inputs(cfg, 2, "train", seed=5, rois_per_clip=rois, crop=64, frames=16)
+    shapes = collections.OrderedDict((k + "_train", v.shape) for k, v in tin.items())
+    shapes["lfb_train"] = (2,) + tuple(tin["lfb"].shape[1:])
+    with pytest.raises(ValueError, match="one bank per clip"):
+        Engine(model, "mix").plan(shapes)

@@ -308,7 +308,7 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
     assert (c.d_f.dtype, c.d_f.out_dtype, c.d_f.math, c.d_f.kt) == (hip.F16, hip.F16, hip.MATH_F16X3, 1) and c.x_pair and c.o_pair
     assert c.d_f.a_pstride == c.x.numel and abs(c.d_f.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.wcode == hip.MIXH_W2
-    assert c.w_f.dtype == torch.float16 and c.w_f.shape[0] == 2 and hip.conv_plan(c.d_f).startswith("nt_pair f16x3")
+    assert c.w_f.dtype == torch.float16 and c.w_f.shape[0] == 2 and hip.conv_plan(c.d_f).startswith("nt8_pair f16x3")         # (K = 2304: the 256-row pipelined form)
     assert (c.d_d.dtype, c.d_d.math, c.d_d.kt, c.d_d.dt, c.d_d.kh, c.d_d.kw) == (hip.F16, hip.MATH_NATIVE, 2, 0, 3, 3)
     assert abs(c.d_d.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.w_d.numel() == c.w_f.numel()
     assert hip.conv_flops(c.d_d) == hip.conv_flops(c.d_f)          # the doubled taps are not algorithmic work

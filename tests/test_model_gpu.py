@@ -22,6 +22,8 @@ Tolerances (relative L2 per tensor; measured values are printed with -s):
 import collections
 import math
 
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -353,14 +355,13 @@ def test_full_size_clip_matches_oracle(preset):
             fh.write("\n".join(lines) + "\n")
         # machine-readable summary, stamped with the hash of the kernel sources it was measured on (bench.py quotes it
         # next to each path's clips/s only while that hash is the current one)
-        h = hashlib.sha256()
-        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-long-term-feature-banks_amd", "csrc")
-        for f in sorted(glob.glob(os.path.join(csrc, "*.h*"))):
-            h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+        # (bench.parity_source_hash: the HIP sources + lib/vlfb/engine.py + hip.py -- everything that decides the arithmetic)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import bench
         with open(os.path.join(out, "parity_fullsize_%s.json" % preset), "w") as fh:
             json.dump({"preset": preset, "size": "1 clip 32x224x224", "metric": "relative L2 vs the fp64 oracle, per tensor",
-                       "csrc_sha256": h.hexdigest(), "paths": summary}, fh, indent=1)
+                       "source_sha256": bench.parity_source_hash(), "paths": summary}, fh, indent=1)
 
 
 @pytest.mark.parametrize("preset", ["epic_verb_r50_lfb_nl", "epic_noun_r50_lfb_nl", "epic_verb_r50_baseline"])

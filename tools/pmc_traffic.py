@@ -2,7 +2,7 @@
 (--pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes) of bench.py's command line.
 usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.txt> <out.json> "<command line>"
 Units: the counters are KiB; FETCH_SIZE is doubled (gfx950 counts 128-byte requests of wide coalesced reads as 64 B).
-Families are bench.py's (hip.conv_family): nt_split / tn_split = the split-bf16 kernels of csrc/vlfb_gemm_split.hip (and
+Families are bench.py's (hip.conv_family): nt_pair = the two-plane fp16 forward kernels (csrc/vlfb_gemm_pair.hip), nt_split / tn_split = the split-bf16 kernels of csrc/vlfb_gemm_split.hip (and
 gemm_tn_tr_kernel<..., SP>), nt_16 / tn_16 = the 16-bit families, nt_f32 / tn_f32 the exact-fp32 kernels; the bytes of a
 split-K launch include its wgrad_reduce / wgrad_bias_reduce launches (slab reads)."""
 import sys, glob, sqlite3, json, collections, os, re
@@ -10,6 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def family(name):
+    # the two-plane fp16 instances (vlfb_gemm_pair.hip): PAIR is the LAST template argument of gemm_nt_kernel (13th) /
+    # gemm_nt8_kernel (7th)
+    m = re.search(r"gemm_(nt8?)_kernel<([^>]*)>\(", name)
+    if m:
+        targs = [a.strip() for a in m.group(2).split(",")]
+        if len(targs) == (13 if m.group(1) == "nt" else 7) and targs[-1] == "true":
+            return "nt_pair"
     if "gemm_nt_sp_kernel" in name or "gemm_nt_pl_kernel" in name:
         return "nt_split"
     if "gemm_tn_sp_kernel" in name or re.search(r"gemm_tn_tr_kernel<.*, true>\(", name):

@@ -246,15 +246,16 @@ __global__ void softmax_ce_kernel(const float* __restrict__ logits, const int32_
 template <typename T>
 __global__ void fbo_attn_fwd_kernel(const T* __restrict__ theta, const T* __restrict__ phi,
                                     const T* __restrict__ g, float* __restrict__ p, T* __restrict__ t,
-                                    int K, int D, long long ld, float scale) {
+                                    int K, int D, long long ld, float scale, const float* __restrict__ owner = nullptr, int ostride = 0) {
   extern __shared__ float sm[];  // [K] logits/probs + 4 reduction slots
   float* s = sm;
   float* red = sm + K;
   const int r = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* th = theta + (long long)r * D;
-  const T* ph = phi + (long long)r * K * ld;
-  const T* gg = g + (long long)r * K * ld;
+  const long long kvr = owner ? (long long)owner[(long long)r * ostride] : (long long)r;      // the bank this row attends to
+  const T* ph = phi + kvr * K * ld;
+  const T* gg = g + kvr * K * ld;
   for (int k = wave; k < K; k += 4) {
     float a = 0.f;
     for (int d = lane; d < D; d += 64) a += Elem<T>::ld(th + d) * Elem<T>::ld(ph + (long long)k * ld + d);
@@ -363,14 +364,15 @@ __global__ void fbo_attn_bwd_kv_kernel(const T* __restrict__ dt, const T* __rest
 // out[r][k] = scale * <q[r], kv[r][k]> : one wave per (r, k), 16 bytes per lane per pass
 template <typename T>
 __global__ void fbo_dot_kernel(const T* __restrict__ q, const T* __restrict__ kv, float* __restrict__ out,
-                               long long RK, int K, int D, long long ld, float scale) {
+                               long long RK, int K, int D, long long ld, float scale, const float* __restrict__ owner = nullptr, int ostride = 0) {
   constexpr int V = Vec16<T>::N;
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= RK) return;
   const long long r = wave / K;
   const T* qr = q + r * D;
-  const T* kr = kv + wave * ld;
+  const long long kvrow = owner ? (long long)owner[r * ostride] * K + (wave - r * K) : wave;
+  const T* kr = kv + kvrow * ld;
   float a = 0.f;
   for (int d = lane * V; d < D; d += 64 * V) {
     float x[V], y[V];
@@ -410,7 +412,7 @@ __device__ __forceinline__ void fbo_row_weights(const float* __restrict__ sr, co
 template <typename T, bool BWD>
 __global__ void fbo_mix_kernel(const float* __restrict__ s, const float* __restrict__ pin,
                                const T* __restrict__ kv, T* __restrict__ out,
-                               int K, int D, long long ld, float scale) {
+                               int K, int D, long long ld, float scale, const float* __restrict__ owner = nullptr, int ostride = 0) {
   constexpr int V = Vec16<T>::N;
   extern __shared__ float sm[];          // [K] weights, [4] reduction slots, [32][8 V] partials
   float* w = sm;
@@ -420,7 +422,7 @@ __global__ void fbo_mix_kernel(const float* __restrict__ s, const float* __restr
   fbo_row_weights<BWD>(s + (long long)r * K, BWD ? pin + (long long)r * K : nullptr, w, red, K, scale);
   const int dl = threadIdx.x & 7, kg = threadIdx.x >> 3;
   const int d0 = (dblk * 8 + dl) * V;
-  const T* base = kv + (long long)r * K * ld + d0;
+  const T* base = kv + (owner ? (long long)owner[(long long)r * ostride] : (long long)r) * K * ld + d0;
   float a[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) a[e] = 0.f;
@@ -601,9 +603,9 @@ extern "C" int vlfb_softmax_ce(const float* logits, const int32_t* labels, float
   return check_launch("softmax_ce");
 }
 
-extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,
-                                 int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
-                                 vlfb_stream_t stream) {
+static int fbo_attn_fwd_impl(const void* theta, const void* phi, const void* g, float* p, void* t,
+                             int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                             const float* owner, int ostride, vlfb_stream_t stream) {
   VLFB_REQUIRE(theta && phi && g && p && t && r > 0 && k > 0 && d > 0 && ld >= d, "fbo_attn_fwd: bad args");
   VLFB_REQUIRE(k <= 8192, "fbo_attn_fwd: bank too long for the LDS row buffer");
   size_t lds = (size_t)(k + 4) * sizeof(float);
@@ -617,22 +619,33 @@ extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void*
       const dim3 g2((unsigned)r, (unsigned)(d / (8 * v)));
       const size_t lds2 = (size_t)(k + 4 + 32 * 8 * v) * sizeof(float);
       if (dtype == VLFB_F32) {
-        hipLaunchKernelGGL(fbo_dot_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)theta, (const float*)phi, p, rk, (int)k, (int)d, (long long)ld, scale);
-        hipLaunchKernelGGL((fbo_mix_kernel<float, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const float*)g, (float*)t, (int)k, (int)d, (long long)ld, scale);
+        hipLaunchKernelGGL(fbo_dot_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)theta, (const float*)phi, p, rk, (int)k, (int)d, (long long)ld, scale, owner, ostride);
+        hipLaunchKernelGGL((fbo_mix_kernel<float, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const float*)g, (float*)t, (int)k, (int)d, (long long)ld, scale, owner, ostride);
       } else {
-        VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_dot_kernel<T16>, dim3(g1), dim3(256), 0, s, (const T16*)theta, (const T16*)phi, p, rk, (int)k, (int)d, (long long)ld, scale));
-        VLFB_WITH_T16(dtype, hipLaunchKernelGGL((fbo_mix_kernel<T16, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const T16*)g, (T16*)t, (int)k, (int)d, (long long)ld, scale));
+        VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_dot_kernel<T16>, dim3(g1), dim3(256), 0, s, (const T16*)theta, (const T16*)phi, p, rk, (int)k, (int)d, (long long)ld, scale, owner, ostride));
+        VLFB_WITH_T16(dtype, hipLaunchKernelGGL((fbo_mix_kernel<T16, false>), g2, dim3(256), lds2, s, (const float*)p, (const float*)nullptr, (const T16*)g, (T16*)t, (int)k, (int)d, (long long)ld, scale, owner, ostride));
       }
       hipLaunchKernelGGL((fbo_rowfix_kernel<false>), dim3((unsigned)r), dim3(256), lds, s, p, (const float*)nullptr, (int)k, scale);
       return check_launch("fbo_attn_fwd");
     }
   }
   if (dtype == VLFB_F32)
-    hipLaunchKernelGGL(fbo_attn_fwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)t, (int)k, (int)d, (long long)ld, scale);
+    hipLaunchKernelGGL(fbo_attn_fwd_kernel<float>, dim3((unsigned)r), dim3(256), lds, s, (const float*)theta, (const float*)phi, (const float*)g, p, (float*)t, (int)k, (int)d, (long long)ld, scale, owner, ostride);
   else if (is16(dtype))
-    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_attn_fwd_kernel<T16>, dim3((unsigned)r), dim3(256), lds, s, (const T16*)theta, (const T16*)phi, (const T16*)g, p, (T16*)t, (int)k, (int)d, (long long)ld, scale));
+    VLFB_WITH_T16(dtype, hipLaunchKernelGGL(fbo_attn_fwd_kernel<T16>, dim3((unsigned)r), dim3(256), lds, s, (const T16*)theta, (const T16*)phi, (const T16*)g, p, (T16*)t, (int)k, (int)d, (long long)ld, scale, owner, ostride));
   else return set_error(VLFB_ERR_ARG, "fbo_attn_fwd: bad dtype");
   return check_launch("fbo_attn_fwd");
+}
+extern "C" int vlfb_fbo_attn_fwd(const void* theta, const void* phi, const void* g, float* p, void* t,
+                                 int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                                 vlfb_stream_t stream) {
+  return fbo_attn_fwd_impl(theta, phi, g, p, t, dtype, r, k, d, ld, scale, nullptr, 0, stream);
+}
+extern "C" int vlfb_fbo_attn_fwd_shared(const void* theta, const void* phi, const void* g, float* p, void* t,
+                                        int dtype, int64_t r, int64_t k, int64_t d, int64_t ld, float scale,
+                                        const float* owner, int64_t owner_stride, vlfb_stream_t stream) {
+  VLFB_REQUIRE(owner && owner_stride > 0, "fbo_attn_fwd_shared: the owner column is required");
+  return fbo_attn_fwd_impl(theta, phi, g, p, t, dtype, r, k, d, ld, scale, owner, (int)owner_stride, stream);
 }
 extern "C" int vlfb_fbo_attn_bwd(const void* dt, const void* theta, const void* phi, const void* g,
                                  const float* p, void* dtheta, void* dphi, void* dg, float* ds_ws,

@@ -761,6 +761,16 @@ class AttentionStep(Step):
         self.B, self.Ci, self.L1, self.L2 = B, Ci, L1, L2
         code, bcode = eng.code, eng.bcode
         self.single = (L1 == 1)
+        # One bank per CLIP instead of one copy per RoI (inference): the `lfb` blob was planned with a row per
+        # clip, lfb_1x1 and the phi / g convs of every FBO layer run on n_clips x K rows instead of R x K, and a query row
+        # reads the bank of its clip -- the batch-index column of `proposals` (ava_data_input.py:175-192 writes it).
+        self.kv_owner = None
+        if self.phi.shape[0] != B:
+            prop = [b for n, b in eng.env.items() if str(n).startswith("proposals")]
+            if not (self.single and not eng.train and prop and self.phi.shape[0] == eng.plan_clips and self.g.shape[0] == self.phi.shape[0]):
+                raise ValueError("attention %s: %d query rows against %d banks -- one bank per clip is an inference-mode plan of a "
+                                 "RoI head (no dropout on the bank)" % (self.out.name, B, self.phi.shape[0]))
+            self.kv_owner = prop[0].root
         if eng.train:
             for t in (self.theta, self.phi, self.g) + (() if self.single else (self.prob,)):
                 eng.want_half(t)
@@ -836,6 +846,10 @@ class AttentionStep(Step):
     def fwd(self):
         eng = self.eng
         B, Ci, L1, L2 = self.B, self.Ci, self.L1, self.L2
+        if self.single and self.kv_owner is not None:
+            hip.call("vlfb_fbo_attn_fwd_shared", self.theta.ptr(), self.phi.ptr(), self.g.ptr(), self.prob.ptr(),
+                     self.out.ptr(), eng.code, B, L2, Ci, Ci, self.scale, self.kv_owner.ptr(), 5)
+            return
         if self.single:
             hip.call("vlfb_fbo_attn_fwd", self.theta.ptr(), self.phi.ptr(), self.g.ptr(), self.prob.ptr(),
                      self.out.ptr(), eng.code, B, L2, Ci, Ci, self.scale)
@@ -1986,6 +2000,33 @@ class Engine(object):
         if hip.tracing() is not None:
             hip.tracing().append((stream.wait_event, (ev,), "stream wait"))
 
+    def traced(self, fn, name):
+        """run a HOST-side action of a step that is not a library call or a stream edge -- the gradient all-reduces torch issues
+        (GradComm), their bookkeeping -- and, while a step is being recorded, append it to the call list so that a replayed
+        step re-issues it at the same point between the same kernel launches (Engine.STEP_TRACE on data-parallel steps)"""
+        fn()
+        rec = hip.tracing()
+        if rec is not None:
+            def call():
+                fn()
+                return 0
+            rec.append((call, (), name))
+
+    def _issue_reductions(self, stream, i, wait):
+        """the all-reduces of the gradient buckets that are final after backward step i, ordered behind `stream` (ProcessGroupNCCL
+        = RCCL orders a collective behind the stream that is current at the call)"""
+        ctx = torch.cuda.stream(stream) if stream is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            works = self.comm.after_step(i)
+            if wait:
+                for w in works:
+                    w.wait()
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
     def wait_stream(self, other):
         cur = torch.cuda.current_stream()
         cur.wait_stream(other)
@@ -2812,7 +2853,7 @@ class Engine(object):
             self.wait_stream(self.side)
             self._half_pending = False
         if self.comm is not None:
-            self.comm.begin()
+            self.traced(self.comm.begin, "comm begin")
         eager = self._eager_lr is not None
         self._eager_next = 0
         buckets = self.sol_buckets
@@ -2846,10 +2887,9 @@ class Engine(object):
             # joins the parameter-gradient stream and issues the collective itself -- no third stream, no cross-stream
             # events to get wrong; costs the overlap of the wgrad stream at every bucket boundary
             self.join_side_stream()
-            works = self.comm.after_step(i) if self.comm is not None else []
+            if self.comm is not None:
+                self.traced(lambda: self._issue_reductions(None, i, eager), "all-reduce buckets")
             if eager:
-                for w in works:
-                    w.wait()
                 self._solve_ready_buckets(i)
             return
         # position of the dgrad chain (main stream) and of the parameter-gradient stream; the third stream waits for
@@ -2857,11 +2897,10 @@ class Engine(object):
         sol = self.solver_stream
         self.wait_event(sol, self.record_event())
         self.wait_event(sol, self.record_event(self.side))
+        if self.comm is not None:
+            self.traced(lambda: self._issue_reductions(sol, i, eager), "all-reduce buckets")
         with torch.cuda.stream(sol):
-            works = self.comm.after_step(i) if self.comm is not None else []
             if eager:
-                for w in works:
-                    w.wait()
                 self._solve_ready_buckets(i)
         self.side_dirty = True
         self.solver_dirty = True
@@ -2981,7 +3020,7 @@ class Engine(object):
         if lr is not None:
             self.lr = float(lr)
         if self.comm is not None:
-            self.comm.wait()
+            self.traced(self.comm.wait, "comm wait")      # (the current stream waits for every bucket's reduction)
         if self._eager_done:
             # train_step(): every bucket was solved and refreshed during backward, as soon as it was final
             assert self._eager_next == len(self.sol_buckets)
@@ -3034,8 +3073,10 @@ class Engine(object):
     # bookkeeping, descriptor selection, ~450 ctypes argument conversions) is gone.  Unlike STEP_GRAPH the device
     # still sees ordinary stream launches, so the two-stream overlap is kept.  The per-iteration values (learning rate,
     # dropout seeds) are read from device memory as in a captured step.  Bit-identical to the stream path
-    # (tests/test_step_graph_gpu.py).  Data-parallel steps (the collectives are issued by torch) and profiled steps
-    # use the stream path; the trace is re-recorded when the stream or a class switch changes.
+    # (tests/test_step_graph_gpu.py).  Data-parallel steps are recorded too (round 6): the all-reduces torch issues and the
+    # communicator's bookkeeping are host actions appended to the list at the point of the step they happen at
+    # (Engine.traced), so a replay re-issues every collective between the same launches, behind the same stream edges.
+    # Profiled steps use the stream path; the trace is re-recorded when the stream, the communicator or a class switch changes.
     # Measured on one MI355X (8 clips bf16, idle queue): enqueuing a step takes 6.1-6.3 ms through the step objects,
     # 1.9-2.8 ms from the trace (C3 frozen backbone: 2.5 -> 0.75 ms); the step itself is GPU-bound either way
     # (440.1 vs 440.1 clips/s), the point is the host thread the data loader shares.
@@ -3044,9 +3085,8 @@ class Engine(object):
     def train_step(self, lr=None):
         if lr is not None:
             self.lr = float(lr)
-        if self.STEP_TRACE and not self.STEP_GRAPH and self.comm is None and hip.PROFILE is None and \
-                self._eager_steps >= 1 and not self.dry_run:
-            return self._trace_step()
+        if self.STEP_TRACE and not self.STEP_GRAPH and hip.PROFILE is None and self._eager_steps >= 1 and not self.dry_run:
+            return self._trace_step()         # (data-parallel steps too: the collectives are recorded host actions, Engine.traced)
         if self.STEP_GRAPH and self.comm is None and hip.PROFILE is None and self._eager_steps >= 1 and \
                 not self.dry_run:
             if self.STEP_GRAPH == "forward":
@@ -3082,7 +3122,7 @@ class Engine(object):
         if self._operand_version != self._pstate[0]:
             self.refresh_operands(all_params=True)
         key = (torch.cuda.current_stream().cuda_stream, self.side is None, self.EAGER_SOLVER, self.FORWARD_BRANCHES,
-               self.BUCKET_HANDOFF, self.WGRAD_LAG)
+               self.BUCKET_HANDOFF, self.WGRAD_LAG, id(self.comm))
         self._store_step_scalars()
         if self._trace is None or self._trace_key != key:
             self._trace, self._trace_key = None, None

@@ -157,6 +157,7 @@ _SIGS = {
                                          C.c_int, C.c_float, _P]),
     "vlfb_roi_align_decisions": (C.c_int, [_P, _P, _I64, _I64, _I64, C.c_int, C.c_float, C.c_int, _P]),
     "vlfb_fbo_attn_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P]),
+    "vlfb_fbo_attn_fwd_shared": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64, C.c_float, _P, _I64, _P]),
     "vlfb_fbo_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I64, _I64, _I64,
                                     C.c_float, _P]),
     "vlfb_sgd_update": (C.c_int, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
