@@ -262,6 +262,8 @@ def _relu(cx, x, name):
         y = torch.relu(x)
         if cx.record:
             cx.rec["relu"][name] = (y.detach() > 0).numpy()
+            if name in cx.rec.get("_want_pre", ()):          # (diagnostics: the pre-activations of the named sites)
+                cx.rec.setdefault("pre", {})[name] = x.detach().numpy().copy()
         return y
     cx.dec_used.add(name)
     return x * torch.from_numpy(np.ascontiguousarray(m)).reshape(x.shape).to(x.dtype)

@@ -1207,7 +1207,8 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     g.epi = (int)((tile + pl->lds - 1) / pl->lds);
     if (g.epi > 2) { pl->lds = tile / 2; g.epi = 2; }
     // (re-measured in round 3: prefetching for <= 16 / 36 / all k-tiles instead of 8 moves the bf16 step by -0.1 .. -0.7 %)
-    pl->pre = g.vec_epi && ktiles <= 8;   // host decides; only launches with R / Mask use it
+    static const int pre_kt = getenv("VLFB_PAIR_PRE_KT") ? atoi(getenv("VLFB_PAIR_PRE_KT")) : 16;       // (A/B switch)
+    pl->pre = g.vec_epi && ktiles <= (pl->h2 ? pre_kt : 8);   // host decides; only launches with R / Mask use it (two planes: 32-k tiles)
     if (pl->sp) {
       pl->sp_kind = pl->ident ? 0 : pl->packw ? 3 : d->mode == VLFB_CONV_FPROP ? 1 : 2;
       pl->threads = kThreads;

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   // PRE: thin-K launches are epilogue (HBM) bound, so the residual / mask rows of this lane are
   // requested BEFORE the k-loop and arrive while the MFMAs run.
   constexpr bool PREM = PRE && !PAIR;          // (PAIR launches are forward convs: no mask operand)
-  uint4 rpre[PRE ? NPASS : 1], mpre[PREM ? NPASS : 1];
+  constexpr bool PRE2 = PRE && PAIR;           // (PAIR: the residual is two planes -- the low one is requested up front as well)
+  uint4 rpre[PRE ? NPASS : 1], mpre[PREM ? NPASS : 1], r2pre[PRE2 ? NPASS : 1];
   if (PRE) {
 #pragma unroll
     for (int gp = 0; gp < NPASS; ++gp) {
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
       const bool ok = m < mrows && ncol < p.Ncols;
       const long long off = (row_pos(ok ? m : 0) * p.ldr + ncol) * (long long)sizeof(T);
       rpre[gp] = ld16_if(Rb ? Rb : Ab, off, ok && Rb != nullptr);
+      if constexpr (PRE2) r2pre[gp] = ld16_if(R2b ? R2b : Ab, off, ok && R2b != nullptr);
       if constexpr (PREM) mpre[gp] = ld16_if(Mb ? Mb : Ab, off, ok && Mb != nullptr);
     }
   }
@@ -400,7 +402,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
         if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
           if (R2b) {                                 // low term of a two-term residual
             float r[EPT];
-            load_elems<T, EPT>(reinterpret_cast<const T*>(R2b) + ridx, r);
+            if constexpr (PRE2) unpack_elems<T, EPT>(r2pre[PRE2 ? gp : 0], r);
+            else load_elems<T, EPT>(reinterpret_cast<const T*>(R2b) + ridx, r);
 #pragma unroll
             for (int e = 0; e < EPT; ++e) v[e] += r[e];
           }
