@@ -1,5 +1,6 @@
 """oracle/lfb.py against a literal transcription of the reference's samplers' *structure* (CPU)."""
 import numpy as np
+import pytest
 
 from oracle import lfb as ol
 
@@ -125,3 +126,44 @@ def test_epic_window_arithmetic_matches_the_reference_loops():
                 assert (l, h) == (frames[0] // 30, frames[-1] // 30), (window, c)
             else:
                 assert l > h
+
+
+def test_reference_draw_table_replays_sample_lfb_including_a_repeated_keyframe():
+    """lfb_bank.reference_draw_table (host half of DeviceBank.sample_window_reference_draw) against the reference's own loop
+    (lib/datasets/ava.py:300-323 `sample_lfb`, called once per clip of the minibatch, ava.py:230): same np.random stream, same
+    slots -- also when one keyframe sits in the minibatch TWICE (two draws, not one) and when a clip has several boxes (one
+    draw, repeated per box: ava_data_input.py:191-192)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-long-term-feature-banks_amd", "lib"))
+    from vlfb.lfb_bank import reference_draw_table
+    W, K = 5, 3
+    gen = np.random.RandomState(7)
+    counts = gen.randint(0, 6, size=(4, 40)).astype(np.int64)          # features stored per (video, second)
+    counts[2, 10:13] = 0                                               # seconds without features: `si not in in_video_lfb`
+    clips = [(1, 20), (2, 11), (1, 20), (3, 1), (0, 38)]               # (video, sec); clip 0 and clip 2: the SAME keyframe
+    boxes = [2, 1, 3, 1, 2]                                            # rows per clip
+
+    def sample_lfb_slots(video, sec, rng):                             # the reference loop, slots instead of feature copies
+        t = np.full((W, K), -1, dtype=np.int32)
+        lower = sec - W // 2
+        for j, si in enumerate(range(lower, lower + W)):
+            n = int(counts[video, si]) if 0 <= si < counts.shape[1] else 0
+            if n > 0:
+                used = min(n, K)
+                t[j, :used] = rng.choice(range(n), used, replace=False)
+        return t
+    ref_rng = np.random.RandomState(123)
+    want = []
+    for (v, sec), nb in zip(clips, boxes):
+        t = sample_lfb_slots(v, sec, ref_rng)                          # one draw per clip of the minibatch ...
+        want += [t] * nb                                               # ... repeated for every box of the clip
+    vid = np.concatenate([[v] * nb for (v, _), nb in zip(clips, boxes)])
+    centre = np.concatenate([[s_] * nb for (_, s_), nb in zip(clips, boxes)])
+    clip_index = np.concatenate([[i] * nb for i, nb in enumerate(boxes)])
+    got = reference_draw_table(counts, vid, centre, clip_index, W, K, np.random.RandomState(123))
+    assert np.array_equal(got, np.stack(want))
+    assert not np.array_equal(got[0], got[3])                          # the repeated keyframe was drawn again
+    # keyframe ids instead of minibatch positions (the two equal keyframes would share one draw): refused
+    with pytest.raises(ValueError):
+        reference_draw_table(counts, vid, centre, np.concatenate([[7] * 2, [9], [7] * 3, [4], [5] * 2]), W, K, np.random.RandomState(123))

@@ -183,7 +183,8 @@ def test_every_shipped_config_plans_in_train_and_test_mode():
 def test_mix_keeps_fp32_gradients_on_the_direct_path_of_the_head():
     """Engine._plan_head_f32 (validated on the GPU at full size in round 5 and made part of the `mix` dtype: no switch): the
     gradient slots of the head's direct path -- classifier input, dropout input, the RoI features, the pooled res5 map --
-    are fp32 and the FBO branch keeps fp16; the backbone is untouched"""
+    are fp32, and so are the 22 blobs of the FBO branch (Engine._plan_fbo_f32: its convs run the split-bf16 backward between
+    fp32 slots); the backbone is untouched"""
     from vlfb.engine import Engine
     small = ("NUM_GPUS", 1, "TRAIN.BATCH_SIZE", 2, "TRAIN.VIDEO_LENGTH", 8, "TRAIN.CROP_SIZE", 64)
     assert not hasattr(Engine, "MIX_HEAD_F32") and not hasattr(Engine, "MIX_W2_SKIP")     # no default-off parity switches

@@ -14,8 +14,10 @@ import torch.distributed as td
 
 
 def make_buckets(segments, bucket_bytes, esize=4):
-    """cut [(offset, count, ready_step)] (flat order, ready_step non-decreasing) into [(start, end, ready_step)]
-    buckets of at least `bucket_bytes` (the last one may be smaller)"""
+    """cut [(offset, count, ready_step)] (flat order; ready_step = backward step after which the segment is final, roughly
+    non-decreasing) into [(start, end, ready_step)] buckets of at least `bucket_bytes` (the last one may be smaller).  A bucket's
+    ready step is the MAX over its segments and buckets are issued in order, so a segment that becomes final a few steps
+    after its flat neighbours (the strided shortcuts the engine re-orders) only delays its own bucket."""
     buckets = []
     start, end, ready = None, 0, -1
     for off, cnt, step in segments:
@@ -34,7 +36,7 @@ def make_buckets(segments, bucket_bytes, esize=4):
 class GradComm(object):
     def __init__(self, flat_grad, segments, bucket_bytes=32 << 20, group=None, buckets=None):
         """segments: [(offset, count, ready_step)] in flat order; ready_step = index of the backward
-        step after which that segment's gradient is final (non-decreasing).  `buckets` overrides the cut
+        step after which that segment's gradient is final (see make_buckets).  `buckets` overrides the cut
         (the engine's per-bucket solver uses the same buckets)."""
         self.flat = flat_grad
         self.group = group

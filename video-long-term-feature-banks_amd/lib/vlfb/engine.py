@@ -334,6 +334,7 @@ class ConvStep(Step):
         self.d_d_full = None
         self.w2 = False
         self.bwd_split = False
+        self.dx_f32 = False
         self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
         if self.bwd_f32:
             eng.need_scratch_act(self.out.numel)
@@ -362,7 +363,6 @@ class ConvStep(Step):
                                          math=hip.MATH_BF16X3, **rows, **planes, **dg, **ld_d)
             # (Engine._plan_sparse_shortcut_dgrads) the strided 1x1x1 shortcut as an in-place accumulate over the rows it
             # touches; d_d_full is the ordinary launch, for a pass in which this DGRAD is not an in-place second contribution
-            self.d_d_full = None
             if getattr(self, "sparse_dgrad", False) and not self.bwd_split and not self.dx_f32:
                 sp = hip.ConvDesc.from_buffer_copy(bytes(self.d_d))
                 sp.algo = hip.ALGO_CLASS0
@@ -612,10 +612,14 @@ class ConvStep(Step):
                 if planes is not None:
                     kw.update(o_planes=2, o_pstride=planes.numel() // 2)
                 base = self.d_d
-                if self.d_d_full is not None and not (add is not None and add.data_ptr() == out.data_ptr() and mask is None):
+                xs = self.x.root.slot
+                # the sparse launch leaves three quarters of the rows untouched: legal only as an IN-PLACE second contribution,
+                # low term included (a two-term slot whose first contribution left no low term would keep stale rows of buf_lo)
+                inplace = add is not None and add.data_ptr() == out.data_ptr() and mask is None and \
+                    (xs.out_lo is None or (xs.add_lo is not None and xs.add_lo.data_ptr() == xs.out_lo.data_ptr()))
+                if self.d_d_full is not None and not inplace:
                     base = self.d_d_full          # (not an in-place second contribution: the launch that writes every row)
                 d = self._pl_desc(base, **kw) if kw else base
-                xs = self.x.root.slot
                 if self.group == 1:
                     hip.conv_run(d, gp if a_pl else g, self.w_d, None, out, R=add, mask=mask, O_planes=planes,
                                  R_lo=xs.add_lo, O_lo=xs.out_lo)
@@ -2940,6 +2944,9 @@ class Engine(object):
         its weight-decay ranges, the batched operand-refresh table of its conv weights and its effective biases"""
         from vlfb.comm import make_buckets
         index = {id(st): i for i, st in enumerate(self.bwd_steps)}
+        # (flat order = backward completion order as planned BEFORE _plan_sparse_shortcut_dgrads moved the strided shortcuts
+        # behind their sibling DGRAD: a shortcut's weights are then ready 2-3 steps later than their flat neighbours.
+        # make_buckets takes the MAX ready step of a bucket's segments, so a bucket is never issued early.)
         segs = []
         for n in self.train_order:
             off, cnt, _ = self.train_layout[n]

@@ -68,6 +68,39 @@ def epic_noun_window_steps(center_frames, window, max_per_frame=10, frames_per_s
     return _ceil_div(lower, sf), upper // sf
 
 
+def reference_draw_table(counts, vid, centre, clip_index, window, K, rng):
+    """The slot table of `sample_lfb` (lib/datasets/ava.py:300-323) for the rows of a minibatch, drawn from `rng` in the
+    reference's call order: clips in minibatch order (ava.py:205-230 appends one sampled bank per clip; rows of one clip --
+    its boxes, ava_data_input.py:191-192 -- share that bank), per clip the occupied seconds of its window in ascending
+    order, one `rng.choice(range(num_feat), min(num_feat, K), replace=False)` each.  counts[video][step] = features stored
+    for that second (0 = `si not in in_video_lfb`); centre = keyframe second minus the bank's first second.
+    -> int32 [rows][window][K], -1 = empty slot.  Pure host code (tests/test_lfb_oracle.py replays the reference loop)."""
+    rows = len(vid)
+    ids = np.asarray(clip_index).astype(np.int64).reshape(-1)
+    if ids.size != rows or (rows and (ids[0] != 0 or np.any(np.diff(ids) < 0) or np.any(np.diff(ids) > 1))):
+        raise ValueError("clip_index must be the minibatch position of every row's clip: 0, 0, 1, 1, 1, ... (got %r)" % (ids[:8],))
+    table = np.full((rows, int(window), int(K)), -1, dtype=np.int32)
+    prev = None
+    for r in range(rows):
+        if prev is None or ids[r] != ids[prev]:              # a new clip of the minibatch: its own draw
+            if prev is not None and (vid[r] == vid[prev] and centre[r] == centre[prev]):
+                pass                                         # (the same keyframe again: still a NEW draw, as in the reference)
+            t = np.full((int(window), int(K)), -1, dtype=np.int32)
+            lower = int(centre[r]) - int(window) // 2
+            for j in range(int(window)):
+                si = lower + j
+                n = int(counts[vid[r], si]) if (0 <= vid[r] < counts.shape[0] and 0 <= si < counts.shape[1]) else 0
+                if n > 0:                                    # `if si in in_video_lfb`
+                    used = min(n, int(K))
+                    t[j, :used] = rng.choice(range(n), used, replace=False)
+            cur = t
+        elif vid[r] != vid[prev] or centre[r] != centre[prev]:
+            raise ValueError("rows %d and %d belong to one clip but name different keyframes" % (prev, r))
+        table[r] = cur
+        prev = r
+    return table
+
+
 class DeviceBank(object):
     """bank[video][step][slot][dim] + count[video][step] on one GPU.
 
@@ -172,37 +205,22 @@ class DeviceBank(object):
         torch.cuda.current_stream().synchronize()
         return out
 
-    def sample_window_reference_draw(self, videos, secs, sample_ids, window, max_per_step, rng=None, out=None, out_dtype=None):
-        """AVA (ava.py:300-323) with the reference's OWN random stream: the host makes exactly the calls `sample_lfb` makes --
-        per clip (rows with one sample id share a draw, clips in order of first appearance, as ava_data_input.py:191-192
-        builds the bank once per clip and repeats it per box), per occupied second of the window in ascending order, one
-        `rng.choice(range(num_feat), min(num_feat, K), replace=False)` -- and the device gathers (vlfb_lfb_gather_slots).
-        With `rng = np.random` seeded as the reference seeds it (np.random.seed(cfg.RNG_SEED)) and the same call order the
-        sampled banks are the reference's, element for element.  `sample_window` (a counter-based key per draw, no host
-        work, no sync) has the same DISTRIBUTION but another stream.  Needs the step counts on the host: one small D2H
-        copy per call."""
+    def sample_window_reference_draw(self, videos, secs, clip_index, window, max_per_step, rng=None, out=None, out_dtype=None):
+        """AVA (ava.py:300-323) with the reference's OWN random stream: the host makes exactly the calls `sample_lfb` makes
+        (reference_draw_table below) and the device gathers (vlfb_lfb_gather_slots).  `clip_index[r]` = the position of row r's
+        CLIP inside the minibatch (0, 0, 1, 1, 1, ...: the batch-index column the data layer writes into `proposals`,
+        ava_data_input.py:175-192) -- NOT a keyframe id: the reference calls sample_lfb once per clip of the minibatch
+        (ava.py:230), so a keyframe that was drawn twice into one minibatch makes two draws.  With `rng = np.random` seeded as
+        the reference seeds it (np.random.seed(cfg.RNG_SEED)) and the caller's other np.random calls interleaved as the
+        reference interleaves them, the sampled banks are the reference's, element for element.  `sample_window` (a
+        counter-based key per draw, no host work, no sync) has the same DISTRIBUTION but another stream.  Needs the step
+        counts on the host: one small D2H copy per call."""
         rng = np.random if rng is None else rng
         rows = len(videos)
         vid = self._rows_of(videos)
         centre = np.asarray(secs).astype(np.int64).reshape(-1) - self.step_base
-        ids = np.asarray(sample_ids).astype(np.int64).reshape(-1)
-        cnt = self.counts()
         K = int(max_per_step)
-        table = np.full((rows, int(window), K), -1, dtype=np.int32)
-        drawn = {}
-        for r in range(rows):
-            key = int(ids[r])
-            if key not in drawn:
-                t = np.full((int(window), K), -1, dtype=np.int32)
-                lower = int(centre[r]) - int(window) // 2
-                for j in range(int(window)):
-                    si = lower + j
-                    n = int(cnt[vid[r], si]) if (0 <= vid[r] < cnt.shape[0] and 0 <= si < cnt.shape[1]) else 0
-                    if n > 0:                       # `if si in in_video_lfb`
-                        used = min(n, K)
-                        t[j, :used] = rng.choice(range(n), used, replace=False)
-                drawn[key] = t
-            table[r] = drawn[key]
+        table = reference_draw_table(self.counts(), vid, centre, clip_index, int(window), K, rng)
         qd = self._dev_i32(np.stack([vid, centre], axis=1))
         td = self._dev_i32(table.reshape(-1))
         out = self._out(out, (rows, int(window) * K, self.dim), out_dtype)
