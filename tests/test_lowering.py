@@ -298,12 +298,13 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
         assert (id(b) in by_conv or b.pair) + (id(b) in posted) + (id(b) in fed) == 1, b.name
         assert b.half.dtype == torch.float16 and b.half.numel() * (2 if b.pair else 1) == b.tensor.numel()
         assert not b.pair or (b.tensor.dtype == torch.float16 and b.half.data_ptr() == b.tensor.data_ptr())
-    # the two-plane blobs: every bottleneck / stem / pool output of the trunk; theta / phi / g, the attention internals and the
+    # the two-plane blobs: every bottleneck / stem / pool output of the trunk and the attention output of every non-local block
+    # (its P . g product writes two planes, so the `out` conv is a two-plane conv); theta / phi / g, the probabilities and the
     # head stay fp32
     pairs = {b.name for b in eng.all_blobs if b.root is b and b.pair}
-    assert len(pairs) == 65 and {"res_conv1_bn", "pool1", "res2_0_branch2a_bn", "res3_1_branch2c_bn", "nonlocal_conv4_1_pool",
-                                 "nonlocal_conv4_1_sum", "res5_2_branch2c_bn"} <= pairs
-    assert not any(n.endswith(("_theta", "_phi", "_g", "_y")) or n.startswith(("lfb", "box_pooled", "blob_pooled", "pool5")) for n in pairs)
+    assert len(pairs) == 70 and {"res_conv1_bn", "pool1", "res2_0_branch2a_bn", "res3_1_branch2c_bn", "nonlocal_conv4_1_pool",
+                                 "nonlocal_conv4_1_y", "nonlocal_conv4_1_sum", "res5_2_branch2c_bn"} <= pairs
+    assert not any(n.endswith(("_theta", "_phi", "_g", "_prob")) or n.startswith(("lfb", "box_pooled", "blob_pooled", "pool5")) for n in pairs)
     assert sorted(b.name for b in eng._half_inputs) == ["data_train"]     # (the bank is read by fp32 steps only: the FBO head)
     convs = {s.out.name: s for s in eng.steps if isinstance(s, ConvStep)}
     c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
@@ -323,8 +324,11 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert len(f32) == 20 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g", "y") for n in f32), f32
     oc = [c for c in convs.values() if c.wname == "nonlocal_conv4_1_out_w"][0]       # (fused with its AffineNd + Sum: named by the sum)
     assert oc.dx_f32 and oc.d_d.out_dtype == hip.F32 and oc.x.root.slot.buf.dtype == torch.float32
-    # (its forward: fp32 attention output in, split-bf16 products, the two-plane block input added, a two-plane output)
-    assert (oc.d_f.dtype, oc.d_f.out_dtype, oc.d_f.math) == (hip.F32, hip.F16, hip.MATH_BF16X3) and oc.o_pair and not oc.x_pair
+    # (its forward: the two-plane attention output in -- the P . g product of the block is a split-bf16 launch with a two-plane
+    # output --, the two-plane block input added, a two-plane output)
+    assert (oc.d_f.dtype, oc.d_f.out_dtype, oc.d_f.math) == (hip.F16, hip.F16, hip.MATH_F16X3) and oc.o_pair and oc.x_pair
+    att4 = [s for s in eng.steps if isinstance(s, AttentionStep) and s.out.name == "nonlocal_conv4_1_y"][0]
+    assert att4.o_pair and (att4.d_y.dtype, att4.d_y.out_dtype, att4.d_y.math) == (hip.F32, hip.F16, hip.MATH_BF16X3)
     th = convs["nonlocal_conv4_1_theta"]
     assert th.x_pair and not th.o_pair and (th.d_f.dtype, th.d_f.out_dtype, th.d_f.math) == (hip.F16, hip.F32, hip.MATH_F16X3)
     assert th.bwd_f32 and (th.d_w.dtype, th.d_w.math, th.d_w.wgrad_bias) == (hip.F32, hip.MATH_BF16X3, 1)

@@ -790,7 +790,8 @@ class AttentionStep(Step):
         gemm = lambda dtype=code, **kw: hip.conv_desc(mode=hip.FPROP, dtype=dtype, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
                                                       Ws=L1, batch=B, **kw)
         self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mf, **pl)
-        self.d_y = gemm(out_dtype=code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci, math=mf, **pl)
+        self.o_pair = bool(self.out.root.pair)           # (Engine._plan_pairs: y leaves the P . g product as two fp16 planes)
+        self.d_y = gemm(out_dtype=hip.F16 if self.o_pair else code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci, math=mf, **pl)
         self.d_dp = gemm(dtype=bcode, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mb, **bpl)
         # "mix": dP = dY . g^T as split-bf16 products on fp32 operands (dY through a cast) and the softmax backward on the
         # fp32 probabilities -- what follows cancels the part of dP that is common to a row
@@ -866,7 +867,8 @@ class AttentionStep(Step):
                 S = eng.scratch_f32(B * L1 * L2)
                 hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, S)
                 hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
-            hip.conv_run(self.d_y, self.prob.storage(), self._planes(self.g.storage(), nf, True), None, self.out.storage())
+            hip.conv_run(self.d_y, self.prob.storage(), self._planes(self.g.storage(), nf, True), None, self.out.storage(),
+                         O_lo=self.out.lo() if self.o_pair else None)
             return
         if self.dot:
             hip.conv_run(self.d_s, self.theta.storage(), self.phi.storage(), None, self.prob.storage())
@@ -2222,6 +2224,7 @@ class Engine(object):
     # "mix" dtype: forward activations of the trunk as two fp16 planes, forward convs on them with three fp16 MFMAs per product
     # (hip.MATH_F16X3) -- VLFB_MIX_PAIR=0: the round-5 form (fp32 storage, split-bf16 products, separate fp16 copies)
     MIX_PAIR = os.environ.get("VLFB_MIX_PAIR", "1") != "0"
+    PAIR_ATTENTION_OUT = os.environ.get("VLFB_PAIR_ATTN_OUT", "1") != "0"      # (A/B switch)
 
     def _plan_pairs(self):
         """Which activations are stored as two fp16 planes (Blob.pair).  A blob qualifies when a conv or a max pool over a
@@ -2240,10 +2243,16 @@ class Engine(object):
                 consumers.setdefault(id(b.root), []).append((st, b))
         cand = {}
         for b in self.all_blobs:
-            if b.root is not b or b.kind != "act" or getattr(b, "dead", False) or b.grad_f32 or b.C % 8 or getattr(b, "is_input", False):
+            # (an fp32 gradient slot masks with the fp32 VALUES of a post-ReLU blob: those stay fp32)
+            if b.root is not b or b.kind != "act" or getattr(b, "dead", False) or (b.grad_f32 and b.relu) or b.C % 8 or \
+                    getattr(b, "is_input", False):
                 continue
             st = b.producer
-            if (isinstance(st, ConvStep) and st.group == 1 and st.out is b) or (isinstance(st, PoolStep) and st.is_max):
+            if (isinstance(st, ConvStep) and st.group == 1 and st.out is b and not b.grad_f32) or (isinstance(st, PoolStep) and st.is_max):
+                cand[id(b)] = b
+            elif isinstance(st, AttentionStep) and st.theta.shape[2] > 1 and not st.dot and st.out is b and self.PAIR_ATTENTION_OUT:
+                # the attention output of a non-local block: its P . g product writes two planes (split-bf16 launch with a
+                # two-plane output), so the `out` conv behind it is a two-plane conv as well
                 cand[id(b)] = b
 
         def conv_reads(st, b):
@@ -2262,8 +2271,6 @@ class Engine(object):
                 p = b.producer
                 if isinstance(p, PoolStep):
                     ok = id(p.x.root) in cand
-                elif p.stem:
-                    ok = True
                 for st, v in consumers.get(id(b), []):
                     if isinstance(st, ConvStep):
                         ok = ok and conv_reads(st, b)
