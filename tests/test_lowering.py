@@ -302,9 +302,10 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     # (its P . g product writes two planes, so the `out` conv is a two-plane conv); theta / phi / g, the probabilities and the
     # head stay fp32
     pairs = {b.name for b in eng.all_blobs if b.root is b and b.pair}
-    assert len(pairs) == 70 and {"res_conv1_bn", "pool1", "res2_0_branch2a_bn", "res3_1_branch2c_bn", "nonlocal_conv4_1_pool",
-                                 "nonlocal_conv4_1_y", "nonlocal_conv4_1_sum", "res5_2_branch2c_bn"} <= pairs
-    assert not any(n.endswith(("_theta", "_phi", "_g", "_prob")) or n.startswith(("lfb", "box_pooled", "blob_pooled", "pool5")) for n in pairs)
+    assert len(pairs) == 80 and {"res_conv1_bn", "pool1", "res2_0_branch2a_bn", "res3_1_branch2c_bn", "nonlocal_conv4_1_pool",
+                                 "nonlocal_conv4_1_theta", "nonlocal_conv4_1_phi", "nonlocal_conv4_1_y", "nonlocal_conv4_1_sum",
+                                 "res5_2_branch2c_bn"} <= pairs        # (theta / phi: the scores are a batched two-plane product)
+    assert not any(n.endswith(("_g", "_prob")) or n.startswith(("lfb", "box_pooled", "blob_pooled", "pool5")) for n in pairs)
     assert sorted(b.name for b in eng._half_inputs) == ["data_train"]     # (the bank is read by fp32 steps only: the FBO head)
     convs = {s.out.name: s for s in eng.steps if isinstance(s, ConvStep)}
     c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
@@ -330,7 +331,10 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     att4 = [s for s in eng.steps if isinstance(s, AttentionStep) and s.out.name == "nonlocal_conv4_1_y"][0]
     assert att4.o_pair and (att4.d_y.dtype, att4.d_y.out_dtype, att4.d_y.math) == (hip.F32, hip.F16, hip.MATH_BF16X3)
     th = convs["nonlocal_conv4_1_theta"]
-    assert th.x_pair and not th.o_pair and (th.d_f.dtype, th.d_f.out_dtype, th.d_f.math) == (hip.F16, hip.F32, hip.MATH_F16X3)
+    assert th.x_pair and th.o_pair and (th.d_f.dtype, th.d_f.out_dtype, th.d_f.math) == (hip.F16, hip.F16, hip.MATH_F16X3)
+    gg = convs["nonlocal_conv4_1_g"]                      # g stays fp32 (the backward's dP product splits its fp32 values)
+    assert gg.x_pair and not gg.o_pair and (gg.d_f.dtype, gg.d_f.out_dtype, gg.d_f.math) == (hip.F16, hip.F32, hip.MATH_F16X3)
+    assert att4.s_pair and (att4.d_s.dtype, att4.d_s.out_dtype, att4.d_s.math, att4.d_s.batch) == (hip.F16, hip.F32, hip.MATH_F16X3, att4.B)
     assert th.bwd_f32 and (th.d_w.dtype, th.d_w.math, th.d_w.wgrad_bias) == (hip.F32, hip.MATH_BF16X3, 1)
     assert th.out.root.slot.buf.dtype == torch.float32
     att = [s for s in eng.steps if isinstance(s, AttentionStep) and not s.single][0]

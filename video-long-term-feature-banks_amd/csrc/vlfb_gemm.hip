@@ -1175,9 +1175,12 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     }
     long long a_bytes_all = a_bytes;
     if (pl->h2) {
-      g.b_ps = d->b_pstride > 0 ? d->b_pstride : (long long)d->Cn * g.ldb;
-      VLFB_REQUIRE(batch == 1 && K % 8 == 0 && g.ldb % 8 == 0 && (pl->packw || g.lda % 8 == 0) && g.b_ps % 8 == 0 && d->a_pstride % 8 == 0 && g.vec_epi,
-                   "conv: F16X3 math needs batch 1 and K, lda, ldb, the plane strides and the output rows in multiples of 8 elements");
+      // (batched plain products -- the attention scores of a non-local block, theta x phi^T: the planes of ALL batch elements lie
+      // a_pstride / b_pstride apart, a batch element a_bstride / b_bstride inside its plane)
+      g.b_ps = d->b_pstride > 0 ? d->b_pstride : (long long)batch * (batch > 1 ? d->b_bstride : (long long)d->Cn * g.ldb);
+      VLFB_REQUIRE(K % 8 == 0 && g.ldb % 8 == 0 && (pl->packw || g.lda % 8 == 0) && g.b_ps % 8 == 0 && d->a_pstride % 8 == 0 && g.vec_epi &&
+                       d->a_bstride % 8 == 0 && d->b_bstride % 8 == 0,
+                   "conv: F16X3 math needs K, lda, ldb, the plane / batch strides and the output rows in multiples of 8 elements");
       a_bytes_all = g.a_ps * 2 + a_bytes;          // one descriptor spans both planes
       b_bytes = (g.b_ps + (long long)d->Cn * g.ldb) * 2;
     }

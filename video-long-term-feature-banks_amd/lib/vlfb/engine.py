@@ -790,6 +790,13 @@ class AttentionStep(Step):
         gemm = lambda dtype=code, **kw: hip.conv_desc(mode=hip.FPROP, dtype=dtype, N=1, Tr=1, Hr=1, Wr=L1, Ts=1, Hs=1,
                                                       Ws=L1, batch=B, **kw)
         self.d_s = gemm(out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mf, **pl)
+        # theta and phi as two fp16 planes (Engine._plan_pairs): the scores are a batched two-plane product (no plane pass over phi,
+        # nothing converted in the loop); the backward reads their hi planes as before
+        self.s_pair = bool(self.theta.root.pair and self.phi.root.pair)
+        assert bool(self.theta.root.pair) == bool(self.phi.root.pair) and not self.g.root.pair
+        if self.s_pair:
+            self.d_s = gemm(dtype=hip.F16, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2,
+                            math=hip.MATH_F16X3, a_pstride=B * L1 * Ci, b_pstride=B * L2 * Ci)
         self.o_pair = bool(self.out.root.pair)           # (Engine._plan_pairs: y leaves the P . g product as two fp16 planes)
         self.d_y = gemm(out_dtype=hip.F16 if self.o_pair else code, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci, math=mf, **pl)
         self.d_dp = gemm(dtype=bcode, out_dtype=hip.F32, Cs=Ci, Cn=L2, a_bstride=L1 * Ci, b_bstride=L2 * Ci, o_bstride=L1 * L2, math=mb, **bpl)
@@ -865,7 +872,10 @@ class AttentionStep(Step):
                 hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, self.prob.storage())
             else:
                 S = eng.scratch_f32(B * L1 * L2)
-                hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, S)
+                if self.s_pair:
+                    hip.conv_run(self.d_s, self.theta.storage(), self.phi.storage(), None, S)
+                else:
+                    hip.conv_run(self.d_s, self.theta.storage(), self._planes(self.phi.storage(), nf, False), None, S)
                 hip.call("vlfb_softmax_fwd", hip.ptr(S), self.prob.ptr(), eng.code, B * L1, L2, self.scale)
             hip.conv_run(self.d_y, self.prob.storage(), self._planes(self.g.storage(), nf, True), None, self.out.storage(),
                          O_lo=self.out.lo() if self.o_pair else None)
@@ -2225,6 +2235,7 @@ class Engine(object):
     # (hip.MATH_F16X3) -- VLFB_MIX_PAIR=0: the round-5 form (fp32 storage, split-bf16 products, separate fp16 copies)
     MIX_PAIR = os.environ.get("VLFB_MIX_PAIR", "1") != "0"
     PAIR_ATTENTION_OUT = os.environ.get("VLFB_PAIR_ATTN_OUT", "1") != "0"      # (A/B switch)
+    PAIR_SCORES = os.environ.get("VLFB_PAIR_SCORES", "1") != "0"                # (A/B switch: theta / phi as two planes)
 
     def _plan_pairs(self):
         """Which activations are stored as two fp16 planes (Blob.pair).  A blob qualifies when a conv or a max pool over a
@@ -2248,8 +2259,9 @@ class Engine(object):
                     getattr(b, "is_input", False):
                 continue
             st = b.producer
-            if (isinstance(st, ConvStep) and st.group == 1 and st.out is b and not b.grad_f32) or (isinstance(st, PoolStep) and st.is_max):
-                cand[id(b)] = b
+            if (isinstance(st, ConvStep) and st.group == 1 and st.out is b and (not b.grad_f32 or self.PAIR_SCORES)) or \
+                    (isinstance(st, PoolStep) and st.is_max):
+                cand[id(b)] = b            # (an fp32-gradient conv output -- theta / phi / g -- only survives as theta / phi below)
             elif isinstance(st, AttentionStep) and st.theta.shape[2] > 1 and not st.dot and st.out is b and self.PAIR_ATTENTION_OUT:
                 # the attention output of a non-local block: its P . g product writes two planes (split-bf16 launch with a
                 # two-plane output), so the `out` conv behind it is a two-plane conv as well
@@ -2280,6 +2292,10 @@ class Engine(object):
                             ok = ok and id(st.residual.root) in cand       # (two-plane input + fp32 residual: no kernel)
                     elif isinstance(st, PoolStep):
                         ok = ok and (not st.is_max or id(st.out.root) in cand) and v.caxis == 1 and len(v.shape) == 5
+                    elif isinstance(st, AttentionStep) and st.theta.shape[2] > 1 and not st.dot and self.PAIR_SCORES and \
+                            (v.root is st.theta.root or v.root is st.phi.root) and v.root is not st.g.root:
+                        # the scores product theta x phi^T of a non-local block as a batched two-plane product: both or neither
+                        ok = ok and id(st.theta.root) in cand and id(st.phi.root) in cand
                     else:
                         ok = False
                 if isinstance(p, ConvStep) and p.residual is not None:
