@@ -3,7 +3,7 @@
 O=gpurun_out/${1:-prof}
 mkdir -p $O
 R=$(pwd)
-X="--no-cpu-baseline --no-fp32-line --no-split-line --no-mix-line --no-fp16-line"
+X="--no-cpu-baseline --no-fp32-line --no-split-line --no-mix-line --no-fp16-line --no-bf16-line"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/$O/prof_mix -o stats -- python $R/bench.py --steps 12 --warmup 3 $X ${@:2} > $R/$O/prof_mix.log 2>&1
 cd $R
