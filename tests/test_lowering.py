@@ -376,3 +376,17 @@ def test_dot_product_nonlocal_variant_lowers_to_the_same_attention_step():
     a = att[-1]
     assert a.prob.name == "nonlocal_conv4_5_affinity_sc" and abs(a.d_s.alpha * a.L2 - 1.0) < 1e-6
     assert abs(a.d_dp.alpha * a.L2 / a.ds_scale - 1.0) < 1e-6
+
+
+def test_two_plane_storage_stops_at_the_fp32_head_with_and_without_dropout():
+    """Engine._plan_pairs: the FBO head's convs run the split-bf16 backward on fp32 VALUES (ConvStep.bwd_split), so their
+    blobs keep fp32 storage -- also when the dropouts between them are configured away and `lfb_1x1` feeds the phi / g convs
+    directly (the benchmark-plan test runs that graph; a conv output with an fp32 gradient slot may only become two-plane as
+    theta / phi of a space-time non-local block)."""
+    from vlfb.engine import ConvStep
+    for ov in ((), ("TRAIN.DROPOUT_RATE", 0.0, "FBO_NL.INPUT_DROPOUT_ON", False, "FBO_NL.LFB_DROPOUT_ON", False)):
+        cfg, m, eng = plan("ava_r50_lfb_nl", ov, dtype="mix")
+        assert len(eng.pair_blobs) == 80 and not [n for n in eng.pair_blobs if n.startswith(("lfb", "box_pooled", "pool5"))]
+        for st in eng.steps:
+            if isinstance(st, ConvStep) and st.bwd_split:
+                assert not st.x_pair and not st.o_pair, st.out.name

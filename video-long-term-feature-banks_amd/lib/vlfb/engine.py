@@ -2283,6 +2283,10 @@ class Engine(object):
                 p = b.producer
                 if isinstance(p, PoolStep):
                     ok = id(p.x.root) in cand
+                elif isinstance(p, ConvStep) and b.grad_f32:
+                    # a conv output with an fp32 gradient slot: only theta / phi of a space-time non-local block (the FBO
+                    # head's convs run the split-bf16 backward on fp32 VALUES: they keep fp32 storage)
+                    ok = all(isinstance(st, AttentionStep) for st, _ in consumers.get(id(b), []))
                 for st, v in consumers.get(id(b), []):
                     if isinstance(st, ConvStep):
                         ok = ok and conv_reads(st, b)
