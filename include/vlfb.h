@@ -49,6 +49,11 @@ enum { VLFB_MIX = 4, VLFB_MIX_W2 = 5 };
  * (w * s) * VLFB_MIX_W2_SCALE, planes [term][Cout][taps][Cin] (alpha of the launch carries 1 / VLFB_MIX_W2_SCALE); the
  * DGRAD copy as VLFB_MIX (VLFB_MIXH) or VLFB_MIX_W2 (VLFB_MIXH_W2) */
 enum { VLFB_MIXH = 6, VLFB_MIXH_W2 = 7 };
+/* ... with the two-term DGRAD copy INTERLEAVED per 64-channel k-tile: [Cin][taps][Cout / 64][term][64] (Cout % 64 == 0),
+ * the weight operand of vlfb_conv_desc.math = VLFB_MATH_F16W2 -- the two terms of a tap's 64 channels are consecutive
+ * k-tiles, contracted with ONE gradient tile (fetched into LDS and read from it once).  FPROP copy as VLFB_MIX (three bf16
+ * planes; VLFB_MIX_W2I) or as VLFB_MIXH (two fp16 planes; VLFB_MIXH_W2I). */
+enum { VLFB_MIX_W2I = 9, VLFB_MIXH_W2I = 10 };
 /* A TWO-PLANE fp16 tensor: [2][numel] fp16, value = plane 0 (hi = fp16(v)) + plane 1 (lo = fp16(v - hi)), ~22 significant
  * bits.  The storage format of the forward activations of the "mix" path: plane 0 alone is the fp16 tensor the fp16 backward
  * reads (WGRAD operand, ReLU mask).  vlfb_pool_desc.dtype of vlfb_maxpool_fwd (x, y two-plane) and vlfb_avgpool_fwd (x
@@ -68,7 +73,12 @@ enum { VLFB_MATH_NATIVE = 0, VLFB_MATH_BF16X3 = 3, VLFB_MATH_BF16X6 = 6,
         * converted in the k-loop; fp16 MFMA operands keep subnormals).  out_dtype VLFB_F16: the output is written as two
         * planes O / O_lo, the residual read as R / R_lo (vlfb_conv_args); out_dtype VLFB_F32: a plain fp32 output.
         * The split-bf16 maths accept out_dtype VLFB_F16 in the same sense (fp32 A operand, two-plane output / residual). */
-       VLFB_MATH_F16X3 = 13 };
+       VLFB_MATH_F16X3 = 13,
+       /* dtype VLFB_F16 / VLFB_BF16, unit-stride DGRAD with Cs % 64 == 0: the weight operand holds TWO 16-bit terms per
+        * value, rows [tap][Cs / 64][term][64] (vlfb_weight_prep* VLFB_MIX_W2I; ldb = 2 K), dX = dY . (Wh + Wl) with every
+        * gradient tile contracted with both terms (alpha carries 1 / VLFB_MIX_W2_SCALE).  The same product as the
+        * doubled-tap form of VLFB_MIX_W2 on 3/4 of its LDS DMA bytes and 2/3 of its LDS fragment reads. */
+       VLFB_MATH_F16W2 = 12 };
 
 enum {
   VLFB_OK = 0,

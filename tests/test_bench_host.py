@@ -21,6 +21,12 @@ def test_launch_families_and_mfma_instructions_per_product():
     w2 = d(mode=hip.DGRAD, dtype=hip.F16, out_dtype=hip.F16, kt=2, dt=0)
     assert hip.conv_family(w2) == ("nt_16", 2)
     assert hip.conv_flops(w2) == hip.conv_flops(d(mode=hip.DGRAD, dtype=hip.F16, out_dtype=hip.F16))
+    # ... or the two terms interleaved per 64-channel k-tile (MATH_F16W2): the same two MFMAs per product on the conv's own
+    # geometry; the weight operand is twice as many bytes, the fp16 output is not
+    wi = d(mode=hip.DGRAD, dtype=hip.F16, out_dtype=hip.F16, math=hip.MATH_F16W2)
+    plain = d(mode=hip.DGRAD, dtype=hip.F16, out_dtype=hip.F16)
+    assert hip.conv_family(wi) == ("nt_16", 2) and hip.conv_flops(wi) == hip.conv_flops(plain)
+    assert hip.conv_bytes(wi) == hip.conv_bytes(plain) + 64 * 64 * 2 and hip.conv_plan(wi) == "nt f16 128x64 ut w2 pre"
     # split-bf16 products on fp32 storage: three MFMAs per product (six in a six-term forward)
     assert hip.conv_family(d(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X3)) == ("nt_split", 3)
     assert hip.conv_family(d(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X6)) == ("nt_split", 6)

@@ -226,7 +226,14 @@ def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_n
     cfg, m, eng = plan("charades_r50_baseline", small, dtype="mix")
     convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.d_d is not None]
     # (hip.MIXH*: the same DGRAD copies next to a two-plane fp16 FPROP copy -- the convs whose input is stored as two planes)
-    assert convs and all(s.w2 and s.wcode == (hip.MIXH_W2 if s.x_pair else hip.MIX_W2) for s in convs)
+    def code_of(s):    # (w2i: the two terms interleaved per 64-channel k-tile, hip.MATH_F16W2 -- ConvStep._w2_interleaved)
+        return {(False, False): hip.MIX_W2, (True, False): hip.MIXH_W2, (False, True): hip.MIX_W2I, (True, True): hip.MIXH_W2I}[(s.x_pair, s.w2i)]
+    assert convs and all(s.w2 and s.wcode == code_of(s) for s in convs)
+    # the unit-stride convs that the 128-row kernel runs share one gradient tile between the two weight terms; the strided
+    # convs keep the doubled-tap form (class walk / in-place class-0 accumulate)
+    assert all((s.d_d.math == hip.MATH_F16W2 and s.d_d.kt == s.k[0] and s.d_d.dt == s.d[0]) if s.w2i else
+               (s.d_d.math == hip.MATH_NATIVE and s.d_d.kt == 2 and s.d_d.dt == 0) for s in convs)
+    assert all(not s.w2i for s in convs if tuple(s.s) != (1, 1, 1)) and sum(s.w2i for s in convs) > len(convs) // 2
     real = hip.conv_workspace_bytes
 
     def refuse_some(d):
@@ -238,8 +245,8 @@ def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_n
     convs = [s for s in eng.steps if isinstance(s, ConvStep) and s.d_d is not None]
     plain = [s for s in convs if not s.w2]
     assert plain and all(s.d_d.Cn == 64 and s.wcode == (hip.MIXH if s.x_pair else hip.MIX) and s.d_d.kt == s.k[0] and s.wd_npl == 1 for s in plain)
-    assert all(s.wcode == (hip.MIXH_W2 if s.x_pair else hip.MIX_W2) and s.wd_npl == 2 for s in convs if s.w2) and any(s.w2 for s in convs)
-    assert {s.wcode for s in convs} <= {hip.MIX, hip.MIX_W2, hip.MIXH, hip.MIXH_W2} and len({s.wcode for s in convs}) >= 2    # (one weight-prep batch per format: Engine._wprep_table)
+    assert all(s.wcode == code_of(s) and s.wd_npl == 2 for s in convs if s.w2) and any(s.w2 for s in convs)
+    assert {s.wcode for s in convs} <= {hip.MIX, hip.MIX_W2, hip.MIXH, hip.MIXH_W2, hip.MIX_W2I, hip.MIXH_W2I} and len({s.wcode for s in convs}) >= 2    # (one weight-prep batch per format: Engine._wprep_table)
 
 
 def test_strided_projection_shortcuts_run_their_dgrad_as_an_in_place_accumulate():
@@ -308,18 +315,25 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert not any(n.endswith(("_g", "_prob")) or n.startswith(("lfb", "box_pooled", "blob_pooled", "pool5")) for n in pairs)
     assert sorted(b.name for b in eng._half_inputs) == ["data_train"]     # (the bank is read by fp32 steps only: the FBO head)
     convs = {s.out.name: s for s in eng.steps if isinstance(s, ConvStep)}
-    c = convs["res4_1_branch2b_bn"]                       # 1x3x3: the term dimension is a doubled kt of dilation 0
+    c = convs["res4_1_branch2b_bn"]                       # 1x3x3, unit stride: the two weight terms interleaved per k-tile (MATH_F16W2)
     assert (c.d_f.dtype, c.d_f.out_dtype, c.d_f.math, c.d_f.kt) == (hip.F16, hip.F16, hip.MATH_F16X3, 1) and c.x_pair and c.o_pair
-    assert c.d_f.a_pstride == c.x.numel and abs(c.d_f.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.wcode == hip.MIXH_W2
+    assert c.d_f.a_pstride == c.x.numel and abs(c.d_f.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.wcode == hip.MIXH_W2I and c.w2 and c.w2i
     assert c.w_f.dtype == torch.float16 and c.w_f.shape[0] == 2 and hip.conv_plan(c.d_f).startswith("nt8_pair f16x3")         # (K = 2304: the 256-row pipelined form)
-    assert (c.d_d.dtype, c.d_d.math, c.d_d.kt, c.d_d.dt, c.d_d.kh, c.d_d.kw) == (hip.F16, hip.MATH_NATIVE, 2, 0, 3, 3)
+    assert (c.d_d.dtype, c.d_d.math, c.d_d.kt, c.d_d.dt, c.d_d.kh, c.d_d.kw) == (hip.F16, hip.MATH_F16W2, 1, 1, 3, 3)
+    assert hip.conv_plan(c.d_d) == "nt f16 128x128 ut w2" and hip.conv_family(c.d_d) == ("nt_16", 2)
     assert abs(c.d_d.alpha * hip.MIX_W2_SCALE - 1.0) < 1e-6 and c.w_d.numel() == c.w_f.numel()
-    assert hip.conv_flops(c.d_d) == hip.conv_flops(c.d_f)          # the doubled taps are not algorithmic work
+    assert hip.conv_flops(c.d_d) == hip.conv_flops(c.d_f)          # the second term is not algorithmic work
     assert (c.d_w.dtype, c.d_w.out_dtype, c.d_w.math) == (hip.F16, hip.F32, hip.MATH_NATIVE)
-    a = convs["res4_2_branch2a_bn"]                       # 3x1x1: T plays H, H x W one pointwise axis, T' = 1 carries the terms
-    N, _, T, H, W = a.x.shape
+    sc = convs["res4_0_branch2b_bn"]                      # 1x3x3, stride (1, 2, 2): the class walk on a doubled kt of dilation 0
+    assert (sc.d_d.dtype, sc.d_d.math, sc.d_d.kt, sc.d_d.dt, sc.d_d.kh, sc.d_d.kw) == (hip.F16, hip.MATH_NATIVE, 2, 0, 3, 3)
+    assert sc.w2 and not sc.w2i and sc.wcode == hip.MIXH_W2 and hip.conv_flops(sc.d_d) == hip.conv_flops(sc.d_f)
+    a = convs["res4_0_branch2a_bn"]                       # 3x1x1 that the library gives to the 256-row kernel: the doubled-tap form,
+    N, _, T, H, W = a.x.shape                             # T plays H, H x W one pointwise axis, T' = 1 carries the terms
+    assert not a.w2i and hip.conv_plan(a.d_d).startswith("nt8 ")
     assert (a.d_d.kt, a.d_d.dt, a.d_d.kh, a.d_d.kw, a.d_d.ph) == (2, 0, 3, 1, 1)
     assert (a.d_d.Tr, a.d_d.Hr, a.d_d.Wr, a.d_d.Ts, a.d_d.Hs, a.d_d.Ws) == (1, T, H * W, 1, T, H * W)
+    a2 = convs["res4_2_branch2a_bn"]                      # the same conv shape on the 128-row kernel: its own 3-D geometry
+    assert a2.w2i and (a2.d_d.math, a2.d_d.kt, a2.d_d.dt, a2.d_d.kh, a2.d_d.pt) == (hip.MATH_F16W2, 3, 1, 1, 1)
     # fp32 gradients and split products around the non-local softmax
     f32 = sorted(b.name for b in eng.all_blobs if b.root is b and b.grad_f32 and b.name not in eng.head_f32 + eng.head_f32_fbo)
     assert len(f32) == 20 and all(n.rsplit("_", 1)[1] in ("theta", "phi", "g", "y") for n in f32), f32

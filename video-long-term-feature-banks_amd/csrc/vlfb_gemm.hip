@@ -787,6 +787,7 @@ struct Plan {
   int sp_pl;      //   operands arrive as bf16 term planes (WGRAD: both; FPROP / DGRAD: the activation operand)
   int bias_fused; // WGRAD with desc.wgrad_bias: the launch itself produces the column sums of P (gemm_tn_tr_kernel)
   int h2;         // VLFB_MATH_F16X3: both operands as two fp16 planes, three fp16 MFMAs per product (vlfb_gemm_pair.hip)
+  int w2i;        // VLFB_MATH_F16W2: unit-stride 16-bit DGRAD, two-term weights interleaved per 64-channel k-tile (gemm_nt_kernel<.., W2I>)
   size_t stem_lds;
   dim3 grid;
   size_t lds;
@@ -799,21 +800,25 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   VLFB_REQUIRE(dtype_ok(d->dtype), "conv: bad dtype %d", d->dtype);
   VLFB_REQUIRE(d->out_dtype == VLFB_F32 || d->out_dtype == d->dtype || (d->out_dtype == VLFB_F16 && d->math != VLFB_MATH_NATIVE), "conv: bad out_dtype");
   VLFB_REQUIRE(d->mode >= 0 && d->mode <= 2, "conv: bad mode %d", d->mode);
-  VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || d->math == VLFB_MATH_BF16X3 || d->math == VLFB_MATH_BF16X6 || d->math == VLFB_MATH_F16X3,
-               "conv: bad math %d", d->math);
+  VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || d->math == VLFB_MATH_BF16X3 || d->math == VLFB_MATH_BF16X6 || d->math == VLFB_MATH_F16X3 ||
+                   d->math == VLFB_MATH_F16W2, "conv: bad math %d", d->math);
   pl->h2 = d->math == VLFB_MATH_F16X3;
+  pl->w2i = d->math == VLFB_MATH_F16W2;
+  VLFB_REQUIRE(!pl->w2i || (is16(d->dtype) && d->mode == VLFB_CONV_DGRAD && d->st == 1 && d->sh == 1 && d->sw == 1 && !d->pack_w &&
+                            d->Cs % 64 == 0 && d->batch <= 1 && (d->algo == VLFB_ALGO_AUTO || d->algo == VLFB_ALGO_TILE128)),
+               "conv: F16W2 math is the 16-bit DGRAD of a unit-stride conv with Cs %% 64 == 0 (two-term weights, VLFB_MIX_W2I)");
   VLFB_REQUIRE(!pl->h2 || (d->dtype == VLFB_F16 && d->mode == VLFB_CONV_FPROP && d->a_pstride > 0 && d->algo != VLFB_ALGO_STREAM &&
                            d->algo != VLFB_ALGO_CLASSES && d->algo != VLFB_ALGO_CLASS0),
                "conv: F16X3 math is an FPROP / NT product on fp16 planes (dtype VLFB_F16, a_pstride > 0)");
   // (split-bf16 FPROP / DGRAD with out_dtype VLFB_F16: the output -- and the residual, if any -- are two fp16 planes,
   // O / O_lo and R / R_lo of vlfb_conv_args: where an fp32 tensor enters the two-plane forward of the "mix" path)
-  VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || pl->h2 ||
+  VLFB_REQUIRE(d->math == VLFB_MATH_NATIVE || pl->h2 || pl->w2i ||
                    (d->dtype == VLFB_F32 && (d->out_dtype == VLFB_F32 || (d->out_dtype == VLFB_F16 && d->mode != VLFB_CONV_WGRAD && !d->o_planes))),
                "conv: split-bf16 math needs fp32 operands and an fp32 (or two-plane fp16) output");
   VLFB_REQUIRE(d->math != VLFB_MATH_BF16X6 || d->mode != VLFB_CONV_WGRAD, "conv: WGRAD has no BF16X6 form (use BF16X3)");
   VLFB_REQUIRE(!d->accumulate || d->mode == VLFB_CONV_WGRAD, "conv: accumulate (O += ...) is a WGRAD epilogue");
   VLFB_REQUIRE(!d->wgrad_bias || d->mode == VLFB_CONV_WGRAD, "conv: wgrad_bias belongs to WGRAD descriptors");
-  pl->sp = d->math == VLFB_MATH_BF16X6 ? 3 : d->math == VLFB_MATH_BF16X3 ? 2 : 0;
+  pl->sp = d->math == VLFB_MATH_BF16X6 ? 3 : d->math == VLFB_MATH_BF16X3 ? 2 : 0;     // (0 for F16X3 / F16W2)
   pl->sp_kind = 0;
   VLFB_REQUIRE(pl->sp || (!d->a_planes && !d->p_planes && !d->o_planes), "conv: a_planes / p_planes / o_planes belong to split-bf16 math");
   VLFB_REQUIRE(d->mode == VLFB_CONV_WGRAD ? (d->a_planes ? d->a_planes >= 2 && d->p_planes == 2 : d->p_planes == 0) && !d->o_planes
@@ -846,6 +851,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   }
   pl->ident = !pl->packw && taps == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
               d->ph == 0 && d->pw == 0 && d->Ts == d->Tr && d->Hs == d->Hr && d->Ws == d->Wr;
+  if (pl->w2i) pl->ident = false;        // (a 1x1x1 conv walks the tap cursor over its one tap)
   if (!pl->ident) {
     VLFB_REQUIRE(ilog2_exact(cpt) >= 0, "conv: channels per tap must give a power-of-two chunk count");
     VLFB_REQUIRE(ilog2_exact(d->st) >= 0 && ilog2_exact(d->sh) >= 0 && ilog2_exact(d->sw) >= 0,
@@ -861,7 +867,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   g.lst = ilog2_exact(d->st); g.lsh = ilog2_exact(d->sh); g.lsw = ilog2_exact(d->sw);
   g.cpt_shift = pl->ident ? 0 : ilog2_exact(cpt);
   g.lda = d->lda ? d->lda : d->Cs;
-  g.ldb = d->ldb ? d->ldb : (int)K;
+  g.ldb = d->ldb ? d->ldb : (int)(pl->w2i ? 2 * K : K);      // (F16W2: a weight row holds both terms)
   g.ldp = d->ldp ? d->ldp : d->Cn;
   g.ldo = d->ldo ? d->ldo : (d->mode == VLFB_CONV_WGRAD ? (int)K : d->Cn);
   g.ldr = d->ldr ? d->ldr : g.ldo;
@@ -1081,7 +1087,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
     // (two fp16 planes, pl->h2: a k-tile is 32 k of both planes -- taps of whole 32-channel runs; FPROP / plain rows only)
     const bool gather_ok = pl->ident || (!d->pack_w && ((long long)d->Cs * es) % (pl->h2 ? 64 : 128) == 0 && taps <= 32 &&
                                          (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
-    const bool ok = is16(d->dtype) && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024 &&
+    const bool ok = is16(d->dtype) && g.vec_epi && gather_ok && d->Cn >= 128 && K >= 128 && M >= 1024 && !pl->w2i &&
                     (!pl->h2 || (K % 32 == 0 && batch == 1));
     if (d->algo == VLFB_ALGO_PIPE256)
       VLFB_REQUIRE(ok, "conv: algo = PIPE256 needs bf16 / f16, Cn >= 128, K >= 128, M >= 1024, 16-byte aligned rows and "
@@ -1127,7 +1133,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
                                          (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1)));
     const int uk = nts_chunk(mode, K);
     const bool shape_ok = (d->Cn == 64 || d->Cn == 128 || d->Cn == 256) && d->Cs % 64 == 0 && uk > 0 && M < (1ll << 24);
-    const bool ok = is16(d->dtype) && !pl->h2 && d->out_dtype == d->dtype && batch == 1 && shape_ok && gather_ok &&
+    const bool ok = is16(d->dtype) && !pl->h2 && !pl->w2i && d->out_dtype == d->dtype && batch == 1 && shape_ok && gather_ok &&
                     g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldo % 8 == 0 && g.ldr % 8 == 0 &&
                     (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
                     (long long)d->Cn * K * 2 + d->Cn * 4 <= 156 * 1024 &&
@@ -1146,12 +1152,12 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->stemf = d->mode == VLFB_CONV_FPROP && pl->packw && d->algo == VLFB_ALGO_AUTO && !pl->h2 &&
               (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
               stem_fprop_ok(g, d->pack_w, d->dtype, d->out_dtype, batch);
-  pl->rows64 = d->mode != VLFB_CONV_WGRAD && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && !pl->h2 &&
+  pl->rows64 = d->mode != VLFB_CONV_WGRAD && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && !pl->h2 && !pl->w2i &&
                (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
                conv_rows64_ok(g, d->mode, d->dtype, d->out_dtype, batch);
   // a handful of plain rows (the FBO head on one row per RoI): 16-column workgroups whose waves split K
   static const bool skinny_off = getenv("VLFB_SKINNY") && atoi(getenv("VLFB_SKINNY")) == 0;      // (A/B switch)
-  pl->skinny = d->mode != VLFB_CONV_WGRAD && d->algo == VLFB_ALGO_AUTO && !skinny_off && !pl->sp && !pl->h2 && !pl->rows64 &&
+  pl->skinny = d->mode != VLFB_CONV_WGRAD && d->algo == VLFB_ALGO_AUTO && !skinny_off && !pl->sp && !pl->h2 && !pl->w2i && !pl->rows64 &&
                (d->out_dtype == d->dtype || d->out_dtype == VLFB_F32) && skinny_nt_ok(g, d->dtype, batch, pl->ident);
   pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
   pl->pre = 0;
@@ -1195,7 +1201,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   if (d->mode != VLFB_CONV_WGRAD) {
     pl->ut = !pl->ident && !d->pack_w && ((pl->sp || pl->h2) ? d->Cs % 32 == 0 : ((long long)d->Cs * es) % pl->rb == 0) &&
              (d->mode == VLFB_CONV_FPROP || (d->st == 1 && d->sh == 1 && d->sw == 1));
-    const long long ktiles = pl->h2 ? (K + 31) / 32 : (K * es + pl->rb - 1) / pl->rb;   // (two planes: a 128-byte row is 32 k)
+    const long long ktiles = pl->h2 ? (K + 31) / 32 : (pl->w2i ? 2 : 1) * ((K * es + pl->rb - 1) / pl->rb);   // (two planes: a 128-byte row is 32 k)
     if (pl->h2) {
       if (pl->packw && d->pack_w == 8) {
         // the packed stem as a kw = 1 conv of 32 "channels" per (a, b) tap row (see the split-bf16 form below)
@@ -1204,6 +1210,7 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
       }
       VLFB_REQUIRE(pl->ident || pl->ut, "conv: F16X3 math needs plain rows or taps that span whole 32-element k-tiles");
     }
+    VLFB_REQUIRE(!pl->w2i || (pl->ut && g.vec_epi), "conv: F16W2 math needs taps of whole 64-channel runs and 16-byte aligned output rows");
     const size_t buf = (size_t)(pl->bm + pl->bn) * pl->rb;
     pl->lds = (ktiles <= 1 ? 1 : 2) * buf;           // a single k-tile needs no second buffer
     const size_t tile = (size_t)pl->bm * pl->bn * 4;
@@ -1262,6 +1269,12 @@ void launch_k(K kernel, const Plan& pl, hipStream_t s) {
 template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW>
 void launch_nt_shape(const Plan& pl, hipStream_t s) {
   if constexpr (!IDENT && !PACKW) {
+    if constexpr (DGRAD && sizeof(T) == 2) {
+      if (pl.w2i) {
+        launch_k(gemm_nt_kernel<T, OutT, BM, BN, IDENT, DGRAD, PACKW, RB, PRE, NW, 2, true, false, true>, pl, s);
+        return;
+      }
+    }
     if (pl.ut) {
       launch_k(gemm_nt_kernel<T, OutT, BM, BN, IDENT, DGRAD, PACKW, RB, PRE, NW, 2, true>, pl, s);
       return;
@@ -1410,8 +1423,8 @@ extern "C" int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64
     else if (h16 && pl.nts) fam = "nt_stream";
     else if (h16 && pl.nt8) { fam = "nt8"; bm = pl.nt8_bm; bn = pl.nt8; }
     else fam = "nt";
-    snprintf(buf, (size_t)buf_bytes, "%s %s %dx%d%s%s%s", fam, dt, bm, bn, pl.ut ? " ut" : "", pl.gp.s2 ? (d->algo == VLFB_ALGO_CLASS0 ? " class0" : " classes") : "",
-             pl.pre ? " pre" : "");
+    snprintf(buf, (size_t)buf_bytes, "%s %s %dx%d%s%s%s%s", fam, dt, bm, bn, pl.ut ? " ut" : "", pl.gp.s2 ? (d->algo == VLFB_ALGO_CLASS0 ? " class0" : " classes") : "",
+             pl.w2i ? " w2" : "", pl.pre ? " pre" : "");
   }
   return VLFB_OK;
 }

@@ -10,8 +10,15 @@ namespace {
 // NT kernel: O[m][n] = sum_k X[m][k] * W[n][k]   (X gathered: FPROP / DGRAD / identity)
 // =============================================================================================
 template <typename T, typename OutT, int BM, int BN, bool IDENT, bool DGRAD, bool PACKW, int RB, bool PRE, int NW,
-          int ST = 2, bool UT = false, bool PAIR = false>
+          int ST = 2, bool UT = false, bool PAIR = false, bool W2I = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
+  // W2I (16-bit unit-stride DGRAD with TWO-TERM weights, vlfb_conv_desc.math = VLFB_MATH_F16W2; the backward of the "mix"
+  // path): the weight rows are [tap][Cs / 64][term][64] (vlfb_weight_prep* VLFB_MIX_W2I), i.e. the k-tiles of the weight
+  // operand alternate Wh, Wl of the SAME 64 channels of the same tap, and both are contracted with ONE gradient tile: the
+  // A tile of a pair is fetched once (into its own double buffer, indexed by the pair), its fragments are read from LDS
+  // once and stay in registers for the second term.  Against the doubled-tap form of the same product (kt' = 2 kt,
+  // dt = 0: every A tile fetched and read twice) that is 3/4 of the DMA bytes and 2/3 of the LDS fragment reads per MFMA.
+  static_assert(!W2I || (sizeof(T) == 2 && RB == 128 && ST == 2 && UT && DGRAD && !PAIR), "W2I: 16-bit unit-stride DGRAD on the tap cursor");
   // PAIR (fp16 only; the forward of the "mix" path, vlfb_conv_desc.math = VLFB_MATH_F16X3): both operands are TWO fp16
   // planes, value = hi + lo (hi = fp16(v), lo = fp16(v - hi): ~22 significant bits; fp16 MFMA operands keep subnormals,
   // probed on MI355X), GP::a_ps / b_ps elements apart.  A 128-byte LDS row holds 32 k of the hi plane (chunks 0-3) and
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
 
   int ktiles = (p.K * (int)sizeof(T) + (PAIR ? RB / 2 : RB) - 1) / (PAIR ? RB / 2 : RB);
+  if constexpr (W2I) ktiles *= 2;          // (Wh, Wl) per activation tile
   // class-major strided DGRAD: only the taps with (h + ph - b) and (w + pw - c) even exist for this tile's class
   // (b = b0, b0 + 2, ..; c likewise).  The k-loop walks those taps in ascending order -- the order of the full
   // walk with the structurally-zero taps left out -- through a scalar cursor, one k-tile per load_tile call.
@@ -182,9 +190,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
     TapC tap;
     if (IDENT || UT) { tap.ok = kc * EPC < p.K; tap.a = tap.b = tap.c = tap.ci = 0; }
     else tap = decode_tap<T, PACKW>(p, kc);
-    const bool kok = kc * EPC < p.K;
+    const bool kok = W2I || kc * EPC < p.K;      // (W2I: taps of whole 64-channel runs, every k-tile is full)
     {
-      char* xa = smem + buf * BUF + wave_u * 1024;
+      // W2I: the activation tile of pair kt_seq / 2 has its own double buffer (the A halves of the two ring slots)
+      char* xa = smem + (W2I ? (kt_seq >> 1) & 1 : buf) * BUF + wave_u * 1024;
       char* wb = smem + buf * BUF + BM * RB + wave_u * 1024;
       // the last k-tile may end inside the row (K * sizeof(T) % RB != 0): chunks past K are padding
       const unsigned kbyte = (unsigned)kt * KTB;
@@ -192,16 +201,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
         const int sgn = DGRAD ? -1 : 1;
         const int da = sgn * u_a * p.dt, db = sgn * u_b * p.dh, dc = sgn * u_c * p.dw;   // scalar
         const unsigned dbyte = (unsigned)(((da * p.Hs + db) * p.Ws + dc) * p.lda + ((PAIR && p.pair_il) ? 2 * u_ci : u_ci)) * (unsigned)sizeof(T);
+        if (!W2I || !(kt_seq & 1)) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-          const bool ok = aok[i] && (unsigned)(arow[i].t + da) < (unsigned)p.Ts &&
-                          (unsigned)(arow[i].h + db) < (unsigned)p.Hs && (unsigned)(arow[i].w + dc) < (unsigned)p.Ws;
-          bufglds16(rsA, ok ? aoff[i] + dbyte : kOOB, 0, xa + i * (RPPS * RB));
-        }
-        u_ci += (PAIR ? RB / 2 : RB) / (int)sizeof(T);
-        if (u_ci >= p.Cs) {
-          u_ci = 0;
-          if (++u_c == p.kw) { u_c = 0; if (++u_b == p.kh) { u_b = 0; ++u_a; } }
+          for (int i = 0; i < A_IT; ++i) {
+            const bool ok = aok[i] && (unsigned)(arow[i].t + da) < (unsigned)p.Ts &&
+                            (unsigned)(arow[i].h + db) < (unsigned)p.Hs && (unsigned)(arow[i].w + dc) < (unsigned)p.Ws;
+            bufglds16(rsA, ok ? aoff[i] + dbyte : kOOB, 0, xa + i * (RPPS * RB));
+          }
+          u_ci += (PAIR ? RB / 2 : RB) / (int)sizeof(T);
+          if (u_ci >= p.Cs) {
+            u_ci = 0;
+            if (++u_c == p.kw) { u_c = 0; if (++u_b == p.kh) { u_b = 0; ++u_a; } }
+          }
         }
       } else if (IDENT) {
 #pragma unroll
@@ -281,6 +292,66 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
     if (s0 < ktiles) load_tile(s0, s0);
 
   int cur = 0, nxt = ST - 1;              // ring slots of tile kt and of tile kt + ST - 1
+  if constexpr (W2I) {
+    // pairs of k-tiles (Wh, Wl of one activation tile).  Weight tile kt lives in the W half of ring slot kt & 1, the
+    // activation tile of the pair in the A half of slot (kt >> 1) & 1.  Behind the first barrier of a pair every wave has
+    // finished the previous pair (its Wl tile in slot 1 may be refilled); behind the second one every wave has read its A
+    // fragments and the Wh tile, so slot 0's W half and the OTHER A half take the next pair's DMA.
+    // (PRE instances hold the prefetched residual / mask rows in registers through the k-loop: there the A fragments are
+    // read again for the second term instead of kept -- 148 VGPRs = one workgroup per CU otherwise, measured 0.8x)
+    constexpr bool HOLD = !PRE;
+    for (int kt = 0; kt < ktiles; kt += 2) {
+      typename Mma<T>::Frag xf[KSTEPS][FM];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      load_tile(kt + 1, 1);
+      {
+        const char* xa = smem + ((kt >> 1) & 1) * BUF;
+        const char* wb = smem + BM * RB;
+        if constexpr (HOLD) {
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xf[ks][i] = Mma<T>::template load<RB>(xa, wm * WM + i * 16 + l15, ks, g);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          typename Mma<T>::Frag wf[FN];
+          if constexpr (!HOLD) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xf[ks][i] = Mma<T>::template load<RB>(xa, wm * WM + i * 16 + l15, ks, g);
+          }
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wf[j] = Mma<T>::template load<RB>(wb, wn * WN + j * 16 + l15, ks, g);
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[j][i] = Mma<T>::mma(wf[j], xf[ks][i], acc[j][i]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      if (kt + 2 < ktiles) load_tile(kt + 2, 0);
+      {
+        const char* xa = smem + ((kt >> 1) & 1) * BUF;
+        const char* wb = smem + BUF + BM * RB;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          typename Mma<T>::Frag wf[FN];
+          if constexpr (!HOLD) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xf[ks][i] = Mma<T>::template load<RB>(xa, wm * WM + i * 16 + l15, ks, g);
+          }
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wf[j] = Mma<T>::template load<RB>(wb, wn * WN + j * 16 + l15, ks, g);
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[j][i] = Mma<T>::mma(wf[j], xf[ks][i], acc[j][i]);
+        }
+      }
+    }
+  } else
   for (int kt = 0; kt < ktiles; ++kt) {
     const int ahead = ktiles - 1 - kt;    // tiles after kt
     ring_wait(ahead < ST - 2 ? ahead : ST - 2);

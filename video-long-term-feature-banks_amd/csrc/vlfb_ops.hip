@@ -179,6 +179,12 @@ template <> struct WStore<MixHW> {
   __device__ static __forceinline__ void dgrad(void* base, long long idx, long long, float v) { reinterpret_cast<unsigned short*>(base)[idx] = f2h(v); }
 };
 template <> struct WStore<MixHW2> : WStore<MixHW> {};
+// VLFB_MIX_W2I / VLFB_MIXH_W2I: the two-term DGRAD copy interleaved per 64-channel k-tile, [Cin][taps][Cout / 64][term][64]
+// (the weight operand of VLFB_MATH_F16W2: gemm_nt_kernel<.., W2I>)
+struct MixW2I {};
+struct MixHW2I {};
+template <> struct WStore<MixW2I> : WStore<MixW> {};
+template <> struct WStore<MixHW2I> : WStore<MixHW> {};
 
 template <typename T>
 __device__ __forceinline__ void wstore_dgrad(void* base, int ci, int tap, int co, int taps, int cout, long long plane, float v) {
@@ -188,6 +194,12 @@ __device__ __forceinline__ void wstore_dgrad(void* base, int ci, int tap, int co
     const unsigned short h = f2h(sv);
     o[0] = h;
     o[(long long)taps * cout] = f2h(sv - h2f(h));
+  } else if constexpr (std::is_same<T, MixW2I>::value || std::is_same<T, MixHW2I>::value) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(base) + (((long long)ci * taps + tap) * cout + (co & ~63)) * 2 + (co & 63);
+    const float sv = v * VLFB_MIX_W2_SCALE;
+    const unsigned short h = f2h(sv);
+    o[0] = h;
+    o[64] = f2h(sv - h2f(h));
   } else {
     WStore<T>::dgrad(base, ((long long)ci * taps + tap) * cout + co, plane, v);
   }
@@ -1286,7 +1298,8 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
                                 vlfb_stream_t stream) {
   VLFB_REQUIRE(w && (w_fprop || w_dgrad) && cout > 0 && taps > 0 && cin > 0, "weight_prep: bad args");
   VLFB_REQUIRE(dtype == VLFB_F32 || is16(dtype) || dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2 || dtype == VLFB_MIXH ||
-                   dtype == VLFB_MIXH_W2, "weight_prep: bad dtype");
+                   dtype == VLFB_MIXH_W2 || dtype == VLFB_MIX_W2I || dtype == VLFB_MIXH_W2I, "weight_prep: bad dtype");
+  VLFB_REQUIRE((dtype != VLFB_MIX_W2I && dtype != VLFB_MIXH_W2I) || !w_dgrad || cout % 64 == 0, "weight_prep: the interleaved two-term DGRAD copy needs Cout %% 64 == 0");
   VLFB_REQUIRE(taps < 65536, "weight_prep: too many taps");
   hipStream_t s = (hipStream_t)stream;
   const long long total = cout * taps * cin;
@@ -1294,9 +1307,9 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
     int grid = grid_for(total, 256);
     if (dtype == VLFB_F32)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<float>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
-    else if (dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2)
+    else if (dtype == VLFB_SPLIT || dtype == VLFB_MIX || dtype == VLFB_MIX_W2 || dtype == VLFB_MIX_W2I)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<SplitW>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
-    else if (dtype == VLFB_MIXH || dtype == VLFB_MIXH_W2)
+    else if (dtype == VLFB_MIXH || dtype == VLFB_MIXH_W2 || dtype == VLFB_MIXH_W2I)
       hipLaunchKernelGGL(weight_prep_fprop_kernel<MixHW>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total);
     else
       VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_fprop_kernel<T16>, dim3(grid), dim3(256), 0, s, w, scale, w_fprop, (long long)(taps * cin), total));
@@ -1311,6 +1324,8 @@ extern "C" int vlfb_weight_prep(const float* w, const float* scale, void* w_fpro
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else if (dtype == VLFB_MIX_W2 || dtype == VLFB_MIXH_W2)
       hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW2>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
+    else if (dtype == VLFB_MIX_W2I || dtype == VLFB_MIXH_W2I)
+      hipLaunchKernelGGL(weight_prep_dgrad_kernel<MixW2I>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin);
     else
       VLFB_WITH_T16(dtype, hipLaunchKernelGGL(weight_prep_dgrad_kernel<T16>, grid, dim3(32, 8), 0, s, w, scale, w_dgrad, (int)cout, (int)taps, (int)cin));
   }
@@ -1680,6 +1695,10 @@ extern "C" int vlfb_weight_prep_batched(const vlfb_wprep_item* items_dev, int n_
     hipLaunchKernelGGL(weight_prep_batched_kernel<MixHW>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else if (dtype == VLFB_MIXH_W2)
     hipLaunchKernelGGL(weight_prep_batched_kernel<MixHW2>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_MIX_W2I)      // (the caller keeps Cout % 64 == 0 for these items: vlfb_weight_prep checks it per conv)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<MixW2I>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
+  else if (dtype == VLFB_MIXH_W2I)
+    hipLaunchKernelGGL(weight_prep_batched_kernel<MixHW2I>, dim3((unsigned)total_tiles), block, 0, (hipStream_t)stream, items_dev, n_items);
   else return set_error(VLFB_ERR_ARG, "weight_prep_batched: bad dtype");
   return check_launch("weight_prep_batched");
 }

@@ -333,6 +333,7 @@ class ConvStep(Step):
         self.d_d = None
         self.d_d_full = None
         self.w2 = False
+        self.w2i = False                # (two-term DGRAD weights interleaved per k-tile: hip.MATH_F16W2 / MIX_W2I)
         self.bwd_split = False
         self.dx_f32 = False
         self.bwd_f32 = bool(eng.mix and self.out.root.grad_f32)
@@ -349,15 +350,22 @@ class ConvStep(Step):
             # on the `split` dtype -- fp32 gradient in and out, three bf16 products per product, bf16 term planes of W
             self.bwd_split = bool(eng.mix and self.out.root.grad_f32 and self.x.root.grad_f32 and G == 1)
             w2 = self._w2_geometry(dg, rows) if (eng.mix and eng.MIX_W2 and not self.bwd_split) else None
+            math_d = mb
             if w2 is not None:
-                dg, rows = w2
                 alpha /= hip.MIX_W2_SCALE
                 self.w2 = True
+                if self._w2_interleaved(w2, dg, rows):
+                    # the same two-term product with ONE gradient tile per (Wh, Wl) pair of weight tiles (hip.MATH_F16W2): the
+                    # conv's own DGRAD geometry, weight rows [tap][Cout / 64][term][64]
+                    self.w2i = True
+                    math_d = hip.MATH_F16W2
+                else:
+                    dg, rows = w2
             # ("mix": an input whose gradient slot is fp32 -- box_pooled, the attention output of a non-local block -- gets
             # the fp32 accumulators of the fp16 DGRAD as they are, not their fp16 rounding)
             self.dx_f32 = bool(eng.mix and self.x.root.grad_f32)
             self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=hip.F32 if self.dx_f32 else bcode, Cs=self.Cog,
-                                     Cn=Cin // G, alpha=alpha, math=mb, **rows, **bplanes, **dg, **ld_d)
+                                     Cn=Cin // G, alpha=alpha, math=math_d, **rows, **bplanes, **dg, **ld_d)
             if self.bwd_split:
                 self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, Cs=self.Cog, Cn=Cin // G, alpha=alpha,
                                          math=hip.MATH_BF16X3, **rows, **planes, **dg, **ld_d)
@@ -439,10 +447,11 @@ class ConvStep(Step):
         # the format vlfb_weight_prep writes this conv's operand copies in ("mix": two-term or plain fp16 DGRAD copy, per conv --
         # ConvStep._w2_geometry; a conv without a DGRAD copy goes with the engine's default)
         self.wcode = eng.wcode if not eng.mix else (hip.SPLIT if self.bwd_split else
-                                                    hip.MIX if (self.w_d is not None and not self.w2) else eng.wcode)
+                                                    hip.MIX if (self.w_d is not None and not self.w2) else
+                                                    hip.MIX_W2I if self.w2i else eng.wcode)
         if self.x_pair:
             assert not self.bwd_split, "a conv of the fp32 head with a two-plane input: %s" % self.out.name
-            self.wcode = {hip.MIX: hip.MIXH, hip.MIX_W2: hip.MIXH_W2}[self.wcode]
+            self.wcode = {hip.MIX: hip.MIXH, hip.MIX_W2: hip.MIXH_W2, hip.MIX_W2I: hip.MIXH_W2I}[self.wcode]
         self.half_by_copy = False       # (True: the fp16 copy of the output comes from a copy pass, Engine._plan_half_copies)
         if self.cbname and self.sname:
             self.eff_bias = torch.empty(Cout, device=eng.device, dtype=torch.float32)
@@ -477,6 +486,28 @@ class ConvStep(Step):
         except hip.VlfbError:
             return None
         return dg, rows
+
+    def _w2_interleaved(self, w2, dg, rows):
+        """Can the two-term DGRAD of this conv run as hip.MATH_F16W2 (the gradient tile of a tap's 64 channels fetched and read
+        once for both weight terms)?  Only where the doubled-tap form runs on the 128-row kernel with the tap cursor: the
+        strided convs keep the class walk, and the launches the library gives to the 256-row pipelined kernel keep that
+        (measured: scratch/r6/skipa_probe.py, profiles/r06_dgrad_shared_tile_probe.txt)."""
+        eng = self.eng
+        if not eng.MIX_W2I or self.group != 1 or self.Cog % 64 or self._ld_d:
+            return False
+        dg2, rows2 = w2
+        doubled = hip.conv_desc(mode=hip.DGRAD, dtype=eng.bcode, out_dtype=eng.bcode, Cs=self.Cog, Cn=self.Cin_k,
+                                alpha=1.0, math=hip.MATH_NATIVE, **rows2, **dg2)
+        plan = hip.conv_plan(doubled)
+        if not (plan.startswith("nt ") and " ut" in plan):
+            return False
+        probe = hip.conv_desc(mode=hip.DGRAD, dtype=eng.bcode, out_dtype=eng.bcode, Cs=self.Cog, Cn=self.Cin_k,
+                              alpha=1.0, math=hip.MATH_F16W2, **rows, **dg)
+        try:
+            hip.conv_workspace_bytes(probe)
+        except hip.VlfbError:
+            return False
+        return True
 
     def has_bias(self):
         return bool(self.cbname or self.bname)
@@ -1906,6 +1937,9 @@ class Engine(object):
                          % os.environ.get("VLFB_SPLIT_MATH"))
     # "mix" dtype: DGRAD contracts the fp16 gradient with TWO fp16 terms of the weight (22 bits; hip.MIX_W2) instead of one
     MIX_W2 = os.environ.get("VLFB_MIX_W2", "1") != "0"
+    # ... as hip.MATH_F16W2 where the doubled-tap form would run on the 128-row kernel: one gradient tile in LDS per pair of
+    # weight tiles (0 = every two-term DGRAD in the doubled-tap form, the round-5 arrangement; A/B switch)
+    MIX_W2I = os.environ.get("VLFB_MIX_W2I", "1") != "0"
     # "mix" dtype: gradients of theta / phi / g of the non-local blocks in fp32, their weight gradients and the dP product of
     # the attention backward as split-bf16 products, the softmax backward on the fp32 probabilities
     MIX_NL_F32 = os.environ.get("VLFB_MIX_NL_F32", "1") != "0"

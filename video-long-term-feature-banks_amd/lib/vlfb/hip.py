@@ -14,9 +14,11 @@ F32, BF16, F16 = 0, 1, 2
 SPLIT = 3                                           # weight-operand format of the split-bf16 path (vlfb.h VLFB_SPLIT)
 MIX, MIX_W2 = 4, 5                                  # ... of the "mix" path (split FPROP copy, fp16 DGRAD copy: plain / two terms)
 MIXH, MIXH_W2 = 6, 7                                # ... of the two-plane fp16 forward (two-term fp16 FPROP copy; DGRAD as MIX / MIX_W2)
+MIX_W2I, MIXH_W2I = 9, 10                           # ... with the two-term DGRAD copy interleaved per 64-channel k-tile (MATH_F16W2)
 F16PAIR = 8                                         # two-plane fp16 tensors (vlfb.h VLFB_F16PAIR; pool descriptors)
 MIX_W2_SCALE = 1024.0                               # vlfb.h VLFB_MIX_W2_SCALE
 MATH_NATIVE, MATH_BF16X3, MATH_BF16X6, MATH_F16X3 = 0, 3, 6, 13     # vlfb_conv_desc.math
+MATH_F16W2 = 12                                     # ... 16-bit DGRAD on two-term weights interleaved per k-tile (MIX_W2I)
 FPROP, DGRAD, WGRAD = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ALGO_AUTO, ALGO_TILE128, ALGO_PIPE256, ALGO_STREAM, ALGO_CLASSES, ALGO_CLASS0 = 0, 1, 2, 3, 4, 5
@@ -318,7 +320,7 @@ def conv_flops(d):
 def conv_bytes(d, has_r=False, has_mask=False):
     """ALGORITHMIC HBM bytes of a launch: every operand read once, the output written once"""
     es = 4 if (d.dtype == F32 or d.math == MATH_F16X3) else 2          # (two fp16 planes = 4 bytes per value)
-    os_ = 4 if (d.out_dtype == F32 or d.math != MATH_NATIVE) else 2
+    os_ = 4 if (d.out_dtype == F32 or d.math not in (MATH_NATIVE, MATH_F16W2)) else 2
     batch = max(d.batch, 1)
     taps = d.kt * d.kh * d.kw
     k = d.kt * d.kh * d.pack_w * 4 if d.pack_w else taps * d.Cs
@@ -327,7 +329,8 @@ def conv_bytes(d, has_r=False, has_mask=False):
     if d.mode == WGRAD:
         return batch * (src + m * d.Cn * es + d.Cn * k * os_)
     out = m * d.Cn
-    return batch * (src + d.Cn * k * es + out * os_ + (out * es if has_r else 0) + (out * es if has_mask else 0))
+    wterms = 2 if d.math == MATH_F16W2 else 1
+    return batch * (src + d.Cn * k * es * wterms + out * os_ + (out * es if has_r else 0) + (out * es if has_mask else 0))
 
 
 def conv_tag(d):
@@ -339,7 +342,7 @@ def conv_tag(d):
 def conv_family(d):
     """(family, MFMA instructions per algorithmic product) of a launch, for the roofline records of bench.py: the kernels
     that run a split-bf16 product issue 3 (6) MFMAs per product, an fp16 DGRAD with two-term weights (the "mix" path: doubled
-    outermost tap dimension of dilation 0) 2, everything else 1.  Families: nt_split / tn_split (csrc/vlfb_gemm_split.hip),
+    outermost tap dimension of dilation 0, or MATH_F16W2) 2, everything else 1.  Families: nt_split / tn_split (csrc/vlfb_gemm_split.hip),
     nt_16 / tn_16 (the 16-bit families), nt_f32 / tn_f32 (exact-fp32 MFMA)."""
     side = "tn" if d.mode == WGRAD else "nt"
     if d.math in (MATH_BF16X3, MATH_BF16X6):
@@ -348,7 +351,7 @@ def conv_family(d):
         return side + "_pair", 3
     if d.dtype == F32:
         return side + "_f32", 1
-    return side + "_16", (2 if (d.mode == DGRAD and d.dt == 0 and d.kt == 2) else 1)
+    return side + "_16", (2 if (d.mode == DGRAD and ((d.dt == 0 and d.kt == 2) or d.math == MATH_F16W2)) else 1)
 
 
 
