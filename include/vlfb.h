@@ -231,7 +231,9 @@ int vlfb_conv_run_planes(const vlfb_conv_desc* d, const void* A, const void* B, 
  *   R_lo / O_lo  16-bit FPROP / DGRAD launches with 16-bit outputs: a TWO-TERM residual / output.  The epilogue computes
  *                v = alpha * acc + bias + R + R_lo; relu; mask  and stores O = T(v), O_lo = T(v - O): a running sum that is
  *                re-rounded by every launch of a chain (the residual-stream gradient of the bottleneck stack) keeps ~22
- *                significant bits while its leading term O stays a plain 16-bit MFMA operand.  Either may be NULL. */
+ *                significant bits while its leading term O stays a plain 16-bit MFMA operand.  Either may be NULL.
+ *                With an fp32 output (out_dtype VLFB_F32 on 16-bit operands) O_lo alone is accepted as well: it receives the
+ *                output ROUNDED to the operand type -- the copy the next 16-bit launch reads, without a cast pass. */
 typedef struct vlfb_conv_args {
   const void* A; const void* B; const void* P; void* O;
   const float* bias; const float* rowscale;

@@ -350,6 +350,11 @@ def test_mix_plan_joins_a_split_forward_to_an_fp16_backward():
     assert gg.x_pair and not gg.o_pair and (gg.d_f.dtype, gg.d_f.out_dtype, gg.d_f.math) == (hip.F16, hip.F32, hip.MATH_F16X3)
     assert att4.s_pair and (att4.d_s.dtype, att4.d_s.out_dtype, att4.d_s.math, att4.d_s.batch) == (hip.F16, hip.F32, hip.MATH_F16X3, att4.B)
     assert th.bwd_f32 and (th.d_w.dtype, th.d_w.math, th.d_w.wgrad_bias) == (hip.F32, hip.MATH_BF16X3, 1)
+    # the two fp32 gradients of a block that a 16-bit launch reads next -- the attention output (into the dP / dg products) and
+    # theta (into the theta conv's DGRAD) -- get their fp16 rounding from the launch that produces them (GradSlot.half_buf)
+    halves_g = sorted(b.name for b in eng.all_blobs if b.root is b and b.slot.half_buf is not None)
+    assert halves_g == sorted("nonlocal_conv%s_%s" % (blk, n) for blk in ("3_1", "3_3", "4_1", "4_3", "4_5") for n in ("theta", "y"))
+    assert all(b.slot.half_buf.dtype == torch.float16 and b.slot.half_buf.numel() == b.numel for b in eng.all_blobs if b.root is b and b.slot.half_buf is not None)
     assert th.out.root.slot.buf.dtype == torch.float32
     att = [s for s in eng.steps if isinstance(s, AttentionStep) and not s.single][0]
     assert att.precise and not att.fused_bwd and (att.d_dp.dtype, att.d_dp.math) == (hip.F32, hip.MATH_BF16X3)

@@ -92,10 +92,13 @@ def test_interleaved_two_term_dgrad(case):
         assert " w2" in hip.conv_plan(d_i), hip.conv_plan(d_i)
         o_i = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt)
         o_2 = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt)
-        hip.conv_run(d_i, G, wi, None, o_i)
+        # (fp32 output: O_lo alone = the output rounded to fp16, the copy a 16-bit reader of this gradient takes)
+        o_h = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=torch.float16) if tdt == torch.float32 else None
+        hip.conv_run(d_i, G, wi, None, o_i, O_lo=o_h)
         hip.conv_run(d_2, G, w2, None, o_2)
         ref = 0.5 * gx
         if tdt == torch.float32:
+            assert torch.equal(o_h, o_i.half()), "the fp16 rounding next to the fp32 output"
             assert rel_err(to_ncthw(o_i), ref) < 2e-6, "fp32 output vs fp64"
             assert rel_err(o_i, o_2) < 2e-6, "vs the doubled-tap launch"
         else:
@@ -134,3 +137,36 @@ def test_interleaved_two_term_dgrad_refusals():
     out = torch.empty(2 * 96 * 64, device=dev(), dtype=torch.float16)
     with pytest.raises(hip.VlfbError):
         hip.call("vlfb_weight_prep", hip.ptr(w), None, None, hip.ptr(out), hip.MIX_W2I, 96, 1, 64)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_fp32_output_of_a_16_bit_launch_leaves_its_rounding(tdt):
+    """vlfb_conv_args.O_lo next to out_dtype VLFB_F32 on 16-bit operands (the 128-row kernel, batched plain rows: the d theta
+    product of a non-local block; the 256-row pipelined kernel: the out conv's DGRAD in res4): O_lo = T(O), bit for bit"""
+    code = hip.dtype_code(tdt)
+    gen = torch.Generator().manual_seed(11)
+    B, M, K, Nc = 3, 200, 160, 136
+    a = gpu(torch.randn(B, M, K, generator=gen), tdt)
+    w = gpu(torch.randn(B, Nc, K, generator=gen) * 0.1, tdt)
+    d = hip.conv_desc(mode=hip.FPROP, dtype=code, out_dtype=hip.F32, N=1, Tr=1, Hr=1, Wr=M, Ts=1, Hs=1, Ws=M, Cs=K, Cn=Nc, batch=B,
+                      a_bstride=M * K, b_bstride=Nc * K, o_bstride=M * Nc, alpha=0.25)
+    o = torch.full((B, M, Nc), float("nan"), device=dev(), dtype=torch.float32)
+    oh = torch.full((B, M, Nc), float("nan"), device=dev(), dtype=tdt)
+    hip.conv_run(d, a, w, None, o, O_lo=oh)
+    assert rel_err(o, 0.25 * torch.einsum("bmk,bnk->bmn", a.double().cpu(), w.double().cpu())) < 1e-5
+    assert torch.equal(oh, o.to(tdt))
+    # the 256-row kernel (1x1x1 DGRAD, 512 columns, K = 1024)
+    N, T, H, W, Cout, Cin = 1, 2, 28, 28, 1024, 512
+    dy = gpu(torch.randn(N, T, H, W, Cout, generator=gen), tdt)
+    wd = gpu(torch.randn(Cin, Cout, generator=gen) * 0.03, tdt)
+    d8 = hip.conv_desc(mode=hip.DGRAD, dtype=code, out_dtype=hip.F32, N=N, Tr=T, Hr=H, Wr=W, Ts=T, Hs=H, Ws=W, Cs=Cout, Cn=Cin,
+                       algo=hip.ALGO_PIPE256)
+    assert hip.conv_plan(d8).startswith("nt8 ")
+    o = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=torch.float32)
+    oh = torch.full((N, T, H, W, Cin), float("nan"), device=dev(), dtype=tdt)
+    hip.conv_run(d8, dy, wd, None, o, O_lo=oh)
+    assert rel_err(o, dy.double().cpu() @ wd.double().cpu().t()) < 1e-5
+    assert torch.equal(oh, o.to(tdt))
+    # not with a low residual term, not on fp32 operands
+    with pytest.raises(hip.VlfbError):
+        hip.conv_run(d8, dy, wd, None, o, R=o, R_lo=oh, O_lo=oh)

@@ -39,6 +39,20 @@ for r in step:
 P('%7s %9s %8s  kernel' % ('calls', 'total_us', 'avg_us'))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     P('%7d %9.1f %8.1f  %s' % (c, t, t / c, n))
+# which kernels occupy which queue in which phase (the main queue carries the forward and the DGRAD chain)
+if loss:
+    for q in sorted(byq, key=lambda q: -byq[q]):
+        for phase, sel in (('forward', lambda r: r[1] < tl), ('backward', lambda r: r[1] >= tl)):
+            part = [r for r in step if r[7] == q and sel(r)]
+            if not part:
+                continue
+            tot = sum(r[2] - r[1] for r in part) / 1e3
+            a2 = collections.OrderedDict()
+            for r in part:
+                e = a2.setdefault(short(r[0]).split('<')[0], [0, 0.0])
+                e[0] += 1; e[1] += (r[2] - r[1]) / 1e3
+            P('queue %s, %s: %d kernels, %.1f us: %s' % (q, phase, len(part), tot, ', '.join(
+                '%s x%d %.0f' % (n, c, t) for n, (c, t) in sorted(a2.items(), key=lambda kv: -kv[1][1])[:18])))
 gaps = []
 ends = t0
 for r in sorted(step, key=lambda r: r[1]):

@@ -1504,10 +1504,13 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
   VLFB_REQUIRE(!sp_pair || (O_lo && (!R || R_lo)), "conv: a two-plane fp16 output needs O_lo (and R_lo with R)");
   VLFB_REQUIRE(!pl.h2 || d->out_dtype == VLFB_F32 || O_lo, "conv: F16X3 math with a 16-bit output writes two planes (O, O_lo)");
   VLFB_REQUIRE(!pl.h2 || !Mask, "conv: F16X3 launches take no mask");
+  // (a 16-bit FPROP / DGRAD with an fp32 output: O_lo = the same values rounded to the operand type, for the 16-bit launches
+  // that read this tensor next)
+  const bool copy16 = O_lo && !R_lo && !pl.sp && !pl.h2 && is16(d->dtype) && d->out_dtype == VLFB_F32 && d->mode != VLFB_CONV_WGRAD;
   if ((R_lo || O_lo) && !sp_pair && !(pl.h2 && d->out_dtype == VLFB_F32 && !R_lo)) {
     // two-term residual / output: the epilogues of the tiled NT families (128 x 128, 256-row pipelined) carry it
-    VLFB_REQUIRE(d->mode != VLFB_CONV_WGRAD && is16(d->dtype) && d->out_dtype == d->dtype && !pl.sp,
-                 "conv: R_lo / O_lo belong to 16-bit FPROP / DGRAD launches with 16-bit outputs");
+    VLFB_REQUIRE(d->mode != VLFB_CONV_WGRAD && is16(d->dtype) && (d->out_dtype == d->dtype || copy16) && !pl.sp,
+                 "conv: R_lo / O_lo belong to 16-bit FPROP / DGRAD launches with 16-bit outputs (O_lo alone: also with an fp32 output)");
     VLFB_REQUIRE(!R_lo || R, "conv: R_lo without R");
     if (pl.skinny || pl.rows64 || pl.nts || (d->mode == VLFB_CONV_FPROP && pl.stemf)) {
       vlfb_conv_desc d2 = *d;

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;
   const char* R2b = p.R2 ? p.R2 + (long long)z * p.r_bs * (long long)sizeof(T) : nullptr;     // low terms (GP::R2 / O2)
-  char* O2b = p.O2 ? p.O2 + (long long)z * p.o_bs * (PAIR ? 2ll : (long long)sizeof(OutT)) : nullptr;
+  char* O2b = p.O2 ? p.O2 + (long long)z * p.o_bs * ((PAIR || sizeof(T) == 2) ? 2ll : (long long)sizeof(OutT)) : nullptr;
   constexpr int EPT = 16 / (int)sizeof(OutT);   // output elements per 16-byte store
   constexpr int TPR = BN / EPT;                 // lanes per tile row
   constexpr int RPP = NTHR / TPR;               // rows per pass
@@ -498,6 +498,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
             // the fp16 backward reads (positive values stay positive, as vlfb_half_copy)
             if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(O2b) + mpos * p.ldo + ncol) =
                          make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2 % EPT], v[3 % EPT]));
+          } else if constexpr (sizeof(T) == 2) {
+            // fp32 output of a 16-bit launch (the "mix" backward: a DGRAD into an fp32 gradient slot): O2 = the same values
+            // rounded to T, for the 16-bit launches that read this gradient next (saves them a cast pass)
+            if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(O2b) + mpos * p.ldo + ncol) =
+                         make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2 % EPT], v[3 % EPT]));
           }
         } else {
           const uint4 hv = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),

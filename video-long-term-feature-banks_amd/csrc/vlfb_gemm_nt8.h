@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
   const char* Rb = p.R ? p.R + (long long)z * p.r_bs * 2 : nullptr;
   const char* Mb = p.Mask ? p.Mask + (long long)z * p.r_bs * 2 : nullptr;
   const char* R2b = p.R2 ? p.R2 + (long long)z * p.r_bs * 2 : nullptr;             // low terms (GP::R2 / O2)
-  char* O2b = p.O2 ? p.O2 + (long long)z * p.o_bs * (PAIR ? 2ll : (long long)sizeof(OutT)) : nullptr;
+  char* O2b = p.O2 ? p.O2 + (long long)z * p.o_bs * 2ll : nullptr;          // (16-bit whatever OutT is: low term / 16-bit copy)
   (void)R2b; (void)O2b;
   constexpr int EPT = 16 / (int)sizeof(OutT);
   constexpr int TPR = BN / EPT;                  // lanes per output row
@@ -358,6 +358,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
           if constexpr (PAIR) {       // O2 = the fp16 copy of an fp32 output (vlfb_gemm_nt.h)
             if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(O2b) + (long long)m * p.ldo + ncol) =
                          make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2 % EPT], v[3 % EPT]));
+          } else {                    // ... of a 16-bit launch: the same values rounded to T
+            if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(O2b) + (long long)m * p.ldo + ncol) =
+                         make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2 % EPT], v[3 % EPT]));
           }
         } else {
           const uint4 hv = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),

@@ -141,12 +141,26 @@ class GradSlot(object):
         self.cur_lo = None
         self.add_lo = None            # handed to the contributor being called: low term of `add` ...
         self.out_lo = None            # ... and where it may leave the low term of what it writes
+        # "mix" dtype, an fp32 slot with ONE contributor whose consumer is a 16-bit launch (the attention output / theta of a
+        # non-local block): the contributing NT launch leaves the gradient rounded to fp16 here as well (vlfb_conv_args.O_lo
+        # next to an fp32 output), so the consumer does not run a cast pass first (Engine.GRAD_HALF_COPY)
+        self.half_buf = None
+        self.half_valid = False
 
     def reset(self):
         self.count = 0
         self.cur = None
         self.cur_lo = None
         self.planes_valid = False
+        self.half_valid = False
+
+    def value_half(self):
+        """the finished fp32 gradient rounded to the 16-bit backward type, if its contributor wrote that copy; else None"""
+        return self.half_buf if (self.half_valid and self.count == self.expected and self.cur is self.buf) else None
+
+    def half_dest(self, out, add, mask):
+        """where the contributor being called may leave the 16-bit copy of what it writes (None: not this time)"""
+        return self.half_buf if (out is self.buf and add is None and mask is None and self.expected == 1) else None
 
     def value_lo(self):
         """low term of the finished gradient, or None"""
@@ -364,6 +378,8 @@ class ConvStep(Step):
             # ("mix": an input whose gradient slot is fp32 -- box_pooled, the attention output of a non-local block -- gets
             # the fp32 accumulators of the fp16 DGRAD as they are, not their fp16 rounding)
             self.dx_f32 = bool(eng.mix and self.x.root.grad_f32)
+            if self.dx_f32 and not self.bwd_split:
+                self.x.root.grad_half_src = True        # (this DGRAD can leave the fp16 rounding of its fp32 output: GradSlot.half_buf)
             self.d_d = hip.conv_desc(mode=hip.DGRAD, dtype=bcode, out_dtype=hip.F32 if self.dx_f32 else bcode, Cs=self.Cog,
                                      Cn=Cin // G, alpha=alpha, math=math_d, **rows, **bplanes, **dg, **ld_d)
             if self.bwd_split:
@@ -379,6 +395,8 @@ class ConvStep(Step):
                     self.d_d_full, self.d_d = self.d_d, sp
                 except hip.VlfbError:
                     self.sparse_dgrad = False
+        if self.bwd_f32 and self.d_d is not None and not self.bwd_split:
+            self.out.root.grad_half = True      # (the fp16 DGRAD reads the fp32 output gradient rounded: GradSlot.half_buf)
         self.d_w = None
         if eng.is_trainable(self.wname):
             self.d_w = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=hip.F32, N=N, Tr=To, Hr=Ho, Wr=Wo, Ts=T,
@@ -613,8 +631,10 @@ class ConvStep(Step):
             # fp32 gradient ("mix", non-local theta / phi / g): WGRAD and the bias sum read it as it is, DGRAD its fp16 copy
             g_w = g
             if self.d_d is not None and not self.bwd_split:
-                g = eng.scratch_act(self.out.numel)
-                hip.call("vlfb_cast", hip.ptr(g_w), hip.F32, hip.ptr(g), eng.bcode, self.out.numel)
+                g = self.out.root.slot.value_half()       # (left by the launch that produced the gradient: GradSlot.half_buf)
+                if g is None:
+                    g = eng.scratch_act(self.out.numel)
+                    hip.call("vlfb_cast", hip.ptr(g_w), hip.F32, hip.ptr(g), eng.bcode, self.out.numel)
         gp = self.out.root.slot.value_planes()         # term planes of the finished output gradient, or None
         if self.residual is not None and self.residual.needs_grad and not self.residual.detached:
             self.residual.root.slot.contribute_alias(g, self.out.root.slot.value_lo())
@@ -630,8 +650,13 @@ class ConvStep(Step):
             # (Engine._plan_head_f32, AttentionStep) the input's gradient slot is fp32: the fp16 DGRAD writes its fp32
             # accumulators there (out_dtype F32; GradSlot adds an earlier contribution in fp32)
             assert self.group == 1 and self.dx_f32
-            self.x.root.slot.contribute(lambda out, add, mask: hip.conv_run(self.d_d, g, self.w_d, None, out),
-                                        supports_add=False, supports_mask=False)
+            xs = self.x.root.slot
+
+            def dgrad_f32(out, add, mask):
+                hb = xs.half_dest(out, add, mask)
+                hip.conv_run(self.d_d, g, self.w_d, None, out, O_lo=hb)
+                xs.half_valid = hb is not None
+            xs.contribute(dgrad_f32, supports_add=False, supports_mask=False)
         elif self.d_d is not None:
             # the gradient operand as planes when it has them and this launch can take them (plain rows or taps that
             # span whole k-tiles at unit stride); the input gradient's planes when this is its last contribution
@@ -851,6 +876,8 @@ class AttentionStep(Step):
         o_g = hip.F32 if self.g.root.grad_f32 else bcode
         self.d_dth = gemm(dtype=bcode, out_dtype=o_th, Cs=L2, Cn=Ci, a_bstride=L1 * L2, b_bstride=Ci * L2, o_bstride=L1 * Ci,
                           alpha=gs_th / self.ds_scale, math=mb, **bpl)
+        if o_th == hip.F32 and bcode != hip.F32 and mb == hip.MATH_NATIVE:
+            self.theta.root.grad_half_src = True        # (AttentionStep._dtheta: the fp16 rounding next to the fp32 output)
         # contract over L1: out[L2][Ci] = sum_l P[l][L2] * A[l][Ci]
         self.d_tn = hip.conv_desc(mode=hip.WGRAD, dtype=bcode, out_dtype=o_g, N=1, Tr=1, Hr=1, Wr=L1, Ts=1,
                                   Hs=1, Ws=L1, Cs=Ci, Cn=L2, batch=B, a_bstride=L1 * Ci, p_bstride=L1 * L2,
@@ -876,7 +903,9 @@ class AttentionStep(Step):
                                  o_bstride=L1 * L2, math=mb, alpha=self.ds_scale / L2, **bpl)
         if not (self.fused_fwd and self.fused_bwd):
             eng.need_scratch_f32(B * L1 * L2 + (B * L1 * Ci if self.precise else 0))
-        self.dy_f32 = bool(self.out.root.grad_f32)         # ("mix": dY arrives in fp32; the fp16 products read a cast)
+        self.dy_f32 = bool(self.out.root.grad_f32)         # ("mix": dY arrives in fp32; the fp16 products read a cast ...
+        if self.dy_f32 and not self.single:
+            self.out.root.grad_half = True                 # ... or the copy its producer leaves: GradSlot.half_buf)
         eng.need_scratch_act(B * L1 * L2 + B * Ci * L2 + (B * L1 * Ci if self.dy_f32 else 0))
 
     def _planes(self, src, nplanes, transpose):
@@ -924,6 +953,17 @@ class AttentionStep(Step):
         hip.call("vlfb_transpose2d", self.g.ptr(), hip.ptr(gT), eng.code, B, L2, Ci)
         hip.conv_run(self.d_y, self.prob.storage(), gT, None, self.out.storage())
 
+    def _dtheta(self, th, dS, phT):
+        """d theta = dS . phi: into theta's slot; a 16-bit product with an fp32 output also leaves the result rounded to the
+        operand type for the theta conv's DGRAD (GradSlot.half_buf)"""
+        copy16 = self.d_dth.out_dtype == hip.F32 and self.d_dth.dtype != hip.F32 and self.d_dth.math == hip.MATH_NATIVE
+
+        def fn(out, add, mask):
+            hb = th.half_dest(out, add, mask) if copy16 else None
+            hip.conv_run(self.d_dth, dS, phT, None, out, O_lo=hb)
+            th.half_valid = hb is not None
+        th.contribute(fn, supports_add=False, supports_mask=False)
+
     def bwd(self):
         eng = self.eng
         B, Ci, L1, L2 = self.B, self.Ci, self.L1, self.L2
@@ -950,8 +990,10 @@ class AttentionStep(Step):
         if self.dy_f32:
             # fp32 dY (the `out` conv's DGRAD accumulators): the split product dP reads it as it is, the fp16 products a cast
             dY32 = dY
-            dY = eng.scratch_act(B * L1 * L2 + B * Ci * L2 + B * L1 * Ci)[B * L1 * L2 + B * Ci * L2:]
-            hip.call("vlfb_cast", hip.ptr(dY32), hip.F32, hip.ptr(dY), eng.bcode, B * L1 * Ci)
+            dY = self.out.root.slot.value_half()          # (left by the `out` conv's DGRAD: GradSlot.half_buf)
+            if dY is None:
+                dY = eng.scratch_act(B * L1 * L2 + B * Ci * L2 + B * L1 * Ci)[B * L1 * L2 + B * Ci * L2:]
+                hip.call("vlfb_cast", hip.ptr(dY32), hip.F32, hip.ptr(dY), eng.bcode, B * L1 * Ci)
         if self.dot:
             # dot-product variant: dS = dP / L2 is the scores-gradient product itself (alpha), no softmax Jacobian
             gg.contribute(lambda out, add, mask: hip.conv_run(self.d_tn, dY, None, P, out),
@@ -972,8 +1014,7 @@ class AttentionStep(Step):
                 phT = self._planes(self.phi.storage(), 2, True)
             else:
                 hip.call("vlfb_transpose2d", self.phi.bptr(), hip.ptr(phT), eng.bcode, B, L2, Ci)
-            th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
-                          supports_add=False, supports_mask=False)
+            self._dtheta(th, dS, phT)
             ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.bstorage(), None, dS, out),
                           supports_add=False, supports_mask=False)
             return
@@ -1005,8 +1046,7 @@ class AttentionStep(Step):
             phT = self._planes(self.phi.storage(), 2, True)
         else:
             hip.call("vlfb_transpose2d", self.phi.bptr(), hip.ptr(phT), eng.bcode, B, L2, Ci)
-        th.contribute(lambda out, add, mask: hip.conv_run(self.d_dth, dS, phT, None, out),
-                      supports_add=False, supports_mask=False)
+        self._dtheta(th, dS, phT)
         ph.contribute(lambda out, add, mask: hip.conv_run(self.d_tn_phi, self.theta.bstorage(), None, dS, out),
                       supports_add=False, supports_mask=False)
 
@@ -1940,6 +1980,9 @@ class Engine(object):
     # ... as hip.MATH_F16W2 where the doubled-tap form would run on the 128-row kernel: one gradient tile in LDS per pair of
     # weight tiles (0 = every two-term DGRAD in the doubled-tap form, the round-5 arrangement; A/B switch)
     MIX_W2I = os.environ.get("VLFB_MIX_W2I", "1") != "0"
+    # "mix": the NT launch that produces an fp32 gradient read next by a 16-bit launch (the attention output and theta of a
+    # non-local block) also writes it rounded to fp16 (vlfb_conv_args.O_lo) instead of a cast pass in front of the reader
+    GRAD_HALF_COPY = os.environ.get("VLFB_GRAD_HALF_COPY", "1") != "0"
     # "mix" dtype: gradients of theta / phi / g of the non-local blocks in fp32, their weight gradients and the dP product of
     # the attention backward as split-bf16 products, the softmax backward on the fp32 probabilities
     MIX_NL_F32 = os.environ.get("VLFB_MIX_NL_F32", "1") != "0"
@@ -2535,6 +2578,9 @@ class Engine(object):
                     b.slot.buf_lo = torch.zeros(nval, device=dev, dtype=gdt)
                 if b.relu:
                     self.want_half(b)             # the finished gradient is masked by the sign of the values
+                if self.mix and self.GRAD_HALF_COPY and getattr(b, "grad_half", False) and getattr(b, "grad_half_src", False) and \
+                        b.grad_f32 and b.slot.expected == 1 and not b.relu:       # (a reader that wants it AND a writer that can)
+                    b.slot.half_buf = torch.zeros(nval, device=dev, dtype=self.btdtype)       # (GradSlot.half_buf)
             if b.pair:
                 b.half = b.tensor[:nval]          # the hi plane IS the fp16 copy the backward reads
             elif b.need_half:
