@@ -9,4 +9,4 @@ rocprofv3 --kernel-trace --stats -d $R/$O/prof_mix -o stats -- python $R/bench.p
 cd $R
 python tools/prof_summary.py $O/prof_mix > $O/rocprofv3_kernel_stats_mix.txt 2>&1
 python tools/timeline.py $O/prof_mix $O/timeline_step_mix.txt > /dev/null 2>&1
-rm -rf $O/prof_mix
+[ -n "$KEEP_DB" ] || rm -rf $O/prof_mix

@@ -53,6 +53,27 @@ if loss:
                 e[0] += 1; e[1] += (r[2] - r[1]) / 1e3
             P('queue %s, %s: %d kernels, %.1f us: %s' % (q, phase, len(part), tot, ', '.join(
                 '%s x%d %.0f' % (n, c, t) for n, (c, t) in sorted(a2.items(), key=lambda kv: -kv[1][1])[:18])))
+# backward: when is only ONE of the queues busy (the head before any parameter gradient exists, the tail of either queue)?
+if loss and len(byq) >= 2:
+    qs = sorted(byq, key=lambda q: -byq[q])[:2]
+    evq = []
+    for r in step:
+        if r[1] >= tl and r[7] in qs and 'sgd_kernel' not in r[0]:
+            evq.append((r[1], 1, r[7])); evq.append((r[2], -1, r[7]))
+    evq.sort()
+    actq = {q: 0 for q in qs}
+    only = {q: 0 for q in qs}
+    both = 0
+    lastt = tl
+    for t, d, q in evq:
+        a, b = actq[qs[0]] > 0, actq[qs[1]] > 0
+        if a and b: both += t - lastt
+        elif a: only[qs[0]] += t - lastt
+        elif b: only[qs[1]] += t - lastt
+        actq[q] += d; lastt = t
+    lastk = {q: max(r[2] for r in step if r[7] == q and r[1] >= tl and 'sgd_kernel' not in r[0]) for q in qs}
+    P('backward: both queues busy %.3f ms, only queue %s %.3f ms, only queue %s %.3f ms; last kernel before the solver ends at +%.3f ms (queue %s) / +%.3f ms (queue %s)' % (
+        both / 1e6, qs[0], only[qs[0]] / 1e6, qs[1], only[qs[1]] / 1e6, (lastk[qs[0]] - tl) / 1e6, qs[0], (lastk[qs[1]] - tl) / 1e6, qs[1]))
 gaps = []
 ends = t0
 for r in sorted(step, key=lambda r: r[1]):
