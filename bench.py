@@ -292,8 +292,9 @@ DTYPE_NOTES = {
     "mix": "forward: trunk activations and weights as TWO fp16 planes (hi + lo, ~22 bits), a product = hi.hi + hi.lo + lo.hi on "
            "v_mfma_f32_16x16x32_f16 (3 MFMAs per product, fp32 accumulate, nothing converted in the k-loop); non-local / FBO internals "
            "fp32 with split-bf16 products; backward on v_mfma_f32_16x16x32_f16 with fp16 gradient storage (the hi plane is the fp16 "
-           "operand) -- two-term fp16 weights in DGRAD, two-term gradients on the residual stream / sums of DGRADs, fp32 gradients + "
-           "split products around the non-local softmax and in the head",
+           "operand) -- two-term fp16 weights in DGRAD (2 MFMAs per product; one gradient tile in LDS per pair of weight tiles where the "
+           "128-row kernel runs it), two-term gradients on the residual stream / sums of DGRADs, fp32 gradients + split products around "
+           "the non-local softmax and in the head",
     "fp16": "fp16 storage and v_mfma_f32_16x16x32_f16 operands end to end, fp32 accumulate, static power-of-two loss scale",
     "bf16": "bf16 storage and v_mfma_f32_16x16x32_bf16 operands end to end, fp32 accumulate",
     "split": "fp32 storage, every contraction as split-bf16 products (3 x v_mfma_f32_16x16x32_bf16 per product) in both directions",
