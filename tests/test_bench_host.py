@@ -64,10 +64,11 @@ def test_pmc_traffic_maps_kernel_names_onto_the_bench_families():
         "void vlfb::(anonymous namespace)::gemm_tn_sp_kernel<128, 128, true, false, 8>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::bf16_t, float, 128, 128, false, false, 8, true>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::f16_t, float, 128, 128, false, false, 8, false>(vlfb::GP)": "tn_16",
-        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, true, false, 128, false, 8, 2, true, false>(vlfb::GP)": "nt_16",
-        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, false, false, 128, false, 8, 2, true, true>(vlfb::GP)": "nt_pair",
-        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, float, 128, 128, true, false, false, 128, false, 8, 2, false, true>(vlfb::GP)": "nt_pair",
-        "void vlfb::(anonymous namespace)::gemm_nt_kernel<float, float, 128, 128, true, false, false, 128, false, 4, 2, false, false>(vlfb::GP)": "nt_f32",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, true, false, 128, false, 8, 2, true, false, false>(vlfb::GP)": "nt_16",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, true, false, 128, false, 8, 2, true, false, true>(vlfb::GP)": "nt_16",      # (W2I: the shared-tile two-term DGRAD)
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, vlfb::f16_t, 128, 128, false, false, false, 128, false, 8, 2, true, true, false>(vlfb::GP)": "nt_pair",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<vlfb::f16_t, float, 128, 128, true, false, false, 128, false, 8, 2, false, true, false>(vlfb::GP)": "nt_pair",
+        "void vlfb::(anonymous namespace)::gemm_nt_kernel<float, float, 128, 128, true, false, false, 128, false, 4, 2, false, false, false>(vlfb::GP)": "nt_f32",
         "void vlfb::(anonymous namespace)::gemm_nt8_kernel<vlfb::f16_t, vlfb::f16_t, 256, 2, false, 98, false>(vlfb::GP)": "nt_16",
         "void vlfb::(anonymous namespace)::gemm_nt8_kernel<vlfb::f16_t, vlfb::f16_t, 256, 1, false, 98, true>(vlfb::GP)": "nt_pair",
         "void vlfb::(anonymous namespace)::stem_wgrad_kernel<vlfb::f16_t>(vlfb::GP)": "tn_16",

@@ -10,12 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def family(name):
-    # the two-plane fp16 instances (vlfb_gemm_pair.hip): PAIR is the LAST template argument of gemm_nt_kernel (13th) /
-    # gemm_nt8_kernel (7th)
+    # the two-plane fp16 instances (vlfb_gemm_pair.hip): PAIR is the 13th template argument of gemm_nt_kernel (W2I follows it),
+    # the 7th of gemm_nt8_kernel
     m = re.search(r"gemm_(nt8?)_kernel<([^>]*)>\(", name)
     if m:
         targs = [a.strip() for a in m.group(2).split(",")]
-        if len(targs) == (13 if m.group(1) == "nt" else 7) and targs[-1] == "true":
+        at = 12 if m.group(1) == "nt" else 6
+        if len(targs) > at and targs[at] == "true":
             return "nt_pair"
     if "gemm_nt_sp_kernel" in name or "gemm_nt_pl_kernel" in name:
         return "nt_split"
