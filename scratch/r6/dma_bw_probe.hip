@@ -30,8 +30,8 @@ __global__ __launch_bounds__(512) void probe(const char* src, unsigned bytes, in
         acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
       }
     }
-    if (MODE == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    base += gridDim.x * 8u * 32768u;
+    if (MODE == 0) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+    base += gridDim.x * 8u * 32768u + 37u * 32768u;       // (a different 32-KiB block every step: no L1 re-use at any footprint)
   }
   if (MODE == 0) {
     __syncthreads();
@@ -52,6 +52,21 @@ int main() {
   hipFuncSetAttribute(reinterpret_cast<const void*>(probe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   printf("%d CUs, nominal clock %.0f MHz; 2 workgroups of 8 waves per CU, 1 KiB per wave instruction\n", cus, clk / 1e6);
   const size_t foot[3] = {2ull << 20, 64ull << 20, 1ull << 30};
+  // in-flight sweep (L2-resident footprint, LDS-DMA): `pieces` KiB per wave between two waits = 16 x pieces KiB in flight per CU;
+  // the 128-row GEMM kernels run at 4 (one 32-KiB tile per 8-wave workgroup, two workgroups per CU)
+  for (int pieces : {2, 4, 6, 8, 12, 16, 32}) {
+    const int grid = cus * 2, iters = 6400 / pieces;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(512), 64 * 1024, 0, buf, (unsigned)foot[0], iters, sink, pieces);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)grid * 8 * pieces * 1024.0 * iters;
+    printf("L2-resident, LDS-DMA, %2d KiB per wave (= %3d KiB per CU) in flight between waits: %7.2f TB/s  %6.1f B/clk/CU\n", pieces, 16 * pieces,
+           bytes / ms / 1e9, bytes / (ms * 1e-3) / clk / cus);
+  }
   for (int f = 0; f < 3; ++f)
     for (int mode = 0; mode < 2; ++mode) {
       const int grid = cus * 2, pieces = 32, iters = 200;

@@ -2,7 +2,10 @@
 import sys
 sys.path.insert(0, 'video-long-term-feature-banks_amd/lib')
 import torch
+import os
 from vlfb import hip
+if os.environ.get('VLFB_LIB'):
+    hip.LIB_PATH = os.path.abspath(os.environ['VLFB_LIB'])      # (an experimental build of the library)
 hip.lib()
 dev = torch.device('cuda:0')
 

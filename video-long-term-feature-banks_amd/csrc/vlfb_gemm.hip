@@ -1537,6 +1537,8 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
   g.R2 = (const char*)R_lo; g.O2 = (char*)O_lo;
   g.pair_io = sp_pair ? 1 : 0;
   g.pair_il = (pl.h2 && d->a_pstride == 32) ? 1 : 0;
+  static const int nt_epi = getenv("VLFB_NT_EPI") ? atoi(getenv("VLFB_NT_EPI")) : 1;       // (A/B switch)
+  g.nt_epi = nt_epi;
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
   if (pl.sp) {

@@ -60,6 +60,10 @@ struct GP {
   int pair_io;
   // VLFB_MATH_F16X3: the two planes INTERLEAVED in groups of 32 k ([row][k / 32][hi 32 | lo 32]; a_ps = b_ps = 32 elements)
   int pair_il;
+  // epilogue traffic -- output rows, residual and mask rows: touched once per launch -- with the non-temporal hint, so that
+  // it streams through the L2 instead of evicting the operand panels the other workgroups of the XCD are re-reading
+  // (VLFB_NT_EPI=0 switches it off; measured per launch and in the step)
+  int nt_epi;
 };
 
 // vlfb_gemm8.hip: 256-row phase-pipelined NT kernel.  bm = 256 | 196 (two wave rows of 98), bn = 256 | 128; mode 0 = plain rows, 1 = gathered
@@ -361,6 +365,31 @@ __device__ __forceinline__ void unpack_elems(const uint4& t, float (&v)[N]) {
       v[(2 * i + 1) % N] = Elem<T>::hi(w[i]);
     }
   }
+}
+
+// 16 / 8-byte epilogue accesses, plain or with the non-temporal hint (GP::nt_epi)
+typedef unsigned int u32x4_vec __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_vec __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st16_epi(bool nt, void* p, uint4 v) {
+  if (nt) { const u32x4_vec t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<u32x4_vec*>(p)); }
+  else *reinterpret_cast<uint4*>(p) = v;
+}
+__device__ __forceinline__ void st16_epi(bool nt, void* p, float4 v) {
+  st16_epi(nt, p, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+}
+__device__ __forceinline__ void st8_epi(bool nt, void* p, uint2 v) {
+  if (nt) { const u32x2_vec t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<u32x2_vec*>(p)); }
+  else *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ uint4 ld16_epi(bool nt, const void* p) {
+  if (nt) { const u32x4_vec t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_vec*>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
+  return *reinterpret_cast<const uint4*>(p);
+}
+// N consecutive elements of T as floats (load_elems), the 16-byte forms through ld16_epi
+template <typename T, int N>
+__device__ __forceinline__ void load_elems_epi(bool nt, const T* p, float (&v)[N]) {
+  if constexpr (N * sizeof(T) == 16) unpack_elems<T, N>(ld16_epi(nt, p), v);
+  else load_elems<T, N>(p, v);
 }
 
 // XCD-aware remap of a linear workgroup id: consecutive ids on one XCD share operand panels.

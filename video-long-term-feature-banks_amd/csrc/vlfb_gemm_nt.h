@@ -272,6 +272,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
   // requested BEFORE the k-loop and arrive while the MFMAs run.
   constexpr bool PREM = PRE && !PAIR;          // (PAIR launches are forward convs: no mask operand)
   constexpr bool PRE2 = PRE && PAIR;           // (PAIR: the residual is two planes -- the low one is requested up front as well)
+  const bool nt = p.nt_epi != 0;             // epilogue rows with the non-temporal hint (GP::nt_epi)
   uint4 rpre[PRE ? NPASS : 1], mpre[PREM ? NPASS : 1], r2pre[PRE2 ? NPASS : 1];
   if (PRE) {
 #pragma unroll
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
       const int m = m0 + gp * RPP + tr;
       const bool ok = m < mrows && ncol < p.Ncols;
       const long long off = (row_pos(ok ? m : 0) * p.ldr + ncol) * (long long)sizeof(T);
-      rpre[gp] = ld16_if(Rb ? Rb : Ab, off, ok && Rb != nullptr);
-      if constexpr (PRE2) r2pre[gp] = ld16_if(R2b ? R2b : Ab, off, ok && R2b != nullptr);
-      if constexpr (PREM) mpre[gp] = ld16_if(Mb ? Mb : Ab, off, ok && Mb != nullptr);
+      rpre[gp] = ld16_epi(nt, src_or_zero(Rb ? Rb : Ab, off, ok && Rb != nullptr));
+      if constexpr (PRE2) r2pre[gp] = ld16_epi(nt, src_or_zero(R2b ? R2b : Ab, off, ok && R2b != nullptr));
+      if constexpr (PREM) mpre[gp] = ld16_epi(nt, src_or_zero(Mb ? Mb : Ab, off, ok && Mb != nullptr));
     }
   }
   (void)R2b; (void)O2b;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
         if (Rb) {
           float r[EPT];
           if (PRE) unpack_elems<T, EPT>(rpre[PRE ? gp : 0], r);
-          else load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
+          else load_elems_epi<T, EPT>(nt, reinterpret_cast<const T*>(Rb) + ridx, r);
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] += r[e];
         }
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
           if (R2b) {                                 // low term of a two-term residual
             float r[EPT];
             if constexpr (PRE2) unpack_elems<T, EPT>(r2pre[PRE2 ? gp : 0], r);
-            else load_elems<T, EPT>(reinterpret_cast<const T*>(R2b) + ridx, r);
+            else load_elems_epi<T, EPT>(nt, reinterpret_cast<const T*>(R2b) + ridx, r);
 #pragma unroll
             for (int e = 0; e < EPT; ++e) v[e] += r[e];
           }
@@ -486,34 +487,34 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GP p) {
         if (Mb && !PAIR) {
           float r[EPT];
           if (PREM) unpack_elems<T, EPT>(mpre[PREM ? gp : 0], r);
-          else load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
+          else load_elems_epi<T, EPT>(nt, reinterpret_cast<const T*>(Mb) + ridx, r);
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
         }
         OutT* o = reinterpret_cast<OutT*>(Ob) + mpos * p.ldo + ncol;
         if (sizeof(OutT) == 4) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          st16_epi(nt, o, make_float4(v[0], v[1], v[2], v[3]));
           if constexpr (PAIR) {
             // fp32 output of a two-plane launch (theta / phi / g of a non-local block): O2 = the fp16 copy of the output that
             // the fp16 backward reads (positive values stay positive, as vlfb_half_copy)
-            if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(O2b) + mpos * p.ldo + ncol) =
-                         make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2 % EPT], v[3 % EPT]));
+            if (O2b) st8_epi(nt, reinterpret_cast<unsigned short*>(O2b) + mpos * p.ldo + ncol,
+                             make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2 % EPT], v[3 % EPT])));
           } else if constexpr (sizeof(T) == 2) {
             // fp32 output of a 16-bit launch (the "mix" backward: a DGRAD into an fp32 gradient slot): O2 = the same values
             // rounded to T, for the 16-bit launches that read this gradient next (saves them a cast pass)
-            if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(O2b) + mpos * p.ldo + ncol) =
-                         make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2 % EPT], v[3 % EPT]));
+            if (O2b) st8_epi(nt, reinterpret_cast<T*>(O2b) + mpos * p.ldo + ncol,
+                             make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2 % EPT], v[3 % EPT])));
           }
         } else {
           const uint4 hv = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
                                       Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
-          *reinterpret_cast<uint4*>(o) = hv;
+          st16_epi(nt, o, hv);
           if (O2b) {                                 // low term: what the rounding of the stored value lost
             float h[EPT];
             unpack_elems<OutT, EPT>(hv, h);
-            *reinterpret_cast<uint4*>(reinterpret_cast<OutT*>(O2b) + mpos * p.ldo + ncol) =
-                make_uint4(Elem<OutT>::pack2(v[0] - h[0], v[1] - h[1]), Elem<OutT>::pack2(v[2 % EPT] - h[2 % EPT], v[3 % EPT] - h[3 % EPT]),
-                           Elem<OutT>::pack2(v[4 % EPT] - h[4 % EPT], v[5 % EPT] - h[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT] - h[6 % EPT], v[7 % EPT] - h[7 % EPT]));
+            st16_epi(nt, reinterpret_cast<OutT*>(O2b) + mpos * p.ldo + ncol,
+                     make_uint4(Elem<OutT>::pack2(v[0] - h[0], v[1] - h[1]), Elem<OutT>::pack2(v[2 % EPT] - h[2 % EPT], v[3 % EPT] - h[3 % EPT]),
+                                Elem<OutT>::pack2(v[4 % EPT] - h[4 % EPT], v[5 % EPT] - h[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT] - h[6 % EPT], v[7 % EPT] - h[7 % EPT])));
           }
         }
       }

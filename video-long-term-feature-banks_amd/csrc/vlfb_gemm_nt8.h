@@ -289,6 +289,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
   constexpr int ROWS_PASS = 256 / NPASS;
   const int tc = tid % TPR, tr = tid / TPR;
   const int ncol = n0 + tc * EPT;
+  const bool nt = p.nt_epi != 0;                 // epilogue rows with the non-temporal hint (GP::nt_epi)
 #pragma unroll
   for (int s = 0; s < NPASS; ++s) {
     if (s > 0) __syncthreads();
@@ -330,14 +331,14 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
         const long long ridx = (long long)m * p.ldr + ncol;
         if (Rb) {
           float r[EPT];
-          load_elems<T, EPT>(reinterpret_cast<const T*>(Rb) + ridx, r);
+          load_elems_epi<T, EPT>(nt, reinterpret_cast<const T*>(Rb) + ridx, r);
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] += r[e];
         }
         if constexpr (sizeof(OutT) == 2) {
           if (R2b) {
             float r[EPT];
-            load_elems<T, EPT>(reinterpret_cast<const T*>(R2b) + ridx, r);
+            load_elems_epi<T, EPT>(nt, reinterpret_cast<const T*>(R2b) + ridx, r);
 #pragma unroll
             for (int e = 0; e < EPT; ++e) v[e] += r[e];
           }
@@ -348,30 +349,30 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GP p) {
         }
         if (Mb) {
           float r[EPT];
-          load_elems<T, EPT>(reinterpret_cast<const T*>(Mb) + ridx, r);
+          load_elems_epi<T, EPT>(nt, reinterpret_cast<const T*>(Mb) + ridx, r);
 #pragma unroll
           for (int e = 0; e < EPT; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
         }
         OutT* o = reinterpret_cast<OutT*>(Ob) + (long long)m * p.ldo + ncol;
         if (sizeof(OutT) == 4) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          st16_epi(nt, o, make_float4(v[0], v[1], v[2], v[3]));
           if constexpr (PAIR) {       // O2 = the fp16 copy of an fp32 output (vlfb_gemm_nt.h)
-            if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(O2b) + (long long)m * p.ldo + ncol) =
-                         make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2 % EPT], v[3 % EPT]));
+            if (O2b) st8_epi(nt, reinterpret_cast<unsigned short*>(O2b) + (long long)m * p.ldo + ncol,
+                             make_uint2(pack_h2_pos(v[0], v[1]), pack_h2_pos(v[2 % EPT], v[3 % EPT])));
           } else {                    // ... of a 16-bit launch: the same values rounded to T
-            if (O2b) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(O2b) + (long long)m * p.ldo + ncol) =
-                         make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2 % EPT], v[3 % EPT]));
+            if (O2b) st8_epi(nt, reinterpret_cast<T*>(O2b) + (long long)m * p.ldo + ncol,
+                             make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2 % EPT], v[3 % EPT])));
           }
         } else {
           const uint4 hv = make_uint4(Elem<OutT>::pack2(v[0], v[1]), Elem<OutT>::pack2(v[2 % EPT], v[3 % EPT]),
                                       Elem<OutT>::pack2(v[4 % EPT], v[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT], v[7 % EPT]));
-          *reinterpret_cast<uint4*>(o) = hv;
+          st16_epi(nt, o, hv);
           if (O2b) {
             float h[EPT];
             unpack_elems<OutT, EPT>(hv, h);
-            *reinterpret_cast<uint4*>(reinterpret_cast<OutT*>(O2b) + (long long)m * p.ldo + ncol) =
-                make_uint4(Elem<OutT>::pack2(v[0] - h[0], v[1] - h[1]), Elem<OutT>::pack2(v[2 % EPT] - h[2 % EPT], v[3 % EPT] - h[3 % EPT]),
-                           Elem<OutT>::pack2(v[4 % EPT] - h[4 % EPT], v[5 % EPT] - h[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT] - h[6 % EPT], v[7 % EPT] - h[7 % EPT]));
+            st16_epi(nt, reinterpret_cast<OutT*>(O2b) + (long long)m * p.ldo + ncol,
+                     make_uint4(Elem<OutT>::pack2(v[0] - h[0], v[1] - h[1]), Elem<OutT>::pack2(v[2 % EPT] - h[2 % EPT], v[3 % EPT] - h[3 % EPT]),
+                                Elem<OutT>::pack2(v[4 % EPT] - h[4 % EPT], v[5 % EPT] - h[5 % EPT]), Elem<OutT>::pack2(v[6 % EPT] - h[6 % EPT], v[7 % EPT] - h[7 % EPT])));
           }
         }
       }

@@ -176,7 +176,7 @@ __device__ __forceinline__ void nt_epilogue(const GP& p, const f32x4_v (&acc)[FN
             make_uint2((uint32_t)f2h(v[0] - h2f(h0)) | ((uint32_t)f2h(v[1] - h2f(h1)) << 16), (uint32_t)f2h(v[2] - h2f(h2)) | ((uint32_t)f2h(v[3] - h2f(h3)) << 16));
         continue;
       }
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ob) + oidx) = make_float4(v[0], v[1], v[2], v[3]);
+      st16_epi(p.nt_epi != 0, reinterpret_cast<float*>(Ob) + oidx, make_float4(v[0], v[1], v[2], v[3]));      // (GP::nt_epi)
       if (planes) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.OP) + oidx;
         const uint32_t h01 = peel(v[0], v[1]), h23 = peel(v[2], v[3]);

@@ -462,20 +462,46 @@ __global__ void global_avgpool_pair_kernel(const f16_t* __restrict__ x, float* _
   }
 }
 // fp32 -> the two fp16 planes, and back
-__global__ void pair_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
+// (pure streaming passes, often next to a GEMM on the other stream: non-temporal accesses keep them out of the L2 that the
+// GEMM's operand panels live in -- stream_ld / stream_st below; VLFB_NT_EPI=0 switches the hint off, as in the GEMM epilogues)
+typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 stream_ld16(bool nt, const void* p) {
+  if (nt) { const u32x4_s t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_s*>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
+  return *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ uint2 stream_ld8(bool nt, const void* p) {
+  if (nt) { const u32x2_s t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_s*>(p)); return make_uint2(t.x, t.y); }
+  return *reinterpret_cast<const uint2*>(p);
+}
+__device__ __forceinline__ void stream_st16(bool nt, void* p, uint4 v) {
+  if (nt) { const u32x4_s t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<u32x4_s*>(p)); }
+  else *reinterpret_cast<uint4*>(p) = v;
+}
+__device__ __forceinline__ void stream_st8(bool nt, void* p, uint2 v) {
+  if (nt) { const u32x2_s t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<u32x2_s*>(p)); }
+  else *reinterpret_cast<uint2*>(p) = v;
+}
+static bool stream_nt() {
+  static const bool on = !(getenv("VLFB_NT_EPI") && atoi(getenv("VLFB_NT_EPI")) == 0);
+  return on;
+}
+__global__ void pair_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n, bool nt) {
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
-    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    const uint4 u = stream_ld16(nt, src + i);
+    const float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
     const unsigned short h0 = f2h(v.x), h1 = f2h(v.y), h2 = f2h(v.z), h3 = f2h(v.w);
-    *reinterpret_cast<uint2*>(dst + i) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
-    *reinterpret_cast<uint2*>(dst + n + i) = make_uint2((uint32_t)f2h(v.x - h2f(h0)) | ((uint32_t)f2h(v.y - h2f(h1)) << 16),
-                                                        (uint32_t)f2h(v.z - h2f(h2)) | ((uint32_t)f2h(v.w - h2f(h3)) << 16));
+    stream_st8(nt, dst + i, make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)));
+    stream_st8(nt, dst + n + i, make_uint2((uint32_t)f2h(v.x - h2f(h0)) | ((uint32_t)f2h(v.y - h2f(h1)) << 16),
+                                           (uint32_t)f2h(v.z - h2f(h2)) | ((uint32_t)f2h(v.w - h2f(h3)) << 16)));
   }
 }
-__global__ void pair_join_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long long n) {
+__global__ void pair_join_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long long n, bool nt) {
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
-    const uint2 h = *reinterpret_cast<const uint2*>(src + i), l = *reinterpret_cast<const uint2*>(src + n + i);
-    *reinterpret_cast<float4*>(dst + i) = make_float4(h2f((unsigned short)(h.x & 0xffffu)) + h2f((unsigned short)(l.x & 0xffffu)), h2f((unsigned short)(h.x >> 16)) + h2f((unsigned short)(l.x >> 16)),
+    const uint2 h = stream_ld8(nt, src + i), l = stream_ld8(nt, src + n + i);
+    const float4 o = make_float4(h2f((unsigned short)(h.x & 0xffffu)) + h2f((unsigned short)(l.x & 0xffffu)), h2f((unsigned short)(h.x >> 16)) + h2f((unsigned short)(l.x >> 16)),
                                                       h2f((unsigned short)(h.y & 0xffffu)) + h2f((unsigned short)(l.y & 0xffffu)), h2f((unsigned short)(h.y >> 16)) + h2f((unsigned short)(l.y >> 16)));
+    stream_st16(nt, dst + i, make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)));
   }
 }
 
@@ -1238,10 +1264,10 @@ extern "C" int vlfb_nthwc_to_ncthw(const void* src, float* dst, int dtype, int64
 }
 // fp32 -> fp16 copy for the "mix" engine's backward (16 bytes read, 8 written per lane and step; positive values stay
 // positive, f2h_pos)
-__global__ void half_copy_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n4, long long n) {
+__global__ void half_copy_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n4, long long n, bool nt) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(src)[i];
-    reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_h2_pos(v.x, v.y), pack_h2_pos(v.z, v.w));
+    const uint4 u = stream_ld16(nt, reinterpret_cast<const float4*>(src) + i);
+    stream_st8(nt, reinterpret_cast<uint2*>(dst) + i, make_uint2(pack_h2_pos(__uint_as_float(u.x), __uint_as_float(u.y)), pack_h2_pos(__uint_as_float(u.z), __uint_as_float(u.w))));
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = f2h_pos(src[(n4 << 2) + threadIdx.x]);
 }
@@ -1249,19 +1275,19 @@ extern "C" int vlfb_half_copy(const float* src, void* dst, int64_t n, vlfb_strea
   VLFB_REQUIRE(src && dst && n >= 0, "half_copy: bad args");
   if (n == 0) return VLFB_OK;
   hipLaunchKernelGGL(half_copy_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     (unsigned short*)dst, (long long)(n / 4), (long long)n);
+                     (unsigned short*)dst, (long long)(n / 4), (long long)n, stream_nt());
   return check_launch("half_copy");
 }
 extern "C" int vlfb_pair_split(const float* src, void* dst_pair, int64_t n, vlfb_stream_t stream) {
   VLFB_REQUIRE(src && dst_pair && n >= 0 && n % 8 == 0, "pair_split: bad args (n must be a multiple of 8)");
   if (n == 0) return VLFB_OK;
-  hipLaunchKernelGGL(pair_split_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst_pair, (long long)n);
+  hipLaunchKernelGGL(pair_split_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst_pair, (long long)n, stream_nt());
   return check_launch("pair_split");
 }
 extern "C" int vlfb_pair_join(const void* src_pair, float* dst, int64_t n, vlfb_stream_t stream) {
   VLFB_REQUIRE(src_pair && dst && n >= 0 && n % 8 == 0, "pair_join: bad args (n must be a multiple of 8)");
   if (n == 0) return VLFB_OK;
-  hipLaunchKernelGGL(pair_join_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src_pair, dst, (long long)n);
+  hipLaunchKernelGGL(pair_join_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src_pair, dst, (long long)n, stream_nt());
   return check_launch("pair_join");
 }
 extern "C" int vlfb_cast(const void* src, int sd, void* dst, int dd, int64_t n, vlfb_stream_t stream) {
