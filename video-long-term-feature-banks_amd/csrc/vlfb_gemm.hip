@@ -1537,8 +1537,13 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
   g.R2 = (const char*)R_lo; g.O2 = (char*)O_lo;
   g.pair_io = sp_pair ? 1 : 0;
   g.pair_il = (pl.h2 && d->a_pstride == 32) ? 1 : 0;
-  static const int nt_epi = getenv("VLFB_NT_EPI") ? atoi(getenv("VLFB_NT_EPI")) : 1;       // (A/B switch)
-  g.nt_epi = nt_epi;
+  // Non-temporal epilogue rows (GP::nt_epi) where a launch moves at least 4 bytes per output element through its epilogue
+  // -- fp32 or two-plane outputs / residuals, two-term gradients: the "mix" and "split" launches, +1.0-1.3 % on their steps --
+  // and not on plain 16-bit launches, whose steps measured -0.25 % with it (their rows are half as large, the next launch
+  // finds more of them still cached).  VLFB_NT_EPI: 0 never, 1 this rule (default), 2 every launch.
+  static const int nt_epi = getenv("VLFB_NT_EPI") ? atoi(getenv("VLFB_NT_EPI")) : 1;
+  const bool wide_epi = pl.h2 || pl.sp || pl.w2i || d->dt == 0 || d->out_dtype == VLFB_F32 || R_lo || O_lo;
+  g.nt_epi = nt_epi >= 2 || (nt_epi == 1 && wide_epi);
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
   if (pl.sp) {

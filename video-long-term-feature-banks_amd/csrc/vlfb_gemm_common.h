@@ -62,7 +62,7 @@ struct GP {
   int pair_il;
   // epilogue traffic -- output rows, residual and mask rows: touched once per launch -- with the non-temporal hint, so that
   // it streams through the L2 instead of evicting the operand panels the other workgroups of the XCD are re-reading
-  // (VLFB_NT_EPI=0 switches it off; measured per launch and in the step)
+  // (set per launch in conv_run_impl, VLFB_NT_EPI; measured per launch and in the step)
   int nt_epi;
 };
 
