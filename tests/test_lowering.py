@@ -249,6 +249,22 @@ def test_mix_falls_back_to_plain_dgrad_weights_where_the_doubled_tap_form_does_n
     assert {s.wcode for s in convs} <= {hip.MIX, hip.MIX_W2, hip.MIXH, hip.MIXH_W2, hip.MIX_W2I, hip.MIXH_W2I} and len({s.wcode for s in convs}) >= 2    # (one weight-prep batch per format: Engine._wprep_table)
 
 
+def test_bank_side_of_the_fbo_head_is_issued_first_on_the_second_stream():
+    """Engine._plan_forward_branches rule (c): the forward steps that do not depend on the clip -- lfb_1x1, its dropout, the
+    phi / g convs of the FBO blocks -- are issued at the start of forward() on the second stream; their consumers on the main
+    stream (the FBO attention steps) wait for an event; nothing that reads the clip is among them"""
+    from vlfb.engine import ConvStep, DropoutStep, AttentionStep
+    cfg, m, eng = plan("ava_r50_lfb_nl", dtype="mix")
+    early = [eng.steps[i] for i in eng._fwd_early]
+    assert [st.outputs[0].name for st in early] == ["lfb_1x1", "lfb_1x1_drop", "lfb_nl0_phi", "lfb_nl0_g", "lfb_nl1_phi", "lfb_nl1_g"]
+    assert all(isinstance(st, (ConvStep, DropoutStep)) for st in early) and set(eng._fwd_early) <= eng._fwd_side
+    for i, st in enumerate(eng.steps):
+        if isinstance(st, AttentionStep) and st.outputs[0].name.startswith("lfb_nl"):
+            assert set(eng._fwd_wait[i]) & set(eng._fwd_early), st.outputs[0].name      # (phi / g arrive from the other stream)
+    cfg, m, eng = plan("charades_r50_baseline", dtype="mix")                         # no bank: nothing to hoist
+    assert eng._fwd_early == []
+
+
 def test_strided_projection_shortcuts_run_their_dgrad_as_an_in_place_accumulate():
     """Engine._plan_sparse_shortcut_dgrads (16-bit backward: fp16, bf16, mix): the DGRADs of res3_0 / res4_0 branch1 -- 1x1x1,
     stride (1, 2, 2) -- are planned as hip.ALGO_CLASS0 (only the rows the conv reads) and their backward step comes BEHIND

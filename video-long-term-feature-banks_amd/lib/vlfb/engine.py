@@ -2852,7 +2852,17 @@ class Engine(object):
         # cross streams carry an event.
         main = torch.cuda.current_stream()
         done = {}
+        if self._fwd_early:
+            # the bank side of the FBO head (rule (c) of _plan_forward_branches): issued first, behind whatever fed the inputs
+            self.wait_event(self.side, self.record_event())
+            with torch.cuda.stream(self.side):
+                for i in self._fwd_early:
+                    self._fwd_step(self.steps[i])
+                    if i in self._fwd_signal:
+                        done[i] = self.record_event(self.side)
         for i, st in enumerate(self.steps):
+            if i in self._fwd_early_set:
+                continue
             on_side = i in self._fwd_side
             stream = self.side if on_side else main
             for j in self._fwd_wait[i]:
@@ -2909,6 +2919,7 @@ class Engine(object):
 
     # independent forward branches on the second stream (Engine.forward)
     FORWARD_BRANCHES = True
+    FORWARD_BANK_SIDE = os.environ.get("VLFB_FORWARD_BANK_SIDE", "1") != "0"       # (rule (c) below; A/B switch)
 
     def _plan_forward_branches(self):
         """which forward steps run on the second stream, and which cross-stream edges need an event"""
@@ -2945,6 +2956,27 @@ class Engine(object):
                                 all(isinstance(steps[c], ConvStep) for c in readers.get(src, [])):
                             side.add(p)
                             side.add(src)
+        # (c) the bank side of the FBO head: steps that do not depend on the clip at all -- lfb -> (dropout) -> lfb_1x1 -> the
+        #     phi / g convs of the FBO blocks -- sit at the END of the step list (the head is built last) but can run from
+        #     the start of the pass: on the second stream they finish under the stem instead of extending the chain
+        early = []
+        if self.FORWARD_BANK_SIDE:
+            clip_dep = set()                          # steps that (transitively) read the clip
+            for i, st in enumerate(steps):
+                reads = [b.root for b in st.inputs]
+                if isinstance(st, ConvStep) and st.residual is not None:
+                    reads.append(st.residual.root)
+                from_clip = any(getattr(r, "is_input", False) and r.name.startswith("data") for r in reads)
+                if from_clip or any(j in clip_dep for j in writers_at[i].values()):
+                    clip_dep.add(i)
+            for i, st in enumerate(steps):
+                reads = [b.root for b in st.inputs]
+                if i not in clip_dep and reads and isinstance(st, (ConvStep, DropoutStep)) and \
+                        all(getattr(r, "is_input", False) or writers_at[i].get(id(r)) in early for r in reads):
+                    early.append(i)
+            side.update(early)
+        self._fwd_early = early                       # issued at the start of forward(), in this order
+        self._fwd_early_set = set(early)
         self._fwd_side = side
         self._fwd_wait = []
         self._fwd_signal = set()
