@@ -335,3 +335,56 @@ def test_split_products_on_presplit_operands(case):
         ws = torch.empty(max(hip.conv_workspace_bytes(desc), 16) // 4, device=dev(), dtype=torch.float32)
         hip.conv_run(desc, Ap, None, Gp, DW, rowscale=gpu(scale), workspace=ws)
         assert rel_err(DW, gw_ref) < TOL3, "wgrad on planes, splits=%d" % splits
+
+
+@pytest.mark.parametrize("M,K,Cn", [(33, 512, 512), (33, 2048, 512), (64, 512, 2048), (7, 128, 40), (1, 512, 520)])
+def test_split_products_on_a_handful_of_rows(M, K, Cn):
+    """gemm_skinny_nt_sp_kernel (csrc/vlfb_gemm_skinny.hip): the FBO convs of the fp32 head on one row per RoI -- plain fp32
+    rows, two-term weight planes (BF16X3), FPROP with bias + residual + ReLU and DGRAD with a mask, against fp64 and against
+    the 128 x 128 split kernel (the same terms, another accumulation order)"""
+    gen = torch.Generator().manual_seed(M * 7 + K)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(Cn, K, generator=gen) * (1.0 / math.sqrt(K))
+    bias = torch.randn(Cn, generator=gen)
+    res = torch.randn(M, Cn, generator=gen)
+    wp = torch.empty(3, Cn, K, device=dev(), dtype=torch.bfloat16)
+    hip.call("vlfb_weight_prep", hip.ptr(gpu(w)), None, hip.ptr(wp), None, hip.SPLIT, Cn, 1, K)
+    rows = dict(N=1, Tr=1, Hr=1, Wr=M, Ts=1, Hs=1, Ws=M, Cs=K, Cn=Cn)
+    base = dict(mode=hip.FPROP, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X3, b_pstride=Cn * K, relu=1, bias_mode=hip.BIAS_COL,
+                alpha=0.5, **rows)
+    d = hip.conv_desc(**base)
+    d128 = hip.conv_desc(algo=hip.ALGO_TILE128, **base)
+    assert hip.conv_plan(d).startswith("nt_skinny_split") and hip.conv_plan(d128).startswith("nt_split")
+    xg, rg, bg = gpu(x), gpu(res), gpu(bias)
+    o = torch.full((M, Cn), float("nan"), device=dev())
+    o128 = torch.full((M, Cn), float("nan"), device=dev())
+    hip.conv_run(d, xg, wp, None, o, bias=bg, R=rg)
+    hip.conv_run(d128, xg, wp, None, o128, bias=bg, R=rg)
+    ref = torch.relu(0.5 * (x.double() @ w.double().t()) + bias.double() + res.double())
+    assert rel_err(o, ref) < TOL3 and rel_err(o, o128) < 2e-6
+    # DGRAD form: rows of the output gradient, the [Cin][Cout] two-term copy, a ReLU mask on the input gradient
+    wd = torch.empty(2, K, Cn, device=dev(), dtype=torch.bfloat16)          # (conv Cn -> K seen from the gradient: "Cout" = Cn)
+    wt = torch.randn(Cn, K, generator=gen) * (1.0 / math.sqrt(Cn))          # conv weight [Cout = Cn][Cin = K]
+    hip.call("vlfb_weight_prep", hip.ptr(gpu(wt)), None, None, hip.ptr(wd), hip.SPLIT, Cn, 1, K)
+    dy = torch.randn(M, Cn, generator=gen)
+    mask = torch.randn(M, K, generator=gen)
+    dd = hip.conv_desc(mode=hip.DGRAD, dtype=hip.F32, out_dtype=hip.F32, math=hip.MATH_BF16X3, b_pstride=K * Cn,
+                       N=1, Tr=1, Hr=1, Wr=M, Ts=1, Hs=1, Ws=M, Cs=Cn, Cn=K)
+    ok_k = Cn % 32 == 0 and Cn >= 128
+    assert hip.conv_plan(dd).startswith("nt_skinny_split" if ok_k else "nt_split")
+    dx = torch.full((M, K), float("nan"), device=dev())
+    hip.conv_run(dd, gpu(dy), wd, None, dx, mask=gpu(mask))
+    ref = torch.where(mask.double() > 0, dy.double() @ wt.double(), torch.zeros(M, K, dtype=torch.float64))
+    assert rel_err(dx, ref) < TOL3
+    # the fp16 copy of the output (o_planes = 1: what the "mix" engine asks of its forward convs) comes out of the same launch
+    dh = hip.conv_desc(o_planes=1, **base)
+    assert hip.conv_plan(dh).startswith("nt_skinny_split")
+    o2 = torch.full((M, Cn), float("nan"), device=dev())
+    oh = torch.full((M, Cn), float("nan"), device=dev(), dtype=torch.float16)
+    hip.conv_run(dh, xg, wp, None, o2, bias=bg, R=rg, O_planes=oh)
+    assert torch.equal(o2, o)
+    want = o.half()
+    want = torch.where((o > 0) & (want == 0), torch.full_like(want, 2.0 ** -24), want)        # (positive stays positive: vlfb_half_copy)
+    assert torch.equal(oh, want)
+    # not with two-plane outputs (the tiled kernel carries that epilogue)
+    assert hip.conv_plan(hip.conv_desc(**dict(base, out_dtype=hip.F16))).startswith("nt_split")

@@ -783,6 +783,7 @@ struct Plan {
   int nts_mode;
   int sp;         // split-bf16 math (vlfb_gemm_split.hip): bf16 terms per operand (2 | 3), 0 = native MFMA of the dtype
   int skinny;     // NT: at most 64 plain rows (vlfb_gemm_skinny.hip)
+  int skinny_sp;  //     ... with split-bf16 math on fp32 rows (two terms, fp32 output without a copy)
   int sp_kind;    //   NT: 0 plain rows, 1 gathered FPROP, 2 gathered DGRAD, 3 packed stem
   int sp_pl;      //   operands arrive as bf16 term planes (WGRAD: both; FPROP / DGRAD: the activation operand)
   int bias_fused; // WGRAD with desc.wgrad_bias: the launch itself produces the column sums of P (gemm_tn_tr_kernel)
@@ -1159,6 +1160,10 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   static const bool skinny_off = getenv("VLFB_SKINNY") && atoi(getenv("VLFB_SKINNY")) == 0;      // (A/B switch)
   pl->skinny = d->mode != VLFB_CONV_WGRAD && d->algo == VLFB_ALGO_AUTO && !skinny_off && !pl->sp && !pl->h2 && !pl->w2i && !pl->rows64 &&
                (d->out_dtype == d->dtype || d->out_dtype == VLFB_F32) && skinny_nt_ok(g, d->dtype, batch, pl->ident);
+  // ... and the same rows in the fp32 head of the "mix" / "split" paths: two-term split-bf16 products (FPROP and DGRAD of the
+  // FBO convs on one row per RoI: 26-29 us each on four 128 x 128 workgroups, 77 us for K = 2048)
+  pl->skinny_sp = d->mode != VLFB_CONV_WGRAD && d->algo == VLFB_ALGO_AUTO && !skinny_off && pl->sp == 2 && !pl->sp_pl &&
+                  d->out_dtype == VLFB_F32 && d->o_planes <= 1 && skinny_nt_split_ok(g, batch, pl->ident);
   pl->rb = 128;    // (64-byte tile rows were measured slower: 314 vs 348 TFLOP/s at the time, twice the barriers)
   pl->pre = 0;
   pl->threads = kThreads;
@@ -1414,7 +1419,8 @@ extern "C" int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64
   } else {
     const char* fam;
     int bm = pl.bm, bn = pl.bn;
-    if (pl.sp) fam = pl.sp_pl ? "nt_planes" : "nt_split";
+    if (pl.skinny_sp) { fam = "nt_skinny_split"; bm = 64; bn = 16; }
+    else if (pl.sp) fam = pl.sp_pl ? "nt_planes" : "nt_split";
     else if (pl.h2 && pl.nt8) { fam = "nt8_pair"; bm = pl.nt8_bm; bn = pl.nt8; }
     else if (pl.h2) fam = "nt_pair";
     else if (h16 && pl.skinny) fam = "nt_skinny";
@@ -1546,7 +1552,8 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
   g.nt_epi = nt_epi >= 2 || (nt_epi == 1 && wide_epi);
   hipStream_t s = (hipStream_t)stream;
   if (!R && !Mask) pl.pre = 0;
-  if (pl.sp) {
+  if (pl.skinny_sp) rc = launch_skinny_nt_split(g, s);
+  else if (pl.sp) {
     if (d->mode == VLFB_CONV_WGRAD && pl.sp_pl) {
       if (pl.ident) launch_tn_tr<bf16_t, float, true, false, true>(pl, s);
       else if (pl.packw) launch_tn_tr<bf16_t, float, false, true, true>(pl, s);

@@ -87,6 +87,8 @@ int launch_wgrad_rows_fat(const GP& gp, int splits, int dtype, hipStream_t s);
 // vlfb_gemm_skinny.hip: plain-row NT products with at most 64 rows (the FBO head's 1x1x1 convs on one row per RoI)
 bool skinny_nt_ok(const GP& gp, int dtype, long long batch, bool ident);
 int launch_skinny_nt(const GP& gp, int dtype, bool out_f32, hipStream_t s);
+bool skinny_nt_split_ok(const GP& gp, long long batch, bool ident);
+int launch_skinny_nt_split(const GP& gp, hipStream_t s);
 
 // vlfb_stem.hip: direct-convolution FPROP of the packed stem (whole output rows per wave, raw input rows in LDS)
 bool stem_fprop_ok(const GP& gp, int pack_w, int dtype, int out_dtype, long long batch);
