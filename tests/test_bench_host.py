@@ -61,6 +61,8 @@ def test_pmc_traffic_maps_kernel_names_onto_the_bench_families():
     names = {
         "void vlfb::(anonymous namespace)::gemm_nt_sp_kernel<2, 128, true, false, false, false, false, 1>(vlfb::GP)": "nt_split",
         "void vlfb::(anonymous namespace)::gemm_nt_pl_kernel<2, 64, false, false>(vlfb::GP)": "nt_split",
+        "vlfb::(anonymous namespace)::gemm_skinny_nt_sp_kernel(vlfb::GP)": "nt_split",
+        "void vlfb::(anonymous namespace)::gemm_skinny_nt_kernel<vlfb::f16_t, float>(vlfb::GP)": "nt_16",
         "void vlfb::(anonymous namespace)::gemm_tn_sp_kernel<128, 128, true, false, 8>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::bf16_t, float, 128, 128, false, false, 8, true>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::f16_t, float, 128, 128, false, false, 8, false>(vlfb::GP)": "tn_16",
