@@ -164,6 +164,53 @@ def test_pair_stem_fprop():
     assert rel_err(got, y_ref) < TOL, rel_err(got, y_ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 50), (1, 3, 224), (3, 2, 17)], ids=["cut_last_block", "full_frame", "two_blocks"])
+@pytest.mark.parametrize("epi", [(True, True), (False, False)], ids=["bias_relu", "plain"])
+def test_pair_stem_direct_kernel_is_bit_identical_to_the_tiled_kernel(shape, epi):
+    """conv1 at the benchmarked width (112-wide output rows): the two-plane DIRECT convolution (csrc/vlfb_stem.hip,
+    stem_fprop_pair_kernel: raw input rows and the tap's weights of both planes in one LDS stage) against the tiled two-plane
+    kernel (algo = TILE128): same (a, b) order, same three MFMAs per accumulator and k-step, same epilogue -- both output
+    planes bit for bit, with row blocks cut by the frame height and temporal padding on both sides; and against fp64"""
+    N, T, H = shape
+    relu, has_bias = epi
+    W, Cout, wpad = 224, 64, 4
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(N, 3, T, H, W, generator=gen)
+    w = torch.randn(Cout, 3, 5, 7, 7, generator=gen) * 0.05
+    bias = torch.randn(Cout, generator=gen) * 0.3
+    xs = torch.zeros(N, T, H, W + 2 * wpad, 4)
+    xs[:, :, :, wpad:wpad + W, :3] = x.permute(0, 2, 3, 4, 1)
+    A = pair_of(xs)
+    wk = torch.zeros(Cout, 5, 7, 8, 4)
+    wk[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
+    Wf = torch.empty(2, Cout, 35, 32, device=dev(), dtype=torch.float16)
+    hip.call("vlfb_weight_prep", hip.ptr(gpu(wk)), None, hip.ptr(Wf), None, hip.MIXH, Cout, 35, 32)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, 112
+    n_out = N * T * Ho * Wo * Cout
+    outs = {}
+    for algo in (hip.ALGO_AUTO, hip.ALGO_TILE128):
+        desc = hip.conv_desc(mode=hip.FPROP, dtype=hip.F16, out_dtype=hip.F16, N=N, Tr=T, Hr=Ho, Wr=Wo, Ts=T, Hs=H, Ws=W + 2 * wpad, Cs=4,
+                             Cn=Cout, pack_w=8, relu=int(relu), bias_mode=hip.BIAS_COL if has_bias else hip.BIAS_NONE, math=hip.MATH_F16X3,
+                             a_pstride=xs.numel(), b_pstride=Cout * 35 * 32, alpha=0.75 / hip.MIX_W2_SCALE, algo=algo,
+                             kt=5, kh=7, kw=7, st=1, sh=2, sw=2, pt=2, ph=3, pw=3 - wpad, dt=1, dh=1, dw=1)
+        assert hip.conv_plan(desc).startswith("stem_fprop_pair" if algo == hip.ALGO_AUTO else "nt_pair"), hip.conv_plan(desc)
+        O = torch.full((2 * n_out,), float("nan"), device=dev(), dtype=torch.float16)
+        hip.conv_run(desc, A, Wf, None, O, bias=gpu(bias) if has_bias else None, O_lo=O[n_out:])
+        torch.cuda.synchronize()
+        outs[algo] = O
+    a, t = outs[hip.ALGO_AUTO], outs[hip.ALGO_TILE128]
+    assert not torch.isnan(a.float()).any()
+    assert torch.equal(a.view(torch.int16), t.view(torch.int16))
+    ref = F.conv3d(x.double(), w.double(), None, (1, 2, 2), (2, 3, 3)) * 0.75
+    if has_bias:
+        ref = ref + bias.double().view(1, -1, 1, 1, 1)
+    if relu:
+        ref = torch.relu(ref)
+        assert float((a[:n_out].float() == 0).float().mean()) > 0.2
+    got = to_ncthw(pair_value(a, (N, T, Ho, Wo, Cout)))
+    assert rel_err(got, ref) < TOL, rel_err(got, ref)
+
+
 def test_split_launch_with_two_plane_output():
     """the `out` conv of a non-local block (nonlocal_helper.py:123-160): fp32 attention output in (split-bf16 products), the
     block input added as a two-plane residual, a two-plane output"""

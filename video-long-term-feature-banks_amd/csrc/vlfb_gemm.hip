@@ -1153,6 +1153,11 @@ int make_plan(const vlfb_conv_desc* d, Plan* pl) {
   pl->stemf = d->mode == VLFB_CONV_FPROP && pl->packw && d->algo == VLFB_ALGO_AUTO && !pl->h2 &&
               (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
               stem_fprop_ok(g, d->pack_w, d->dtype, d->out_dtype, batch);
+  // ... and its two-plane form (fp16 planes in and out; one 134-KB stage, vlfb_stem.hip)
+  static const bool pair_stem_off = getenv("VLFB_PAIR_STEM_DIRECT") && atoi(getenv("VLFB_PAIR_STEM_DIRECT")) == 0;     // (A/B switch)
+  if (pl->h2 && !pair_stem_off && d->mode == VLFB_CONV_FPROP && pl->packw && d->algo == VLFB_ALGO_AUTO && d->out_dtype == VLFB_F16 &&
+      (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) && stem_fprop_pair_ok(g, d->pack_w, batch))
+    pl->stemf = 1;
   pl->rows64 = d->mode != VLFB_CONV_WGRAD && !pl->packw && !pl->ident && d->algo == VLFB_ALGO_AUTO && !pl->h2 && !pl->w2i &&
                (d->bias_mode == VLFB_BIAS_NONE || d->bias_mode == VLFB_BIAS_COL) &&
                conv_rows64_ok(g, d->mode, d->dtype, d->out_dtype, batch);
@@ -1421,6 +1426,7 @@ extern "C" int vlfb_conv_plan_describe(const vlfb_conv_desc* d, char* buf, int64
     int bm = pl.bm, bn = pl.bn;
     if (pl.skinny_sp) { fam = "nt_skinny_split"; bm = 64; bn = 16; }
     else if (pl.sp) fam = pl.sp_pl ? "nt_planes" : "nt_split";
+    else if (pl.h2 && pl.stemf) fam = "stem_fprop_pair";
     else if (pl.h2 && pl.nt8) { fam = "nt8_pair"; bm = pl.nt8_bm; bn = pl.nt8; }
     else if (pl.h2) fam = "nt_pair";
     else if (h16 && pl.skinny) fam = "nt_skinny";
@@ -1518,7 +1524,7 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
     VLFB_REQUIRE(d->mode != VLFB_CONV_WGRAD && is16(d->dtype) && (d->out_dtype == d->dtype || copy16) && !pl.sp,
                  "conv: R_lo / O_lo belong to 16-bit FPROP / DGRAD launches with 16-bit outputs (O_lo alone: also with an fp32 output)");
     VLFB_REQUIRE(!R_lo || R, "conv: R_lo without R");
-    if (pl.skinny || pl.rows64 || pl.nts || (d->mode == VLFB_CONV_FPROP && pl.stemf)) {
+    if (pl.skinny || pl.rows64 || pl.nts || (d->mode == VLFB_CONV_FPROP && pl.stemf && !pl.h2)) {      // (the two-plane stem writes O / O_lo itself)
       vlfb_conv_desc d2 = *d;
       d2.algo = VLFB_ALGO_TILE128;
       rc = cached_plan(&d2, &pl);
@@ -1562,7 +1568,8 @@ static int conv_run_impl(const vlfb_conv_desc* d, const void* A, const void* B, 
     } else if (d->mode == VLFB_CONV_WGRAD) rc = launch_tn_split(g, pl.bm, pl.bn, pl.ident, pl.packw, pl.grid, pl.lds, s);
     else if (pl.sp_pl) rc = launch_nt_planes(g, pl.sp, pl.bn, pl.sp_kind, pl.grid, pl.lds, s);
     else rc = launch_nt_split(g, pl.sp, pl.bn, pl.sp_kind, pl.ut != 0, pl.grid, pl.lds, s);
-  } else if (pl.h2 && pl.nt8) rc = launch_nt8_pair(g, pl.nt8_bm, pl.nt8, pl.nt8_mode, d->out_dtype == VLFB_F32, s);
+  } else if (pl.h2 && pl.stemf && !R && !Mask) rc = launch_stem_fprop_pair(g, s);
+  else if (pl.h2 && pl.nt8) rc = launch_nt8_pair(g, pl.nt8_bm, pl.nt8, pl.nt8_mode, d->out_dtype == VLFB_F32, s);
   else if (pl.h2) rc = launch_nt_pair(g, pl.bn, pl.ident, pl.pre != 0, d->out_dtype == VLFB_F32, pl.grid, pl.lds, s);
   else if (d->dtype == VLFB_F32) rc = dispatch<float, float>(d, pl, s);
   else if (d->dtype == VLFB_F16) rc = d->out_dtype == VLFB_F32 ? dispatch<f16_t, float>(d, pl, s) : dispatch<f16_t, f16_t>(d, pl, s);

@@ -93,6 +93,8 @@ int launch_skinny_nt_split(const GP& gp, hipStream_t s);
 // vlfb_stem.hip: direct-convolution FPROP of the packed stem (whole output rows per wave, raw input rows in LDS)
 bool stem_fprop_ok(const GP& gp, int pack_w, int dtype, int out_dtype, long long batch);
 int launch_stem_fprop(const GP& gp, int dtype, hipStream_t s);
+bool stem_fprop_pair_ok(const GP& gp, int pack_w, long long batch);      // (two fp16 planes in and out: VLFB_MATH_F16X3)
+int launch_stem_fprop_pair(const GP& gp, hipStream_t s);
 
 // vlfb_conv_rows.hip: direct-convolution FPROP / unit-stride DGRAD of 1x3x3 convs with 64 -> 64 channels (weights
 // resident in LDS, input rows rolling through a ring); mode = VLFB_CONV_FPROP | VLFB_CONV_DGRAD

@@ -202,6 +202,184 @@ __global__ __launch_bounds__(512) void stem_fprop_kernel(const GP p, const int h
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same direct convolution on TWO fp16 planes per operand (VLFB_MATH_F16X3: conv1 of the "mix" forward; the tiled
+// two-plane kernel runs it at 1.27-1.41 ms, bound by the 14 GB of im2col'd activation tiles it DMAs).  Both planes of the
+// raw input rows and of the tap's weights make one stage of 2 x (39 + 28) KB = 134 KB, so there is no second stage: a
+// stage is loaded, waited for and computed in turn (the load is ~1/4 of the compute, and the rows come out of the L2 the
+// neighbouring frames of the XCD stripe just filled).  A k-step is 22 fragment reads for 84 MFMAs -- per accumulator
+// wl.xh, wh.xl, wh.xh, in the (a, b) order of the tiled kernel, so the two planes written (O = hi, O2 = lo) are
+// bit-identical to its output (tests/test_pair_gpu.py).
+template <int MT, int KH>
+__global__ __launch_bounds__(512) void stem_fprop_pair_kernel(const GP p, const int hblocks, const int ntiles, const int tpw) {
+  typedef f16x8_v vec_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int rbytes = p.Ws * 8;
+  const int ppr = rbytes >> 4;
+  const int nrows = (kStemWaves - 1) * p.sh + KH;
+  const int in_bytes = nrows * rbytes;                       // one plane of the staged rows
+  constexpr int wbytes = KH * 4096;                          // one plane of a tap's weights
+  // stage: [rows hi][rows lo][W hi][W lo]
+  float* bias_l = reinterpret_cast<float*>(smem + 2 * (in_bytes + wbytes));
+  if (tid < 64) bias_l[tid] = p.bias_mode == VLFB_BIAS_COL ? p.bias[tid] : 0.f;
+
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.B, p.b_bytes);
+  const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.O, (unsigned)p.M * (unsigned)p.ldo * 2u);
+  const __amdgpu_buffer_rsrc_t rsO2 = make_rsrc(p.O2, (unsigned)p.M * (unsigned)p.ldo * 2u);
+  const unsigned shift = (unsigned)(-p.pw) * 8u;
+  const unsigned x_plane = (unsigned)p.a_ps * 2u, w_plane = (unsigned)p.b_ps * 2u;     // byte distance of the lo planes
+
+  constexpr int RI = 5, WI = (KH * 256 + 511) / 512;
+  const int tid16 = tid * 16;
+  unsigned woff[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int id = tid + 512 * i;
+    const int chunk = id & 3, r = (id >> 2) & 63, ks = id >> 8;
+    const int c = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);     // permuted channel order (see above)
+    woff[i] = ks < KH ? (unsigned)(c * p.ldb + ks * 32 + (chunk ^ ((0 - (r >> 2)) & 3)) * 8) * 2u : kOOB;
+  }
+
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_beg = wg * tpw, tile_end = min(ntiles, tile_beg + tpw);
+  const int nst = max(0, tile_end - tile_beg) * p.kt;
+  const unsigned lds0 = lds_addr_of(smem);
+
+  f32x4_v acc[MT][4];
+  const int a_lane = l15 * p.sw * 8 + g * 16;
+  const int w_lane = 2 * in_bytes + l15 * 64 + ((g ^ ((0 - (l15 >> 2)) & 3)) << 4);
+
+  for (int s = 0; s < nst; ++s) {
+    const int tile = tile_beg + s / p.kt, a = s - (s / p.kt) * p.kt;
+    const int hb = tile % hblocks, nt = tile / hblocks;
+    const int t = nt % p.Tr, n = nt / p.Tr;
+    // ---- load the stage (every wave is done with the previous one behind the barrier) ----------------------------
+    asm volatile("s_barrier" ::: "memory");
+    {
+      const int tin = t * p.st - p.pt + a;
+      const bool tok = (unsigned)tin < (unsigned)p.Ts;
+      const int rel0 = (hb * kStemWaves * p.sh - p.ph) * rbytes;
+      const unsigned fbyte = (unsigned)((n * p.Ts + tin) * p.Hs) * (unsigned)rbytes + shift;
+      const unsigned wsoff = (unsigned)(a * KH * 64);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int k = 0; k < RI; ++k) {
+          if (tid + 512 * k < nrows * ppr) {
+            const int rel = rel0 + k * 8192 + tid16;
+            const bool ok = tok && (unsigned)rel < (unsigned)(p.Hs * rbytes);
+            const unsigned off = ok ? fbyte + (unsigned)rel + (pl ? x_plane : 0u) : kOOB;
+            bufglds16_hidden(rsX, off, 0u, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + pl * in_bytes + (k * 512 + wave * 64) * 16)));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+          if (tid + 512 * i < KH * 256)
+            bufglds16_hidden(rsW, woff[i] == kOOB ? kOOB : woff[i] + (pl ? w_plane : 0u), wsoff,
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 2 * in_bytes + pl * wbytes + (i * 512 + wave * 64) * 16)));
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (a == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    }
+    const char* arow = smem + wave * p.sh * rbytes + a_lane;
+    const char* wrow = smem + w_lane;
+#pragma unroll
+    for (int b = 0; b < KH; ++b) {
+      vec_t wh[4], wl[4], xh[MT], xl[MT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wh[j] = *reinterpret_cast<const vec_t*>(wrow + b * 4096 + j * 1024);
+        wl[j] = *reinterpret_cast<const vec_t*>(wrow + wbytes + b * 4096 + j * 1024);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        xh[m] = *reinterpret_cast<const vec_t*>(arow + b * rbytes + m * 16 * p.sw * 8);
+        xl[m] = *reinterpret_cast<const vec_t*>(arow + in_bytes + b * rbytes + m * 16 * p.sw * 8);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = V16<f16_t>::mma(wl[j], xh[m], acc[m][j]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = V16<f16_t>::mma(wh[j], xl[m], acc[m][j]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = V16<f16_t>::mma(wh[j], xh[m], acc[m][j]);
+    }
+    if (a == p.kt - 1) {
+      // ---- epilogue in registers (lane = position l15 of fragment m, channels q*32 + g*8 .. +7): hi and lo planes ----
+      const int h = hb * kStemWaves + wave;
+      if (h < p.Hr) {
+        const int row0 = (nt * p.Hr + h) * p.Wr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const unsigned oo = (unsigned)((row0 + m * 16 + l15) * p.ldo + g * 8) * 2u;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[e * 4 + r] = __fmul_rn(acc[m][2 * q + e][r], p.alpha);
+            if (p.bias_mode == VLFB_BIAS_COL) {
+              const float4 b0 = *reinterpret_cast<const float4*>(bias_l + q * 32 + g * 8);
+              const float4 b1 = *reinterpret_cast<const float4*>(bias_l + q * 32 + g * 8 + 4);
+              v[0] = __fadd_rn(v[0], b0.x); v[1] = __fadd_rn(v[1], b0.y); v[2] = __fadd_rn(v[2], b0.z); v[3] = __fadd_rn(v[3], b0.w);
+              v[4] = __fadd_rn(v[4], b1.x); v[5] = __fadd_rn(v[5], b1.y); v[6] = __fadd_rn(v[6], b1.z); v[7] = __fadd_rn(v[7], b1.w);
+            }
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x4_s o, ol;
+            uint32_t w4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[e] = Elem<f16_t>::pack2(v[2 * e], v[2 * e + 1]);
+            o.x = w4[0]; o.y = w4[1]; o.z = w4[2]; o.w = w4[3];
+            uint32_t l4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              l4[e] = Elem<f16_t>::pack2(__fsub_rn(v[2 * e], Elem<f16_t>::lo(w4[e])), __fsub_rn(v[2 * e + 1], Elem<f16_t>::hi(w4[e])));
+            ol.x = l4[0]; ol.y = l4[1]; ol.z = l4[2]; ol.w = l4[3];
+            if (p.nt_epi) {            // (aux = 2: the non-temporal hint, GP::nt_epi)
+              __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(oo + q * 64u), 0, 2);
+              __builtin_amdgcn_raw_buffer_store_b128(ol, rsO2, (int)(oo + q * 64u), 0, 2);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(oo + q * 64u), 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(ol, rsO2, (int)(oo + q * 64u), 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_stem_fprop_pair_t(const GP& gp, int hblocks, int ntiles, int tpw, unsigned nwg, size_t lds, hipStream_t s) {
+  auto kernel = stem_fprop_pair_kernel<7, 7>;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    configured = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), lds, s, gp, hblocks, ntiles, tpw);
+  return check_launch("conv kernel (stem, direct, fp16 planes)");
+}
+
 template <typename T>
 int launch_stem_fprop_t(const GP& gp, int hblocks, int ntiles, int tpw, unsigned nwg, size_t lds, hipStream_t s) {
   auto kernel = stem_fprop_kernel<T, 7, 7>;
@@ -231,6 +409,39 @@ bool stem_fprop_ok(const GP& gp, int pack_w, int dtype, int out_dtype, long long
   if (lds > 160 * 1024) return false;
   if ((long long)gp.M * gp.ldo * 2 >= (1ll << 31)) return false;
   return true;
+}
+
+// ... and the two-plane form: fp16 planes in and out, one 134-KB stage
+bool stem_fprop_pair_ok(const GP& gp, int pack_w, long long batch) {
+  if (batch != 1) return false;
+  if (pack_w != 8 || gp.Ncols != 64 || gp.kh != 7 || gp.Wr != 112 || gp.sw != 2 || gp.pw > 0 || gp.dt != 1 || gp.dh != 1) return false;
+  if (gp.ldo % 8 || gp.ldb % 8 || gp.K != gp.kt * 7 * 32) return false;
+  if ((gp.Wr - 1) * gp.sw + 8 - gp.pw > gp.Ws) return false;
+  const int nrows = (kStemWaves - 1) * gp.sh + 7;
+  const long long ppr = (long long)gp.Ws * 8 / 16;
+  if ((gp.Ws * 8) % 16 || nrows * ppr > 5 * 512) return false;
+  const size_t lds = 2 * ((size_t)nrows * gp.Ws * 8 + 7 * 4096) + 256;
+  if (lds > 160 * 1024) return false;
+  if ((long long)gp.M * gp.ldo * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
+int launch_stem_fprop_pair(const GP& gp, hipStream_t s) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    ncu = n / 8 * 8;
+  }
+  const int hblocks = (gp.Hr + kStemWaves - 1) / kStemWaves;
+  const long long ntiles = (long long)(gp.M / (gp.Hr * gp.Wr)) * hblocks;
+  long long nwg = (ntiles + 7) / 8 * 8;
+  if (nwg > ncu) nwg = ncu;
+  const int tpw = (int)((ntiles + nwg - 1) / nwg);
+  const int nrows = (kStemWaves - 1) * gp.sh + 7;
+  const size_t lds = 2 * ((size_t)nrows * gp.Ws * 8 + 7 * 4096) + 256;
+  return launch_stem_fprop_pair_t(gp, hblocks, (int)ntiles, tpw, (unsigned)nwg, lds, s);
 }
 
 int launch_stem_fprop(const GP& gp, int dtype, hipStream_t s) {
