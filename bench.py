@@ -41,7 +41,7 @@ for _p in (os.path.join(ROOT, "video-long-term-feature-banks_amd", "lib"), ROOT)
 
 MFMA16_PEAK, MFMA32_PEAK = 2500.0, 157.3         # MI355X dense MFMA peaks, TFLOP/s: 16-bit operands / exact fp32 (MI355X_MICROARCH.md)
 FAMILY_KERNELS = collections.OrderedDict([
-    ("nt_pair", "gemm_nt_kernel<f16, PAIR> (two-plane fp16 implicit-GEMM conv FPROP: three fp16 MFMAs per product on pre-split operands; the `mix` forward)"),
+    ("nt_pair", "gemm_nt_kernel<f16, PAIR> / gemm_nt8_kernel<f16, PAIR> / stem_fprop_pair_kernel (two-plane fp16 implicit-GEMM conv FPROP: three fp16 MFMAs per product on pre-split operands; the `mix` forward)"),
     ("nt_split", "gemm_nt_sp_kernel / gemm_nt_pl_kernel / gemm_skinny_nt_sp_kernel (split-bf16 implicit-GEMM conv FPROP / DGRAD + NT attention products on fp32 storage)"),
     ("nt_16", "gemm_nt_kernel / gemm_nt8_kernel / gemm_nts_kernel / stem_fprop_kernel / conv_rows64_kernel / gemm_skinny_nt_kernel "
               "(16-bit implicit-GEMM conv FPROP + DGRAD, NT attention products)"),

@@ -62,6 +62,8 @@ def test_pmc_traffic_maps_kernel_names_onto_the_bench_families():
         "void vlfb::(anonymous namespace)::gemm_nt_sp_kernel<2, 128, true, false, false, false, false, 1>(vlfb::GP)": "nt_split",
         "void vlfb::(anonymous namespace)::gemm_nt_pl_kernel<2, 64, false, false>(vlfb::GP)": "nt_split",
         "vlfb::(anonymous namespace)::gemm_skinny_nt_sp_kernel(vlfb::GP)": "nt_split",
+        "void vlfb::(anonymous namespace)::stem_fprop_pair_kernel<7, 7>(vlfb::GP, int, int, int)": "nt_pair",
+        "void vlfb::(anonymous namespace)::stem_fprop_kernel<vlfb::f16_t, 7, 7>(vlfb::GP, int, int, int)": "nt_16",
         "void vlfb::(anonymous namespace)::gemm_skinny_nt_kernel<vlfb::f16_t, float>(vlfb::GP)": "nt_16",
         "void vlfb::(anonymous namespace)::gemm_tn_sp_kernel<128, 128, true, false, 8>(vlfb::GP)": "tn_split",
         "void vlfb::(anonymous namespace)::gemm_tn_tr_kernel<vlfb::bf16_t, float, 128, 128, false, false, 8, true>(vlfb::GP)": "tn_split",

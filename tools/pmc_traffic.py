@@ -18,6 +18,8 @@ def family(name):
         at = 12 if m.group(1) == "nt" else 6
         if len(targs) > at and targs[at] == "true":
             return "nt_pair"
+    if "stem_fprop_pair_kernel" in name:          # conv1 of the two-plane forward (vlfb_stem.hip)
+        return "nt_pair"
     if "gemm_nt_sp_kernel" in name or "gemm_nt_pl_kernel" in name or "gemm_skinny_nt_sp_kernel" in name:
         return "nt_split"
     if "gemm_tn_sp_kernel" in name or re.search(r"gemm_tn_tr_kernel<.*, true>\(", name):
